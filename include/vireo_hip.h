@@ -1,0 +1,185 @@
+/*
+ * vireo_hip.h -- C ABI of libvireo_hip.so: the MI355X (gfx950) implementation of the
+ * vireoSNP variational-EM hot path.
+ *
+ * The reference (vireoSNP 0.5.9, pure Python) has no FFI layer; its boundary for this
+ * path is the Python API (class Vireo, class BinomMixtureVB, vireo_wrap).  This header is
+ * what a ctypes binding of that API calls.  Each entry point names the reference
+ * interface (file:line under /root/reference) whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; vrx_last_error() gives the
+ *     thread-local message of the last failing call.
+ *   - all pointers are HOST pointers to caller-owned memory; the library copies in/out
+ *     and retains nothing across calls (device state lives behind the opaque handles).
+ *   - dense arrays are C-contiguous float64 in the reference's own shapes:
+ *       ID_prob (n_cell, n_donor)   GT_prob (n_var, n_donor, n_gt)
+ *       beta_mu/beta_sum (theta_rows, n_gt) for Vireo [theta_rows = n_var in ASE mode
+ *       else 1], (n_var, n_donor) for BinomMixtureVB.
+ *   - one host thread per handle; distinct handles may be driven concurrently.
+ */
+#ifndef VIREO_HIP_H
+#define VIREO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vrx_problem vrx_problem; /* AD/DP resident in HBM, both orientations   */
+typedef struct vrx_model vrx_model;     /* variational state + priors + scratch in HBM */
+typedef struct vrx_comm vrx_comm;       /* RCCL communicator (restart shard)           */
+
+#define VRX_OK 0
+#define VRX_ERR_ARG (-1)
+#define VRX_ERR_HIP (-2)
+#define VRX_ERR_NOMEM (-3)
+#define VRX_ERR_UNSUPPORTED (-4)
+#define VRX_ERR_COMM (-5)
+
+const char* vrx_last_error(void);
+int vrx_device_count(int* n);
+/* name / CU count / HBM bytes of a device (for logs and bench.py) */
+int vrx_device_info(int device, char* name, int name_len, int* n_cu, int64_t* hbm_bytes);
+
+/* ---- the sparse count matrices -------------------------------------------------------
+ * AD and DP (n_var x n_cell), given once, as ONE CSC pattern (the union of both patterns,
+ * row indices strictly increasing inside a column) carrying an (ad, dp) pair per entry.
+ * Replaces: the scipy.sparse operands of Vireo.fit (vireoSNP/utils/vireo_model.py:278)
+ * and BinomMixtureVB.fit (vireoSNP/utils/bmm_model.py:204); "BD = DP - AD"
+ * (vireo_model.py:168,190,228; bmm_model.py:122,136) is never materialised.
+ * Builds the variant-major (CSR) copy and the segment tables on the way in. */
+int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int64_t nnz,
+                       const int64_t* csc_colptr /* n_cell+1 */,
+                       const int32_t* csc_rowidx /* nnz */,
+                       const int32_t* ad /* nnz */, const int32_t* dp /* nnz */,
+                       vrx_problem** out);
+void vrx_problem_destroy(vrx_problem* p);
+
+/* sum over entries with dp>0 of float32(min(log C(dp,ad), 700)), accumulated in float64.
+ * Replaces: np.sum(get_binom_coeff(AD, DP))  (vireoSNP/utils/vireo_base.py:7-22; called at
+ * vireo_model.py:313 and bmm_model.py:239).  Computed once per problem and cached. */
+int vrx_problem_binom_const(vrx_problem* p, double* sum_out);
+
+/* per-cell count of variants with dp>0 (vireoSNP/vireo.py:191, "n_vars") */
+int vrx_problem_n_vars(vrx_problem* p, int32_t* out /* n_cell */);
+
+/* ---- model ------------------------------------------------------------------------- */
+#define VRX_KIND_VIREO 0 /* class Vireo            vireoSNP/utils/vireo_model.py:11 */
+#define VRX_KIND_BMM 1   /* class BinomMixtureVB   vireoSNP/utils/bmm_model.py:9    */
+
+typedef struct {
+    int32_t kind;         /* VRX_KIND_*                                                  */
+    int32_t n_donor;      /* K                                                           */
+    int32_t n_gt;         /* T (Vireo only; vireo_model.py:61)                           */
+    int32_t learn_gt;     /* Vireo.learn_GT      (vireo_model.py:65)                     */
+    int32_t learn_theta;  /* Vireo.learn_theta   (vireo_model.py:67)                     */
+    int32_t ase_mode;     /* Vireo.ASE_mode      (vireo_model.py:66): theta per variant  */
+    int32_t fix_beta_sum; /* fix_beta_sum        (vireo_model.py:68, bmm_model.py:52)    */
+    int32_t reserved;
+} vrx_model_cfg;
+
+int vrx_model_create(vrx_problem* p, const vrx_model_cfg* cfg, vrx_model** out);
+void vrx_model_destroy(vrx_model* m);
+
+/* Upload the variational state (attributes ID_prob, GT_prob, beta_mu, beta_sum of the
+ * reference objects: vireo_model.py:84-104, bmm_model.py:69-83).  A NULL pointer leaves
+ * that array as it is on the device.  GT_prob is ignored for VRX_KIND_BMM. */
+int vrx_model_set_state(vrx_model* m, const double* ID_prob, const double* GT_prob,
+                        const double* beta_mu, const double* beta_sum);
+int vrx_model_get_state(vrx_model* m, double* ID_prob, double* GT_prob, double* beta_mu,
+                        double* beta_sum);
+
+/* Priors (Vireo.set_prior vireo_model.py:107-137; BinomMixtureVB.set_prior
+ * bmm_model.py:87-105).  ID_prior: id_rows = 0 -> uniform 1/K (pointer ignored), 1 -> one
+ * row broadcast to every cell, n_cell -> full.  GT_prior: gt_rows = 0 -> uniform 1/T,
+ * 1 -> one (K,T) slab broadcast over variants, n_var -> full.  Priors are given as
+ * probabilities (not logs); rows are re-normalised for the KL terms exactly like
+ * scipy.stats.entropy does (vireo_model.py:237-238).  theta priors have the shape of
+ * beta_mu (prior_rows = 1 or the state's row count). */
+int vrx_model_set_prior(vrx_model* m, const double* ID_prior, int64_t id_rows,
+                        const double* GT_prior, int64_t gt_rows,
+                        const double* theta_s1_prior, const double* theta_s2_prior,
+                        int64_t theta_prior_rows);
+
+/* The coordinate-ascent loop.
+ * Replaces Vireo._fit_VB (vireo_model.py:251-276) / BinomMixtureVB._fit_BV
+ * (bmm_model.py:178-201): same update order, same convergence test, same "it" on exit.
+ *   elbo_trace[0 .. *it_out] receives EVERY computed ELBO (without the binomial
+ *   constant), i.e. one more than the reference keeps: the reference returns
+ *   ELBO[:it] -- the host mirrors that truncation.
+ *   warn_flags: bit0 = "lower bound decreases" seen, bit1 = "did not converge".
+ * Continues from the state currently on the device (warm restart, vireo_wrap.py:94). */
+int vrx_model_fit(vrx_model* m, int32_t max_iter, int32_t min_iter, double epsilon_conv,
+                  int32_t delay_fit_theta, double* elbo_trace /* max_iter */,
+                  int32_t* it_out, int32_t* warn_flags);
+
+/* Single coordinate updates, for the public step methods:
+ *   VRX_STEP_THETA  Vireo.update_theta_size (vireo_model.py:165) / bmm_model.py:133
+ *   VRX_STEP_GT     Vireo.update_GT_prob    (vireo_model.py:204)
+ *   VRX_STEP_ID     Vireo.update_ID_prob    (vireo_model.py:187) -> logLik_ID kept on device
+ *                   BMM: get_E_logLik + update_ID_prob (bmm_model.py:118,147)
+ *   VRX_STEP_LOGLIK recompute logLik_ID only (get_ELBO(None, AD, DP), vireo_model.py:227)
+ *   VRX_STEP_ELBO   get_ELBO with the logLik_ID on the device (vireo_model.py:236-248) */
+#define VRX_STEP_THETA 1
+#define VRX_STEP_GT 2
+#define VRX_STEP_ID 3
+#define VRX_STEP_LOGLIK 4
+#define VRX_STEP_ELBO 5
+#define VRX_STEP_SOFTMAX 6 /* ID_prob <- softmax(logLik_ID on device + log ID_prior): the tail of
+                              update_ID_prob alone (bmm_model.py:153-154 with logLik_ID given) */
+int vrx_model_step(vrx_model* m, int32_t which, double* elbo_out /* VRX_STEP_ELBO only */);
+int vrx_model_get_loglik(vrx_model* m, double* logLik_ID /* n_cell x n_donor */);
+int vrx_model_set_loglik(vrx_model* m, const double* logLik_ID);
+/* the four ELBO terms of the last VRX_STEP_ELBO / fit iteration:
+ * LB_p, KL_ID, KL_GT, KL_theta (vireo_model.py:236-245) */
+int vrx_model_get_elbo_parts(vrx_model* m, double* parts4);
+
+/* One-shot cell log-likelihood against caller-supplied genotype/theta tables:
+ *   logLik[m,c] = sum_n sum_g GT[n,c,g] * (AD[n,m] psi1[g] + BD[n,m] psi2[g] - DP[n,m] psis[g])
+ * with psi*(n_rows_psi x G): the 3*G transposed products of predict_doublet
+ * (vireoSNP/utils/vireo_doublet.py:53-62), C = K + K(K-1)/2 columns, G = 6 classes.
+ * If prob_out is non-NULL it receives softmax_c(logLik + log ID_prior)
+ * (vireo_doublet.py:67-68; ID_prior rows as in vrx_model_set_prior). */
+int vrx_problem_cell_loglik(vrx_problem* p, int64_t n_col, int64_t n_class,
+                            const double* GT /* n_var x n_col x n_class */,
+                            const double* psi1, const double* psi2, const double* psis,
+                            int64_t psi_rows /* 1 or n_var */,
+                            const double* ID_prior, int64_t id_rows,
+                            double* logLik /* n_cell x n_col */,
+                            double* prob_out /* n_cell x n_col, may be NULL */);
+
+/* ---- timing (bench.py roofline leg) ---------------------------------------------------
+ * When enabled, every launch of a pass kernel is bracketed by hipEvents on the model's
+ * stream; totals are read back after a sync.  Kernel ids: */
+#define VRX_KERN_VARIANT_PASS 0 /* variant-major sparse pass (AD,DP)*ID_prob          */
+#define VRX_KERN_CELL_PASS 1    /* cell-major sparse pass (AD,DP)^T*W                 */
+#define VRX_KERN_DENSE 2        /* all dense/epilogue kernels together                */
+#define VRX_KERN_COUNT 3
+int vrx_model_profile(vrx_model* m, int32_t enable);
+int vrx_model_profile_read(vrx_model* m, double* ms_total /* VRX_KERN_COUNT */,
+                           int64_t* launches /* VRX_KERN_COUNT */);
+/* run `n_iter` full iterations with no convergence test and no host sync in between
+ * (the timed region of bench.py); returns wall ms measured with hipEvents on the stream. */
+int vrx_model_run_iters(vrx_model* m, int32_t n_iter, int32_t theta_from_iter,
+                        double* elbo_trace /* n_iter */, double* ms_out);
+
+/* ---- restart shard over RCCL ---------------------------------------------------------
+ * vireo_wrap.py:74-91 farms n_init restarts to a multiprocessing.Pool and takes
+ * argmax(ELBO_[-1]).  Here restarts are sharded one process per GPU and the per-restart
+ * ELBOs are all-gathered over RCCL/xGMI. */
+#define VRX_UNIQUE_ID_BYTES 128
+int vrx_comm_unique_id(uint8_t* id /* VRX_UNIQUE_ID_BYTES */);
+int vrx_comm_create(int device, int rank, int world, const uint8_t* id, vrx_comm** out);
+void vrx_comm_destroy(vrx_comm* c);
+/* all ranks contribute n_local doubles; out has world*n_local doubles, rank-major */
+int vrx_comm_allgather_f64(vrx_comm* c, const double* local, int64_t n_local, double* out);
+int vrx_comm_barrier(vrx_comm* c);
+/* broadcast a host buffer of doubles from `root` (winner's state to rank 0 / everyone) */
+int vrx_comm_bcast_f64(vrx_comm* c, double* buf, int64_t n, int root);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIREO_HIP_H */

@@ -1,0 +1,310 @@
+"""GPU parity tests: the HIP path (through the Python mirror -> ctypes -> C ABI) against
+(1) the golden vectors captured from the real reference and (2) the CPU oracle on the same
+seeded inputs.  Bar (BASELINE.json north_star): bit-exact assignment indices and iteration
+counts; ID_prob / GT_prob / ELBO within 1e-5 relative.  The tolerance used here is
+RTOL = 1e-5 as stated; ATOL only absorbs sub-denormal noise on probabilities that underflow.
+"""
+import numpy as np
+import pytest
+from scipy.sparse import csc_matrix, csr_matrix
+
+from oracle import vireo_oracle as O
+from tests import gold
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+ATOL = 1e-290
+
+
+@pytest.fixture(scope="module")
+def va():
+    import vireo_amd
+    from vireo_amd import _lib
+    _lib.require_gpu()          # fail loudly: there is no CPU fallback
+    return vireo_amd
+
+
+def close(a, b, rtol=RTOL, atol=ATOL):
+    np.testing.assert_allclose(np.asarray(a), np.asarray(b), rtol=rtol, atol=atol)
+
+
+def check_state(m, g, pre, gt=True):
+    close(m.ID_prob, g[pre + "ID_prob"])
+    if gt:
+        close(m.GT_prob, g[pre + "GT_prob"])
+    close(m.beta_mu, g[pre + "beta_mu"])
+    close(m.beta_sum, g[pre + "beta_sum"])
+    assert np.array_equal(np.argmax(m.ID_prob, 1), np.argmax(g[pre + "ID_prob"], 1))
+
+
+def model_from(va, g, pre, **kw):
+    m = va.Vireo(n_cell=g[pre + "ID_prob"].shape[0], n_var=g[pre + "GT_prob"].shape[0],
+                 n_donor=g[pre + "ID_prob"].shape[1], ID_prob_init=g[pre + "ID_prob"],
+                 GT_prob_init=g[pre + "GT_prob"], beta_mu_init=g[pre + "beta_mu"].copy(),
+                 beta_sum_init=g[pre + "beta_sum"].copy(), **kw)
+    m.ID_prob = g[pre + "ID_prob"].copy()
+    m.GT_prob = g[pre + "GT_prob"].copy()
+    return m
+
+
+# ---------------------------------------------------------------- golden: single kernels
+def test_binom_const(va):
+    g = gold.load("binom_const")
+    AD, DP = gold.c1()
+    c = va.device_counts(AD, DP).binom_const()
+    assert c.dtype == np.float32
+    close(c, g["c1"], rtol=1e-6)
+    mAD, mDP = gold.mito()                      # exercises the 700 clamp (DP up to 85197)
+    close(va.device_counts(mAD, mDP).binom_const(), g["mito"], rtol=1e-6)
+
+
+def test_onestep_each_update(va):
+    g = gold.load("c1_onestep")
+    AD, DP = gold.c1()
+    m = model_from(va, g, "s0_")
+    m.update_theta_size(AD, DP)
+    check_state(m, g, "s1_")
+    m.update_GT_prob(AD, DP)
+    check_state(m, g, "s2_")
+    L = m.update_ID_prob(AD, DP)
+    check_state(m, g, "s3_")
+    close(L, g["logLik_ID"], rtol=1e-9)
+    close(m.get_ELBO(L, AD, DP), g["ELBO"], rtol=1e-9)
+    close(m.get_ELBO(None, AD, DP), g["ELBO_recompute"], rtol=1e-9)
+
+
+# ---------------------------------------------------------------- golden: full traces
+def test_trace_and_warm_restart(va):
+    g = gold.load("c1_trace_seed2")
+    AD, DP = gold.c1()
+    np.random.seed(2)
+    m = va.Vireo(n_var=AD.shape[0], n_cell=AD.shape[1], n_donor=4)
+    assert np.array_equal(m.ID_prob, g["init_ID_prob"])     # RNG stream consumed identically
+    assert np.array_equal(m.GT_prob, g["init_GT_prob"])
+    m.fit(AD, DP, min_iter=5, max_iter=20, delay_fit_theta=3, verbose=False)
+    assert len(m.ELBO_) == int(g["n_first"])
+    check_state(m, g, "mid_")
+    m.fit(AD, DP, min_iter=5, verbose=False)
+    assert len(m.ELBO_) == len(g["ELBO_"]) == 79
+    close(m.ELBO_, g["ELBO_"])
+    check_state(m, g, "end_")
+    print("max rel ELBO err %.3e" % np.max(np.abs(m.ELBO_ / g["ELBO_"] - 1)))
+
+
+@pytest.mark.parametrize("tag,kw", [("ase", dict(ASE_mode=True)),
+                                    ("fixsum", dict(fix_beta_sum=True)),
+                                    ("notheta", dict(learn_theta=False))])
+def test_flags(va, tag, kw):
+    g = gold.load("c1_flag_" + tag)
+    AD, DP = gold.c1()
+    np.random.seed(2)
+    m = va.Vireo(n_var=AD.shape[0], n_cell=AD.shape[1], n_donor=4, **kw)
+    m.fit(AD, DP, max_iter=12, verbose=False)
+    assert len(m.ELBO_) == len(g["ELBO_"])
+    close(m.ELBO_, g["ELBO_"])
+    check_state(m, g, "end_")
+
+
+@pytest.mark.parametrize("tag,learn", [("fixedGT", False), ("priorGT", True)])
+def test_gt_prior(va, tag, learn):
+    g = gold.load("c1_flag_" + tag)
+    AD, DP = gold.c1()
+    np.random.seed(2)
+    m = va.Vireo(n_var=AD.shape[0], n_cell=AD.shape[1], n_donor=4, learn_GT=learn,
+                 GT_prob_init=g["GT_prior_in"].copy())
+    m.set_prior(GT_prior=g["GT_prior_in"].copy())
+    m.fit(AD, DP, max_iter=12, verbose=False)
+    assert len(m.ELBO_) == len(g["ELBO_"])
+    close(m.ELBO_, g["ELBO_"])
+    check_state(m, g, "end_")
+
+
+# ---------------------------------------------------------------- golden: vireo_wrap
+@pytest.mark.parametrize("name,kw", [
+    ("c1_wrap_seed2_init1", dict(n_donor=4, n_init=1, random_seed=2)),
+    ("c1_wrap_seed2_init4", dict(n_donor=4, n_init=4, random_seed=2)),
+    ("c1_wrap_seed2_nodoublet", dict(n_donor=3, n_init=2, random_seed=2, check_doublet=False)),
+    ("c1_wrap_seed1_init50", dict(n_donor=4, n_init=50, random_seed=1)),
+])
+def test_wrap(va, name, kw, capsys):
+    g = gold.load(name)
+    AD, DP = gold.c1()
+    rv = va.vireo_wrap(AD, DP, **kw)
+    capsys.readouterr()
+    close(rv["LB_list"], g["LB_list"])
+    assert np.argmax(rv["LB_list"]) == np.argmax(g["LB_list"])
+    close(rv["LB_doublet"], g["LB_doublet"])
+    for k in ("ID_prob", "GT_prob", "doublet_prob", "theta_shapes", "theta_mean", "theta_sum"):
+        close(rv[k], g[k])
+    close(rv["doublet_LLR"], g["doublet_LLR"], rtol=1e-5, atol=1e-8)
+    assert np.array_equal(np.argmax(rv["ID_prob"], 1), np.argmax(g["ID_prob"], 1))
+    if kw.get("check_doublet", True):
+        assert np.array_equal(np.argmax(rv["doublet_prob"], 1), np.argmax(g["doublet_prob"], 1))
+
+
+# ---------------------------------------------------------------- golden: clone mode
+def test_bmm_mito_known_answer(va):
+    g = gold.load("mito_bmm_k3_seed1")
+    AD, DP = gold.mito()
+    b = va.BinomMixtureVB(n_var=AD.shape[0], n_cell=AD.shape[1], n_donor=3)
+    b.fit(AD, DP, min_iter=30, n_init=50, random_seed=1, verbose=False)
+    assert len(b.ELBO_iters) == len(g["ELBO_iters"])
+    close(b.ELBO_iters, g["ELBO_iters"])
+    close(b.ELBO_iters[-1], -190779.74335041404)        # examples/vireoSNP_clones.ipynb
+    close(b.ELBO_inits, g["ELBO_inits"])
+    close(b.ID_prob, g["ID_prob"])
+    close(b.beta_mu, g["beta_mu"])
+    close(b.beta_sum, g["beta_sum"])
+    assert np.array_equal(np.argmax(b.ID_prob, 1), np.argmax(g["ID_prob"], 1))
+
+
+def test_bmm_trace(va):
+    g = gold.load("mito_bmm_k4_trace")
+    AD, DP = gold.mito()
+    np.random.seed(5)
+    b = va.BinomMixtureVB(n_var=AD.shape[0], n_cell=AD.shape[1], n_donor=4)
+    assert np.array_equal(b.ID_prob, g["ID_prob_init"])
+    b._fit_BV(AD, DP, max_iter=15, min_iter=5, verbose=False)
+    assert len(b.ELBO_iters) == len(g["ELBO_iters"])
+    close(b.ELBO_iters, g["ELBO_iters"])
+    close(b.ID_prob, g["ID_prob"])
+    close(b.beta_mu, g["beta_mu"])
+    close(b.beta_sum, g["beta_sum"])
+
+
+# ---------------------------------------------------------------- golden: other K
+@pytest.mark.parametrize("tag", ["k3", "k16", "k5"])
+def test_synthetic_golden(va, tag):
+    g = gold.load("synth_" + tag)
+    AD, DP = gold.unpack(g)
+    n, m_ = AD.shape
+    k = g["init_ID_prob"].shape[1]
+    np.random.seed(1)
+    m = va.Vireo(n_var=n, n_cell=m_, n_donor=k)
+    m.fit(AD, DP, min_iter=5, max_iter=20, delay_fit_theta=3, verbose=False)
+    assert len(m.ELBO_) == len(g["ELBO_"])
+    close(m.ELBO_, g["ELBO_"])
+    check_state(m, g, "end_")
+    dbl, sing, llr = va.predict_doublet(m, AD, DP)
+    close(dbl, g["doublet_prob"])
+    close(sing, g["singlet_prob"])
+    close(llr, g["doublet_LLR"], rtol=1e-5, atol=1e-8)
+    close(m.GT_prob, g["GT_prob_after_doublet"])
+
+
+# ---------------------------------------------------------------- oracle: input formats
+def test_input_formats_agree(va):
+    AD, DP = gold.c1()
+    outs = []
+    for conv in (lambda X: X, lambda X: csr_matrix(X), lambda X: X.astype(np.float64),
+                 lambda X: X.toarray()):
+        np.random.seed(4)
+        m = va.Vireo(n_var=AD.shape[0], n_cell=AD.shape[1], n_donor=3)
+        m.fit(conv(AD), conv(DP), max_iter=8, verbose=False)
+        outs.append((m.ELBO_.copy(), m.ID_prob.copy()))
+    for e, p in outs[1:]:
+        assert np.array_equal(e, outs[0][0]) and np.array_equal(p, outs[0][1])
+
+
+# ---------------------------------------------------------------- oracle: edge cases
+def _ragged_case(seed=0):
+    """empty cells, empty variants, one variant covering > 4096 cells and one cell covering
+    > 4096 variants (both take the split-segment path), AD entries without DP."""
+    rng = np.random.default_rng(seed)
+    N, M = 6000, 5000
+    dp = (rng.random((N, M)) < 0.002) * (1 + rng.poisson(1.0, (N, M)))
+    dp[7, :] = 1 + rng.poisson(2.0, M)            # long variant row (5000 entries)
+    dp[:, 11] = 1 + rng.poisson(2.0, N)           # long cell column (6000 entries)
+    dp[100:120, :] = 0                            # empty variants
+    dp[:, 200:230] = 0                            # empty cells
+    ad = rng.binomial(dp, 0.4)
+    ad[5, 300] = 2 if dp[5, 300] == 0 else ad[5, 300]     # AD entry outside DP's pattern
+    dp[6, 301], ad[6, 301] = 0, 3
+    return csc_matrix(ad), csc_matrix(dp)
+
+
+@pytest.mark.parametrize("K", [2, 7])
+def test_ragged_and_split_segments(va, K):
+    AD, DP = _ragged_case()
+    np.random.seed(3)
+    ref = O.vireo_new(AD.shape[1], AD.shape[0], K)
+    np.random.seed(3)
+    dev = va.Vireo(n_var=AD.shape[0], n_cell=AD.shape[1], n_donor=K)
+    O.vireo_fit(ref, AD, DP, max_iter=8)
+    dev.fit(AD, DP, max_iter=8, verbose=False)
+    assert len(dev.ELBO_) == len(ref.ELBO_)
+    close(dev.ELBO_, ref.ELBO_)
+    close(dev.ID_prob, ref.ID_prob)
+    close(dev.GT_prob, ref.GT_prob)
+    # empty cells keep the prior: uniform posterior
+    close(dev.ID_prob[200:230], 1.0 / K)
+
+
+def test_bmm_long_rows_vs_oracle(va):
+    """clone-mode shape: few variants, many cells, ~90 % dense => every variant row is split
+    over many segments."""
+    rng = np.random.default_rng(1)
+    N, M, K = 12, 30000, 5
+    mask = rng.random((N, M)) < 0.9
+    dp = rng.poisson(30, (N, M)) * mask
+    z = rng.integers(0, K, M)
+    af = rng.beta(0.3, 3, (N, K))
+    ad = rng.binomial(dp, af[:, z])
+    AD, DP = csc_matrix(ad), csc_matrix(dp)
+    np.random.seed(2)
+    ref = O.bmm_new(M, N, K)
+    O.bmm_fit_vb(ref, AD, DP, max_iter=12, min_iter=5)
+    np.random.seed(2)
+    dev = va.BinomMixtureVB(n_var=N, n_cell=M, n_donor=K)
+    dev._fit_BV(AD, DP, max_iter=12, min_iter=5, verbose=False)
+    assert len(dev.ELBO_iters) == len(ref.ELBO_iters)
+    close(dev.ELBO_iters, ref.ELBO_iters)
+    close(dev.ID_prob, ref.ID_prob)
+    close(dev.beta_mu, ref.beta_mu)
+    close(dev.beta_sum, ref.beta_sum)
+
+
+def test_wide_donor_count_vs_oracle(va):
+    """K = 70 > 64 lanes: column-chunked sparse pass and looping softmax."""
+    AD, DP = O.synth_donor(400, 300, 5, 0.1, seed=2)
+    K = 70
+    np.random.seed(6)
+    ref = O.vireo_new(300, 400, K)
+    np.random.seed(6)
+    dev = va.Vireo(n_var=400, n_cell=300, n_donor=K)
+    O.vireo_fit(ref, AD, DP, max_iter=6)
+    dev.fit(AD, DP, max_iter=6, verbose=False)
+    close(dev.ELBO_, ref.ELBO_)
+    close(dev.ID_prob, ref.ID_prob)
+    close(dev.GT_prob, ref.GT_prob)
+
+
+# ---------------------------------------------------------------- oracle: BASELINE config 2
+def test_config2_vs_oracle(va):
+    """synthetic N=10k x M=5k, K=4, ~1 % nnz (BASELINE.json configs[1]) with the timing
+    protocol's seeds."""
+    AD, DP = O.synth_donor(10000, 5000, 4, 0.01, seed=0)
+    np.random.seed(1)
+    ref = O.vireo_new(5000, 10000, 4)
+    np.random.seed(1)
+    dev = va.Vireo(n_var=10000, n_cell=5000, n_donor=4)
+    O.vireo_fit(ref, AD, DP, min_iter=5, max_iter=20, delay_fit_theta=3)
+    dev.fit(AD, DP, min_iter=5, max_iter=20, delay_fit_theta=3, verbose=False)
+    assert len(dev.ELBO_) == len(ref.ELBO_)
+    close(dev.ELBO_, ref.ELBO_)
+    close(dev.ID_prob, ref.ID_prob)
+    close(dev.GT_prob, ref.GT_prob)
+    assert np.array_equal(np.argmax(dev.ID_prob, 1), np.argmax(ref.ID_prob, 1))
+
+
+def test_determinism(va):
+    AD, DP = O.synth_donor(3000, 2000, 16, 0.03, seed=5)
+    runs = []
+    for _ in range(2):
+        np.random.seed(9)
+        m = va.Vireo(n_var=3000, n_cell=2000, n_donor=16)
+        m.fit(AD, DP, max_iter=10, verbose=False)
+        runs.append((m.ELBO_.copy(), m.ID_prob.copy(), m.GT_prob.copy()))
+    for a, b in zip(runs[0], runs[1]):
+        assert np.array_equal(a, b)          # fixed-order reductions: bitwise reproducible

@@ -1,0 +1,158 @@
+"""CPU-only tests: the C ABI exports what include/vireo_hip.h declares, the host logic
+(count canonicalisation, restart sharding with gloo at world size 2, K x K helpers), and
+the loud failure of the product path when no GPU is present."""
+import os
+import pickle
+import re
+import socket
+import subprocess
+import sys
+import ctypes
+
+import numpy as np
+import pytest
+from scipy.sparse import csc_matrix, csr_matrix, coo_matrix
+
+import __graft_entry__ as entry
+from tests import gold
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="session", autouse=True)
+def built():
+    entry.build()
+
+
+def test_abi_exports_every_declared_symbol():
+    from vireo_amd import _lib
+    text = open(os.path.join(ROOT, "include", "vireo_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = set(re.findall(r"\b(vrx_[a-z0-9_]+)\s*\(", text))
+    assert len(declared) >= 25
+    h = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(h, name), "library does not export " + name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+
+
+def test_error_reporting_without_compute():
+    from vireo_amd import _lib
+    n = ctypes.c_int(-1)
+    assert _lib.lib().vrx_device_count(ctypes.byref(n)) == 0 and n.value >= 0
+    rc = _lib.lib().vrx_problem_binom_const(None, None)
+    assert rc < 0 and b"null" in _lib.lib().vrx_last_error()
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import vireo_amd
+    from vireo_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    AD, DP = gold.c1()
+    m = vireo_amd.Vireo(n_var=AD.shape[0], n_cell=AD.shape[1], n_donor=3)
+    with pytest.raises(_lib.VrxError):
+        m.fit(AD, DP, max_iter=2, verbose=False)
+    with pytest.raises(_lib.VrxError):
+        vireo_amd.BinomMixtureVB(n_var=AD.shape[0], n_cell=AD.shape[1], n_donor=3).fit(AD, DP)
+    with pytest.raises(_lib.VrxError):
+        vireo_amd.vireo_wrap(AD, DP, n_donor=3, n_init=1)
+
+
+def test_merge_counts_union_pattern_and_formats():
+    from vireo_amd.counts import merge_counts
+    rng = np.random.default_rng(0)
+    dp = (rng.random((40, 30)) < 0.2) * rng.integers(1, 9, (40, 30))
+    ad = rng.binomial(dp, 0.5)
+    ad[3, 4], dp[3, 4] = 5, 0               # AD outside DP's pattern
+    base = merge_counts(csc_matrix(ad), csc_matrix(dp))
+    shape, ptr, idx, a, d = base
+    assert shape == (40, 30) and ptr[-1] == idx.size == a.size == d.size
+    dense_a = csc_matrix((a, idx, ptr), shape=shape).toarray()
+    dense_d = csc_matrix((d, idx, ptr), shape=shape).toarray()
+    assert np.array_equal(dense_a, ad) and np.array_equal(dense_d, dp)
+    assert idx.size == np.count_nonzero((ad != 0) | (dp != 0))
+    for conv in (csr_matrix, lambda X: csc_matrix(X).astype(np.float64), np.asarray,
+                 lambda X: coo_matrix(X)):
+        other = merge_counts(conv(ad), conv(dp))
+        for x, y in zip(base[1:], other[1:]):
+            assert np.array_equal(x, y)
+    # duplicates are summed, like scipy does implicitly
+    r = np.array([0, 0, 2]); c = np.array([1, 1, 0])
+    dup = coo_matrix((np.array([1, 2, 4]), (r, c)), shape=(3, 2))
+    _, ptr, idx, a, d = merge_counts(dup, dup)
+    assert list(d) == [4, 3] and list(idx) == [2, 0]
+    with pytest.raises(ValueError):
+        merge_counts(csc_matrix(ad * 0.5), csc_matrix(dp))
+    with pytest.raises(ValueError):
+        merge_counts(csc_matrix(-ad), csc_matrix(dp))
+    with pytest.raises(ValueError):
+        merge_counts(csc_matrix(ad[:5]), csc_matrix(dp))
+
+
+def test_restart_sharding_arithmetic():
+    from vireo_amd.dist import my_restarts, gather_restart_elbos, LocalComm
+
+    class FakeComm:
+        def __init__(self, rank, world, board):
+            self.rank, self.world, self.board = rank, world, board
+
+        def allgather(self, local):
+            self.board[self.rank] = np.asarray(local).copy()
+            return np.concatenate([self.board[r] for r in range(self.world)])
+
+    for n_init, world in [(1, 1), (5, 2), (32, 8), (3, 8), (50, 4)]:
+        elbo = np.random.default_rng(n_init).normal(size=n_init)
+        owned = [my_restarts(n_init, r, world) for r in range(world)]
+        assert sorted(sum(owned, [])) == list(range(n_init))
+        board = {}
+        for r in range(world):     # what every other rank contributes to the all-gather
+            board[r] = np.pad(elbo[owned[r]], (0, -(-n_init // world) - len(owned[r])),
+                              constant_values=-np.inf)
+        for r in range(world):
+            got = gather_restart_elbos(FakeComm(r, world, board), n_init,
+                                       {i: elbo[i] for i in owned[r]})
+            assert np.array_equal(got, elbo)
+    assert np.array_equal(gather_restart_elbos(LocalComm(), 3, {0: 1., 1: 5., 2: 5.}), [1, 5, 5])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_sharded_wrap_gloo_world2(tmp_path):
+    """vireo_wrap's restart shard with 2 ranks over gloo (fits replaced by the CPU oracle):
+    both ranks return the single-process result, which is the reference's golden output."""
+    port = _free_port()
+    outs = [str(tmp_path / ("rank%d.pkl" % r)) for r in range(2)]
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"),
+                               str(r), "2", str(port), outs[r]], env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    g = gold.load("c1_wrap_seed2_init4")
+    fits = []
+    for path in outs:
+        rv = pickle.load(open(path, "rb"))
+        fits.append(rv["n_fits_on_rank"])
+        for k in ("ID_prob", "GT_prob", "doublet_prob", "doublet_LLR", "theta_shapes",
+                  "theta_mean", "theta_sum", "LB_list"):
+            assert np.array_equal(rv[k], g[k]), k
+        assert rv["LB_doublet"] == g["LB_doublet"]
+    # 4 restarts over 2 ranks: 2 each, plus the winner's final fit on exactly one rank
+    assert sorted(fits) == [2, 3]
+
+
+def test_match_and_optimal_match():
+    from vireo_amd import match, optimal_match
+    assert list(match([5, 9, 1], [1, 2, 5, 7, 9])) == [2, 4, 0]
+    assert list(match([1, 2, 5, 7, 9], [5, 9, 1])) == [2, None, 0, None, 1]
+    rng = np.random.default_rng(0)
+    X = rng.random((50, 4, 3))
+    perm = np.array([2, 0, 3, 1])
+    i0, i1 = optimal_match(X, X[:, perm, :] + 1e-3 * rng.random((50, 4, 3)))
+    assert list(i0) == [0, 1, 2, 3] and list(perm[i1]) == [0, 1, 2, 3]

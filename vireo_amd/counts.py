@@ -1,0 +1,137 @@
+"""AD/DP count matrices resident in HBM.
+
+The reference hands scipy.sparse matrices (CSC from read_cellSNP, io_utils.py:57; CSR
+from the VCF path, vcf_utils.py:204; int64 or float64; or dense ndarrays) straight to
+SciPy's SpMM.  Here the pair is canonicalised ONCE on the host into a single CSC
+pattern (the union of both patterns) with an int32 (ad, dp) pair per entry, uploaded,
+and kept on the device behind a ``DeviceCounts`` handle; "BD = DP - AD" is never
+formed.  Format independence of the reference's results makes
+this canonicalisation safe.
+"""
+import ctypes as C
+import weakref
+
+import numpy as np
+from scipy.sparse import csc_matrix, issparse
+
+from . import _lib
+
+_I32_MAX = 2 ** 31 - 1
+
+
+def _as_canonical_csc(X, name):
+    if not issparse(X):
+        X = np.asarray(X)
+        if X.ndim != 2:
+            raise ValueError("%s must be a 2-D matrix" % name)
+    X = csc_matrix(X)           # no copy when X is already CSC
+    if not X.has_canonical_format:
+        X = X.copy()
+        X.sum_duplicates()      # also sorts the indices
+    d = X.data
+    if d.size:
+        if d.dtype.kind == "f":
+            if not np.all(d == np.floor(d)):
+                raise ValueError("%s holds non-integer counts" % name)
+        elif d.dtype.kind not in "iub":
+            raise ValueError("%s has unsupported dtype %s" % (name, d.dtype))
+        if d.min() < 0:
+            raise ValueError("%s holds negative counts" % name)
+        if d.max() > _I32_MAX:
+            raise ValueError("%s holds counts >= 2^31" % name)
+    return X
+
+
+def merge_counts(AD, DP):
+    """-> (shape, colptr int64[M+1], rowidx int32[nnz], ad int32[nnz], dp int32[nnz])
+    on the union pattern of AD and DP (entries where both are zero are dropped)."""
+    AD = _as_canonical_csc(AD, "AD")
+    DP = _as_canonical_csc(DP, "DP")
+    if AD.shape != DP.shape:
+        raise ValueError("AD %s and DP %s differ in shape" % (AD.shape, DP.shape))
+    # one sparse add on packed (ad << 32 | dp) values gives the union pattern
+    hi = csc_matrix((AD.data.astype(np.int64) << 32, AD.indices, AD.indptr), shape=AD.shape)
+    lo = csc_matrix((DP.data.astype(np.int64), DP.indices, DP.indptr), shape=DP.shape)
+    U = hi + lo
+    if not U.has_sorted_indices:
+        U.sort_indices()
+    ad = (U.data >> 32).astype(np.int32)
+    dp = (U.data & 0xFFFFFFFF).astype(np.int32)
+    return (U.shape, U.indptr.astype(np.int64), U.indices.astype(np.int32), ad, dp)
+
+
+class DeviceCounts:
+    """(AD, DP) on one GPU, in both orientations (C handle ``vrx_problem``)."""
+
+    def __init__(self, AD, DP, device=0):
+        _lib.require_gpu()
+        (self.n_var, self.n_cell), colptr, rowidx, ad, dp = merge_counts(AD, DP)
+        self.shape = (self.n_var, self.n_cell)
+        self.nnz = int(rowidx.size)
+        self.device = device
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().vrx_problem_create(
+            device, self.n_var, self.n_cell, self.nnz,
+            colptr.ctypes.data_as(C.POINTER(C.c_int64)),
+            rowidx.ctypes.data_as(C.POINTER(C.c_int32)),
+            ad.ctypes.data_as(C.POINTER(C.c_int32)),
+            dp.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(self._h)))
+        self._binom = None
+        self._fin = weakref.finalize(self, _lib.lib().vrx_problem_destroy, self._h)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def binom_const(self):
+        """float32(sum_{DP>0} float32(min(log C(DP,AD), 700))) -- what the reference adds
+        to the ELBO trace (vireo_model.py:313, bmm_model.py:239; a float32 scalar)."""
+        if self._binom is None:
+            s = C.c_double(0.0)
+            _lib.check(_lib.lib().vrx_problem_binom_const(self._h, C.byref(s)))
+            self._binom = np.float32(s.value)
+        return self._binom
+
+    def n_vars(self):
+        """number of variants with DP > 0 per cell (vireo.py:191)."""
+        out = np.zeros(self.n_cell, dtype=np.int32)
+        _lib.check(_lib.lib().vrx_problem_n_vars(self._h, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
+
+    def close(self):
+        self._fin()
+
+
+# (AD, DP) -> DeviceCounts.  vireo_wrap calls fit() n_init+1 times on the same matrices
+# (vireo_wrap.py:84-94); upload once.  Keyed on object identity + buffer addresses + a
+# content checksum so that in-place edits are noticed.
+_cache = {}
+_CACHE_MAX = 2
+
+
+def _fingerprint(X):
+    if issparse(X):
+        return (id(X), X.shape, X.nnz, X.data.ctypes.data if X.nnz else 0,
+                float(X.data.sum()) if X.nnz else 0.0, X.format)
+    X = np.asarray(X)
+    return (id(X), X.shape, X.ctypes.data, float(X.sum()))
+
+
+def device_counts(AD, DP=None, device=0):
+    """Accepts a DeviceCounts (returned as is) or an (AD, DP) pair in any of the
+    reference's input formats."""
+    if isinstance(AD, DeviceCounts):
+        return AD
+    key = (_fingerprint(AD), _fingerprint(DP), device)
+    hit = _cache.get(key)
+    if hit is not None:
+        return hit
+    dc = DeviceCounts(AD, DP, device=device)
+    while len(_cache) >= _CACHE_MAX:      # evicted handles die with their last reference
+        _cache.pop(next(iter(_cache)))
+    _cache[key] = dc
+    return dc
+
+
+def clear_cache():
+    _cache.clear()

@@ -1,0 +1,92 @@
+// Internal declarations shared by the translation units of libvireo_hip.so.
+// gfx950 (MI355X, CDNA4) only: 64-wide wavefronts are assumed everywhere.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/vireo_hip.h"
+
+void vrx_set_error(const char* fmt, ...);
+
+#define VRX_HIP(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e__ = (expr);                                                        \
+        if (e__ != hipSuccess) {                                                        \
+            vrx_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),       \
+                          __FILE__, __LINE__);                                          \
+            return VRX_ERR_HIP;                                                         \
+        }                                                                               \
+    } while (0)
+
+#define VRX_REQUIRE(cond, ...)                                                          \
+    do {                                                                                \
+        if (!(cond)) {                                                                  \
+            vrx_set_error(__VA_ARGS__);                                                 \
+            return VRX_ERR_ARG;                                                         \
+        }                                                                               \
+    } while (0)
+
+// Owning device buffer (freed with the handle).
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t alloc(size_t count) {
+        release();
+        n = count;
+        if (count == 0) return hipSuccess;
+        return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    }
+    hipError_t upload(const T* src, size_t count, hipStream_t s) {
+        hipError_t e = alloc(count);
+        if (e != hipSuccess || count == 0) return e;
+        return hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s);
+    }
+};
+
+// One orientation of the (ad, dp) matrix plus its segment table.
+//   rows       : the OUTPUT dimension of a sparse pass over this orientation
+//   idx[e]     : index along the CONTRACTED dimension
+//   val[e]     : (ad, dp)
+// A segment is a contiguous run of one row's entries, at most seg_cap long; one wavefront
+// reduces one segment.  Rows with exactly one segment write their result in place
+// (seg_dst >= 0: the row), rows split over several segments write partial sums into
+// slots (seg_dst = -(slot+1)) that `multi_*` lists for the in-order second stage.
+struct Orient {
+    int64_t n_rows = 0, n_contract = 0, nnz = 0;
+    DevBuf<int32_t> idx;
+    DevBuf<int2> val;
+    int64_t n_seg = 0;
+    DevBuf<int64_t> seg_begin;
+    DevBuf<int32_t> seg_len;
+    DevBuf<int32_t> seg_dst;
+    int64_t n_multi = 0, n_slots = 0;
+    DevBuf<int32_t> multi_row;
+    DevBuf<int32_t> multi_ptr;  // n_multi + 1 slot offsets
+};
+
+struct vrx_problem {
+    int device = 0;
+    int n_cu = 0;
+    int64_t n_var = 0, n_cell = 0, nnz = 0;
+    hipStream_t stream = nullptr;
+    Orient by_var;   // rows = variants, contracted = cells   (CSR of the N x M matrix)
+    Orient by_cell;  // rows = cells,    contracted = variants (CSC of the N x M matrix)
+    bool binom_done = false;
+    double binom_sum = 0.0;
+    std::vector<int32_t> n_vars;
+};

@@ -1,0 +1,869 @@
+// Host side of libvireo_hip.so: the C ABI of include/vireo_hip.h.
+// Owns the device state, schedules the kernels of vrx_kernels.h on one HIP stream per
+// problem and runs the coordinate-ascent loop of the reference
+// (vireoSNP/utils/vireo_model.py:251-276, vireoSNP/utils/bmm_model.py:178-201).
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <memory>
+
+#include "vrx_common.h"
+#include "vrx_kernels.h"
+
+// ------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+void vrx_set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+extern "C" const char* vrx_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int vrx_device_count(int* n) {
+    VRX_REQUIRE(n, "vrx_device_count: null output");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        c = 0;
+    }
+    *n = c;
+    return VRX_OK;
+}
+
+extern "C" int vrx_device_info(int device, char* name, int name_len, int* n_cu,
+                               int64_t* hbm_bytes) {
+    hipDeviceProp_t prop;
+    VRX_HIP(hipGetDeviceProperties(&prop, device));
+    if (name && name_len > 0) {
+        snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return VRX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// problem
+// ------------------------------------------------------------------------------------
+static constexpr int kSegCap = 4096;  // entries per segment (one wavefront each)
+
+// Build the segment table of one orientation from its row pointer array and upload all.
+static int build_orient(Orient& o, int64_t n_rows, int64_t n_contract, const int64_t* ptr,
+                        const int32_t* idx, const int2* val, hipStream_t s) {
+    o.n_rows = n_rows;
+    o.n_contract = n_contract;
+    o.nnz = ptr[n_rows];
+    std::vector<int64_t> seg_begin;
+    std::vector<int32_t> seg_len, seg_dst, multi_row, multi_ptr;
+    seg_begin.reserve(n_rows);
+    seg_len.reserve(n_rows);
+    seg_dst.reserve(n_rows);
+    multi_ptr.push_back(0);
+    int64_t slots = 0;
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const int64_t len = ptr[r + 1] - ptr[r];
+        if (len <= 0) continue;  // empty row: its output stays 0 (buffers are zero-filled)
+        const int64_t parts = (len + kSegCap - 1) / kSegCap;
+        if (parts == 1) {
+            seg_begin.push_back(ptr[r]);
+            seg_len.push_back((int32_t)len);
+            seg_dst.push_back((int32_t)r);
+            continue;
+        }
+        int64_t chunk = (len + parts - 1) / parts;
+        chunk = (chunk + 63) / 64 * 64;
+        for (int64_t b = 0; b < len; b += chunk) {
+            seg_begin.push_back(ptr[r] + b);
+            seg_len.push_back((int32_t)std::min(chunk, len - b));
+            seg_dst.push_back((int32_t)(-(slots + 1)));
+            ++slots;
+        }
+        multi_row.push_back((int32_t)r);
+        multi_ptr.push_back((int32_t)slots);
+    }
+    if (slots >= INT32_MAX || (int64_t)seg_begin.size() >= INT32_MAX) {
+        vrx_set_error("too many segments");
+        return VRX_ERR_UNSUPPORTED;
+    }
+    o.n_seg = (int64_t)seg_begin.size();
+    o.n_multi = (int64_t)multi_row.size();
+    o.n_slots = slots;
+    VRX_HIP(o.idx.upload(idx, (size_t)o.nnz, s));
+    VRX_HIP(o.val.upload(val, (size_t)o.nnz, s));
+    VRX_HIP(o.seg_begin.upload(seg_begin.data(), seg_begin.size(), s));
+    VRX_HIP(o.seg_len.upload(seg_len.data(), seg_len.size(), s));
+    VRX_HIP(o.seg_dst.upload(seg_dst.data(), seg_dst.size(), s));
+    VRX_HIP(o.multi_row.upload(multi_row.data(), multi_row.size(), s));
+    VRX_HIP(o.multi_ptr.upload(multi_ptr.data(), multi_ptr.size(), s));
+    VRX_HIP(hipStreamSynchronize(s));  // the host vectors die at return
+    return VRX_OK;
+}
+
+extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int64_t nnz,
+                                  const int64_t* colptr, const int32_t* rowidx, const int32_t* ad,
+                                  const int32_t* dp, vrx_problem** out) {
+    VRX_REQUIRE(out, "vrx_problem_create: null output");
+    *out = nullptr;
+    VRX_REQUIRE(n_var > 0 && n_cell > 0 && nnz >= 0, "vrx_problem_create: bad shape");
+    VRX_REQUIRE(n_var < INT32_MAX && n_cell < INT32_MAX, "vrx_problem_create: dimension >= 2^31");
+    VRX_REQUIRE(colptr && (nnz == 0 || (rowidx && ad && dp)), "vrx_problem_create: null input");
+    VRX_REQUIRE(colptr[0] == 0 && colptr[n_cell] == nnz, "vrx_problem_create: colptr/nnz mismatch");
+    int ndev = 0;
+    vrx_device_count(&ndev);
+    if (device < 0 || device >= ndev) {
+        vrx_set_error("vrx_problem_create: device %d not available (%d HIP devices visible)",
+                      device, ndev);
+        return VRX_ERR_HIP;
+    }
+    VRX_HIP(hipSetDevice(device));
+    std::unique_ptr<vrx_problem> p(new vrx_problem());
+    p->device = device;
+    p->n_var = n_var;
+    p->n_cell = n_cell;
+    p->nnz = nnz;
+    hipDeviceProp_t prop;
+    VRX_HIP(hipGetDeviceProperties(&prop, device));
+    p->n_cu = prop.multiProcessorCount;
+    VRX_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+
+    // validate + interleave (ad, dp); count per-cell and per-variant entries
+    std::vector<int2> cval((size_t)nnz);
+    std::vector<int64_t> rptr((size_t)n_var + 1, 0);
+    p->n_vars.assign((size_t)n_cell, 0);
+    for (int64_t c = 0; c < n_cell; ++c) {
+        if (colptr[c + 1] < colptr[c]) {
+            vrx_set_error("vrx_problem_create: colptr not monotone at column %lld", (long long)c);
+            return VRX_ERR_ARG;
+        }
+        int32_t prev = -1, nv = 0;
+        for (int64_t e = colptr[c]; e < colptr[c + 1]; ++e) {
+            const int32_t r = rowidx[e];
+            if (r <= prev || r >= n_var) {
+                vrx_set_error("vrx_problem_create: row indices of column %lld not strictly "
+                              "increasing / out of range", (long long)c);
+                return VRX_ERR_ARG;
+            }
+            if (ad[e] < 0 || dp[e] < 0) {
+                vrx_set_error("vrx_problem_create: negative count at entry %lld", (long long)e);
+                return VRX_ERR_ARG;
+            }
+            prev = r;
+            cval[(size_t)e] = make_int2(ad[e], dp[e]);
+            ++rptr[(size_t)r + 1];
+            nv += dp[e] > 0;
+        }
+        p->n_vars[(size_t)c] = nv;
+    }
+    for (int64_t r = 0; r < n_var; ++r) rptr[(size_t)r + 1] += rptr[(size_t)r];
+
+    // variant-major copy (counting sort keeps cells increasing inside each variant row)
+    std::vector<int32_t> ridx((size_t)nnz);
+    std::vector<int2> rval((size_t)nnz);
+    {
+        std::vector<int64_t> cur(rptr.begin(), rptr.end() - 1);
+        for (int64_t c = 0; c < n_cell; ++c)
+            for (int64_t e = colptr[c]; e < colptr[c + 1]; ++e) {
+                const int64_t q = cur[(size_t)rowidx[e]]++;
+                ridx[(size_t)q] = (int32_t)c;
+                rval[(size_t)q] = cval[(size_t)e];
+            }
+    }
+    int rc = build_orient(p->by_cell, n_cell, n_var, colptr, rowidx, cval.data(), p->stream);
+    if (rc) return rc;
+    rc = build_orient(p->by_var, n_var, n_cell, rptr.data(), ridx.data(), rval.data(), p->stream);
+    if (rc) return rc;
+    *out = p.release();
+    return VRX_OK;
+}
+
+extern "C" void vrx_problem_destroy(vrx_problem* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+}
+
+extern "C" int vrx_problem_binom_const(vrx_problem* p, double* sum_out) {
+    VRX_REQUIRE(p && sum_out, "vrx_problem_binom_const: null argument");
+    if (!p->binom_done) {
+        VRX_HIP(hipSetDevice(p->device));
+        const int nb = (int)std::min<int64_t>(std::max<int64_t>((p->nnz + VRX_BLOCK - 1) / VRX_BLOCK, 1),
+                                              (int64_t)p->n_cu * 8);
+        DevBuf<double> part;
+        VRX_HIP(part.alloc((size_t)nb));
+        vrx_binom_partial<<<nb, VRX_BLOCK, 0, p->stream>>>(p->nnz, p->by_cell.val.p, part.p);
+        VRX_HIP(hipGetLastError());
+        std::vector<double> h((size_t)nb);
+        VRX_HIP(hipMemcpyAsync(h.data(), part.p, (size_t)nb * sizeof(double), hipMemcpyDeviceToHost,
+                               p->stream));
+        VRX_HIP(hipStreamSynchronize(p->stream));
+        double s = 0.0;
+        for (double v : h) s += v;
+        p->binom_sum = s;
+        p->binom_done = true;
+    }
+    *sum_out = p->binom_sum;
+    return VRX_OK;
+}
+
+extern "C" int vrx_problem_n_vars(vrx_problem* p, int32_t* out) {
+    VRX_REQUIRE(p && out, "vrx_problem_n_vars: null argument");
+    std::memcpy(out, p->n_vars.data(), p->n_vars.size() * sizeof(int32_t));
+    return VRX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// model
+// ------------------------------------------------------------------------------------
+static constexpr int kMaxTrace = 1 << 16;
+static constexpr int kEventPairs = 1 << 13;
+
+struct vrx_model {
+    vrx_problem* p = nullptr;
+    vrx_model_cfg cfg{};
+    int K = 0, T = 0, KP = 0;
+    int64_t N = 0, M = 0, NK = 0;
+    int64_t th_rows = 1, th_cols = 0;  // shape of beta_mu / beta_sum
+    // variational state
+    DevBuf<double> ID, GT, mu, sm;
+    // derived tables
+    DevBuf<double> psi;  // [3][th_rows][T]   (Vireo)
+    DevBuf<double> S;    // [N][K] double2  (sum ad*ID, sum dp*ID)
+    DevBuf<double> W;    // [N][K] double2  (W1, W2)
+    DevBuf<double> LID;  // [M][K]          logLik_ID
+    DevBuf<double> PV, PC;  // split-row partial slots
+    // priors
+    DevBuf<double> logq_id, logq_gt, prior1, prior2, tmp;
+    int id_mode = 0, gt_mode = 0;
+    int64_t prior_rows = 1;
+    // reductions
+    int nb_theta = 0, nb_nk = 0, nb_cell = 0, nb_throws = 0, n_th_part = 1;
+    DevBuf<double> part_theta, part_gt, part_cell, part_th;
+    DevBuf<double> d_elbo, d_parts;
+    double* h_pin = nullptr;  // pinned staging for scalar read-backs
+    bool w_valid = false;     // W matches (GT, psi) on the device
+    // profiling
+    bool prof = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> ev_kind;
+    int ev_used = 0;
+    double prof_ms[VRX_KERN_COUNT] = {0, 0, 0};
+    int64_t prof_n[VRX_KERN_COUNT] = {0, 0, 0};
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+
+    ~vrx_model() {
+        if (h_pin) (void)hipHostFree(h_pin);
+        for (auto e : ev) (void)hipEventDestroy(e);
+        if (t0) (void)hipEventDestroy(t0);
+        if (t1) (void)hipEventDestroy(t1);
+    }
+};
+
+static int pick_kp(int K) {
+    int kp = 1;
+    while (kp < K && kp < 64) kp <<= 1;
+    return kp;
+}
+
+struct ProfScope {  // brackets launches of one kernel class with events when profiling
+    vrx_model* m;
+    int slot = -1;
+    ProfScope(vrx_model* m_, int kind) : m(m_) {
+        if (m->prof && m->ev_used + 2 <= (int)m->ev.size()) {
+            slot = m->ev_used;
+            m->ev_used += 2;
+            m->ev_kind[slot / 2] = kind;
+            (void)hipEventRecord(m->ev[slot], m->p->stream);
+        }
+    }
+    ~ProfScope() {
+        if (slot >= 0) (void)hipEventRecord(m->ev[slot + 1], m->p->stream);
+    }
+};
+
+static int prof_drain(vrx_model* m) {
+    if (m->ev_used == 0) return VRX_OK;
+    VRX_HIP(hipStreamSynchronize(m->p->stream));
+    for (int s = 0; s < m->ev_used; s += 2) {
+        float ms = 0.f;
+        VRX_HIP(hipEventElapsedTime(&ms, m->ev[s], m->ev[s + 1]));
+        m->prof_ms[m->ev_kind[s / 2]] += ms;
+        m->prof_n[m->ev_kind[s / 2]] += 1;
+    }
+    m->ev_used = 0;
+    return VRX_OK;
+}
+
+extern "C" int vrx_model_create(vrx_problem* p, const vrx_model_cfg* cfg, vrx_model** out) {
+    VRX_REQUIRE(p && cfg && out, "vrx_model_create: null argument");
+    *out = nullptr;
+    VRX_REQUIRE(cfg->kind == VRX_KIND_VIREO || cfg->kind == VRX_KIND_BMM,
+                "vrx_model_create: unknown model kind %d", cfg->kind);
+    VRX_REQUIRE(cfg->n_donor >= 1, "vrx_model_create: n_donor must be >= 1");
+    if (cfg->kind == VRX_KIND_VIREO && (cfg->n_gt < 1 || cfg->n_gt > VRX_MAXT)) {
+        vrx_set_error("vrx_model_create: n_GT=%d unsupported (1..%d)", cfg->n_gt, VRX_MAXT);
+        return VRX_ERR_UNSUPPORTED;
+    }
+    VRX_HIP(hipSetDevice(p->device));
+    std::unique_ptr<vrx_model> m(new vrx_model());
+    m->p = p;
+    m->cfg = *cfg;
+    m->K = cfg->n_donor;
+    m->T = cfg->kind == VRX_KIND_VIREO ? cfg->n_gt : 1;
+    m->KP = pick_kp(m->K);
+    m->N = p->n_var;
+    m->M = p->n_cell;
+    m->NK = m->N * m->K;
+    VRX_REQUIRE(m->NK < INT32_MAX * (int64_t)VRX_BLOCK, "vrx_model_create: n_var*n_donor too large");
+    if (cfg->kind == VRX_KIND_VIREO) {
+        m->th_rows = cfg->ase_mode ? m->N : 1;
+        m->th_cols = m->T;
+    } else {
+        m->th_rows = m->N;
+        m->th_cols = m->K;
+    }
+    hipStream_t s = p->stream;
+    const size_t th = (size_t)(m->th_rows * m->th_cols);
+    VRX_HIP(m->ID.alloc((size_t)(m->M * m->K)));
+    VRX_HIP(m->LID.alloc((size_t)(m->M * m->K)));
+    VRX_HIP(m->mu.alloc(th));
+    VRX_HIP(m->sm.alloc(th));
+    VRX_HIP(m->prior1.alloc(th));
+    VRX_HIP(m->prior2.alloc(th));
+    VRX_HIP(m->S.alloc((size_t)m->NK * 2));
+    VRX_HIP(m->W.alloc((size_t)m->NK * 2));
+    VRX_HIP(m->PV.alloc((size_t)(p->by_var.n_slots * m->K * 2)));
+    VRX_HIP(m->PC.alloc((size_t)(p->by_cell.n_slots * m->K)));
+    // rows without entries are never written by the passes: zero once
+    VRX_HIP(hipMemsetAsync(m->S.p, 0, (size_t)m->NK * 2 * sizeof(double), s));
+    VRX_HIP(hipMemsetAsync(m->LID.p, 0, (size_t)(m->M * m->K) * sizeof(double), s));
+    VRX_HIP(hipMemsetAsync(m->ID.p, 0, (size_t)(m->M * m->K) * sizeof(double), s));
+    m->nb_nk = (int)((m->NK + VRX_BLOCK - 1) / VRX_BLOCK);
+    m->nb_cell = (int)((m->M * m->KP + VRX_BLOCK - 1) / VRX_BLOCK);
+    m->nb_throws = (int)((m->N + VRX_BLOCK - 1) / VRX_BLOCK);
+    m->nb_theta = std::min(m->nb_nk, p->n_cu * 4);
+    VRX_HIP(m->part_cell.alloc((size_t)m->nb_cell * 2));
+    VRX_HIP(m->part_gt.alloc((size_t)m->nb_nk));
+    VRX_HIP(hipMemsetAsync(m->part_gt.p, 0, (size_t)m->nb_nk * sizeof(double), s));
+    if (cfg->kind == VRX_KIND_VIREO) {
+        VRX_HIP(m->GT.alloc((size_t)m->NK * m->T));
+        VRX_HIP(m->psi.alloc(3 * th));
+        VRX_HIP(m->part_theta.alloc((size_t)m->nb_theta * 2 * VRX_MAXT));
+        m->n_th_part = cfg->ase_mode ? m->nb_throws : 1;
+    } else {
+        m->n_th_part = m->nb_nk;
+    }
+    VRX_HIP(m->part_th.alloc((size_t)m->n_th_part));
+    VRX_HIP(hipMemsetAsync(m->part_th.p, 0, (size_t)m->n_th_part * sizeof(double), s));
+    VRX_HIP(m->d_elbo.alloc(kMaxTrace));
+    VRX_HIP(m->d_parts.alloc(4));
+    VRX_HIP(hipHostMalloc(reinterpret_cast<void**>(&m->h_pin), 64 * sizeof(double), hipHostMallocDefault));
+    VRX_HIP(hipEventCreate(&m->t0));
+    VRX_HIP(hipEventCreate(&m->t1));
+    VRX_HIP(hipStreamSynchronize(s));
+    *out = m.release();
+    return VRX_OK;
+}
+
+extern "C" void vrx_model_destroy(vrx_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->p->device);
+    (void)hipStreamSynchronize(m->p->stream);
+    delete m;
+}
+
+static int h2d(vrx_model* m, DevBuf<double>& dst, const double* src, size_t n) {
+    if (!src) return VRX_OK;
+    VRX_REQUIRE(dst.n >= n, "internal: upload larger than buffer");
+    VRX_HIP(hipMemcpyAsync(dst.p, src, n * sizeof(double), hipMemcpyHostToDevice, m->p->stream));
+    return VRX_OK;
+}
+
+static int d2h(vrx_model* m, double* dst, const DevBuf<double>& src, size_t n) {
+    if (!dst) return VRX_OK;
+    VRX_HIP(hipMemcpyAsync(dst, src.p, n * sizeof(double), hipMemcpyDeviceToHost, m->p->stream));
+    return VRX_OK;
+}
+
+extern "C" int vrx_model_set_state(vrx_model* m, const double* ID_prob, const double* GT_prob,
+                                   const double* beta_mu, const double* beta_sum) {
+    VRX_REQUIRE(m, "vrx_model_set_state: null model");
+    VRX_HIP(hipSetDevice(m->p->device));
+    int rc;
+    if ((rc = h2d(m, m->ID, ID_prob, (size_t)(m->M * m->K)))) return rc;
+    if (m->cfg.kind == VRX_KIND_VIREO)
+        if ((rc = h2d(m, m->GT, GT_prob, (size_t)m->NK * m->T))) return rc;
+    if ((rc = h2d(m, m->mu, beta_mu, (size_t)(m->th_rows * m->th_cols)))) return rc;
+    if ((rc = h2d(m, m->sm, beta_sum, (size_t)(m->th_rows * m->th_cols)))) return rc;
+    VRX_HIP(hipStreamSynchronize(m->p->stream));
+    m->w_valid = false;
+    return VRX_OK;
+}
+
+extern "C" int vrx_model_get_state(vrx_model* m, double* ID_prob, double* GT_prob, double* beta_mu,
+                                   double* beta_sum) {
+    VRX_REQUIRE(m, "vrx_model_get_state: null model");
+    VRX_HIP(hipSetDevice(m->p->device));
+    int rc;
+    if ((rc = d2h(m, ID_prob, m->ID, (size_t)(m->M * m->K)))) return rc;
+    if (m->cfg.kind == VRX_KIND_VIREO)
+        if ((rc = d2h(m, GT_prob, m->GT, (size_t)m->NK * m->T))) return rc;
+    if ((rc = d2h(m, beta_mu, m->mu, (size_t)(m->th_rows * m->th_cols)))) return rc;
+    if ((rc = d2h(m, beta_sum, m->sm, (size_t)(m->th_rows * m->th_cols)))) return rc;
+    VRX_HIP(hipStreamSynchronize(m->p->stream));
+    return VRX_OK;
+}
+
+extern "C" int vrx_model_get_loglik(vrx_model* m, double* out) {
+    VRX_REQUIRE(m && out, "vrx_model_get_loglik: null argument");
+    VRX_HIP(hipSetDevice(m->p->device));
+    int rc = d2h(m, out, m->LID, (size_t)(m->M * m->K));
+    if (rc) return rc;
+    VRX_HIP(hipStreamSynchronize(m->p->stream));
+    return VRX_OK;
+}
+
+extern "C" int vrx_model_set_loglik(vrx_model* m, const double* in) {
+    VRX_REQUIRE(m && in, "vrx_model_set_loglik: null argument");
+    VRX_HIP(hipSetDevice(m->p->device));
+    int rc = h2d(m, m->LID, in, (size_t)(m->M * m->K));
+    if (rc) return rc;
+    VRX_HIP(hipStreamSynchronize(m->p->stream));
+    return VRX_OK;
+}
+
+extern "C" int vrx_model_get_elbo_parts(vrx_model* m, double* parts4) {
+    VRX_REQUIRE(m && parts4, "vrx_model_get_elbo_parts: null argument");
+    VRX_HIP(hipSetDevice(m->p->device));
+    VRX_HIP(hipMemcpyAsync(parts4, m->d_parts.p, 4 * sizeof(double), hipMemcpyDeviceToHost,
+                           m->p->stream));
+    VRX_HIP(hipStreamSynchronize(m->p->stream));
+    return VRX_OK;
+}
+
+// upload a probability table and turn it into row-normalised logs on the device
+static int upload_log_rows(vrx_model* m, DevBuf<double>& dst, const double* src, int64_t rows,
+                           int cols) {
+    const size_t n = (size_t)(rows * cols);
+    VRX_HIP(dst.alloc(n));
+    VRX_HIP(m->tmp.alloc(n));
+    VRX_HIP(hipMemcpyAsync(m->tmp.p, src, n * sizeof(double), hipMemcpyHostToDevice, m->p->stream));
+    const int nb = (int)((rows + VRX_BLOCK - 1) / VRX_BLOCK);
+    vrx_log_rows<<<nb, VRX_BLOCK, 0, m->p->stream>>>(rows, cols, m->tmp.p, dst.p);
+    VRX_HIP(hipGetLastError());
+    VRX_HIP(hipStreamSynchronize(m->p->stream));
+    m->tmp.release();
+    return VRX_OK;
+}
+
+extern "C" int vrx_model_set_prior(vrx_model* m, const double* ID_prior, int64_t id_rows,
+                                   const double* GT_prior, int64_t gt_rows, const double* s1_prior,
+                                   const double* s2_prior, int64_t theta_prior_rows) {
+    VRX_REQUIRE(m, "vrx_model_set_prior: null model");
+    VRX_HIP(hipSetDevice(m->p->device));
+    VRX_REQUIRE(id_rows == 0 || id_rows == 1 || id_rows == m->M,
+                "vrx_model_set_prior: ID_prior must have 0, 1 or n_cell rows (got %lld)",
+                (long long)id_rows);
+    int rc;
+    if (id_rows == 0) {
+        m->id_mode = 0;
+        m->logq_id.release();
+    } else {
+        VRX_REQUIRE(ID_prior, "vrx_model_set_prior: null ID_prior");
+        if ((rc = upload_log_rows(m, m->logq_id, ID_prior, id_rows, m->K))) return rc;
+        m->id_mode = id_rows == 1 ? 1 : 2;
+    }
+    if (m->cfg.kind == VRX_KIND_VIREO) {
+        VRX_REQUIRE(gt_rows == 0 || gt_rows == 1 || gt_rows == m->N,
+                    "vrx_model_set_prior: GT_prior must have 0, 1 or n_var rows (got %lld)",
+                    (long long)gt_rows);
+        if (gt_rows == 0) {
+            m->gt_mode = 0;
+            m->logq_gt.release();
+        } else {
+            VRX_REQUIRE(GT_prior, "vrx_model_set_prior: null GT_prior");
+            if ((rc = upload_log_rows(m, m->logq_gt, GT_prior, gt_rows * m->K, m->T))) return rc;
+            m->gt_mode = gt_rows == 1 ? 1 : 2;
+        }
+    }
+    VRX_REQUIRE(s1_prior && s2_prior, "vrx_model_set_prior: null theta prior");
+    VRX_REQUIRE(theta_prior_rows == 1 || theta_prior_rows == m->th_rows,
+                "vrx_model_set_prior: theta prior rows must be 1 or %lld", (long long)m->th_rows);
+    m->prior_rows = theta_prior_rows;
+    const size_t n = (size_t)(theta_prior_rows * m->th_cols);
+    if ((rc = h2d(m, m->prior1, s1_prior, n))) return rc;
+    if ((rc = h2d(m, m->prior2, s2_prior, n))) return rc;
+    VRX_HIP(hipStreamSynchronize(m->p->stream));
+    return VRX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// launches
+// ------------------------------------------------------------------------------------
+template <int MODE>
+static int launch_spmm(vrx_model* m, const Orient& o, const double* X, int K, double* out,
+                       double* partial) {
+    if (o.n_seg == 0) return VRX_OK;
+    hipStream_t s = m->p->stream;
+    const int kp = pick_kp(K);
+    dim3 grid((unsigned)((o.n_seg + VRX_WAVES - 1) / VRX_WAVES), (unsigned)((K + kp - 1) / kp));
+#define VRX_SPMM_CASE(KPV)                                                                       \
+    case KPV:                                                                                    \
+        vrx_spmm<KPV, MODE><<<grid, VRX_BLOCK, 0, s>>>(o.n_seg, o.seg_begin.p, o.seg_len.p,      \
+                                                       o.seg_dst.p, o.idx.p, o.val.p, X, K, out, \
+                                                       partial);                                 \
+        break;
+    switch (kp) {
+        VRX_SPMM_CASE(1)
+        VRX_SPMM_CASE(2)
+        VRX_SPMM_CASE(4)
+        VRX_SPMM_CASE(8)
+        VRX_SPMM_CASE(16)
+        VRX_SPMM_CASE(32)
+        VRX_SPMM_CASE(64)
+    }
+#undef VRX_SPMM_CASE
+    VRX_HIP(hipGetLastError());
+    if (o.n_multi > 0) {
+        constexpr int VPE = MODE == 0 ? 2 : 1;
+        const int64_t tot = o.n_multi * K * VPE;
+        vrx_sum_slots<VPE><<<(unsigned)((tot + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
+            o.n_multi, K, o.multi_row.p, o.multi_ptr.p, partial, out);
+        VRX_HIP(hipGetLastError());
+    }
+    return VRX_OK;
+}
+
+// S <- (AD @ ID_prob, DP @ ID_prob)        vireo_model.py:169-170,207-208; bmm_model.py:137-138
+static int variant_pass(vrx_model* m) {
+    ProfScope ps(m, VRX_KERN_VARIANT_PASS);
+    return launch_spmm<0>(m, m->p->by_var, m->ID.p, m->K, m->S.p, m->PV.p);
+}
+
+// LID <- AD^T W1 + DP^T W2                 vireo_model.py:190-196; bmm_model.py:125-129
+static int cell_pass(vrx_model* m) {
+    ProfScope ps(m, VRX_KERN_CELL_PASS);
+    return launch_spmm<1>(m, m->p->by_cell, m->W.p, m->K, m->LID.p, m->PC.p);
+}
+
+// theta update (update=1) or just psi/KL from the current beta (update=0)
+static int theta_step(vrx_model* m, int update) {
+    ProfScope ps(m, VRX_KERN_DENSE);
+    hipStream_t s = m->p->stream;
+    const auto& c = m->cfg;
+    if (c.kind == VRX_KIND_BMM) {
+        vrx_bmm_theta<<<m->nb_nk, VRX_BLOCK, 0, s>>>(
+            m->NK, update, c.fix_beta_sum, reinterpret_cast<const double2*>(m->S.p), m->prior1.p,
+            m->prior2.p, m->prior_rows == 1 ? 0 : 1, m->mu.p, m->sm.p,
+            reinterpret_cast<double2*>(m->W.p), m->part_th.p);
+        m->w_valid = true;
+    } else if (c.ase_mode) {
+        vrx_theta_ase<<<m->nb_throws, VRX_BLOCK, 0, s>>>(
+            m->N, m->K, m->T, update, c.fix_beta_sum, reinterpret_cast<const double2*>(m->S.p),
+            m->GT.p, m->prior1.p, m->prior2.p, (int)m->prior_rows, m->mu.p, m->sm.p, m->psi.p,
+            m->part_th.p);
+        m->w_valid = false;
+    } else {
+        if (update) {
+            vrx_theta_partial<<<m->nb_theta, VRX_BLOCK, 0, s>>>(
+                m->NK, m->T, reinterpret_cast<const double2*>(m->S.p), m->GT.p, m->part_theta.p);
+            VRX_HIP(hipGetLastError());
+        }
+        vrx_theta_final<<<1, VRX_BLOCK, 0, s>>>(m->nb_theta, m->T, update, c.fix_beta_sum,
+                                                 m->part_theta.p, m->prior1.p, m->prior2.p, m->mu.p,
+                                                 m->sm.p, m->psi.p, m->part_th.p);
+        m->w_valid = false;
+    }
+    VRX_HIP(hipGetLastError());
+    return VRX_OK;
+}
+
+// GT softmax (learn=1) or W/KL from the fixed GT (learn=0); always refreshes W
+static int gt_step(vrx_model* m, int learn) {
+    ProfScope ps(m, VRX_KERN_DENSE);
+    vrx_gt_update<<<m->nb_nk, VRX_BLOCK, 0, m->p->stream>>>(
+        m->NK, m->K, m->T, learn, m->cfg.ase_mode, m->N, reinterpret_cast<const double2*>(m->S.p),
+        m->psi.p, m->logq_gt.p, m->gt_mode, -std::log((double)m->T), m->GT.p,
+        reinterpret_cast<double2*>(m->W.p), m->part_gt.p);
+    VRX_HIP(hipGetLastError());
+    m->w_valid = true;
+    return VRX_OK;
+}
+
+static int softmax_step(vrx_model* m, int update) {
+    ProfScope ps(m, VRX_KERN_DENSE);
+    hipStream_t s = m->p->stream;
+    const double lu = -std::log((double)m->K);
+#define VRX_SM_CASE(KPV)                                                                        \
+    case KPV:                                                                                   \
+        vrx_cell_softmax<KPV><<<m->nb_cell, VRX_BLOCK, 0, s>>>(m->M, m->K, update, m->LID.p,    \
+                                                               m->logq_id.p, m->id_mode, lu,    \
+                                                               m->ID.p, m->part_cell.p);        \
+        break;
+    switch (m->KP) {
+        VRX_SM_CASE(1)
+        VRX_SM_CASE(2)
+        VRX_SM_CASE(4)
+        VRX_SM_CASE(8)
+        VRX_SM_CASE(16)
+        VRX_SM_CASE(32)
+        VRX_SM_CASE(64)
+    }
+#undef VRX_SM_CASE
+    VRX_HIP(hipGetLastError());
+    return VRX_OK;
+}
+
+static int elbo_step(vrx_model* m, int slot) {
+    ProfScope ps(m, VRX_KERN_DENSE);
+    const int n_gt = m->cfg.kind == VRX_KIND_VIREO ? m->nb_nk : 0;
+    vrx_elbo_final<<<1, VRX_BLOCK, 0, m->p->stream>>>(m->part_cell.p, m->nb_cell, m->part_gt.p, n_gt,
+                                                      m->part_th.p, m->n_th_part,
+                                                      m->d_elbo.p + slot, m->d_parts.p);
+    VRX_HIP(hipGetLastError());
+    return VRX_OK;
+}
+
+// One iteration of _fit_VB (vireo_model.py:257-264) / _fit_BV (bmm_model.py:183-188).
+// Enqueue only; no host synchronisation.
+static int enqueue_iteration(vrx_model* m, bool do_theta, int slot) {
+    int rc;
+    const auto& c = m->cfg;
+    if (c.kind == VRX_KIND_BMM) {
+        if ((rc = variant_pass(m))) return rc;
+        if ((rc = theta_step(m, 1))) return rc;  // also refreshes W (digamma tables)
+    } else {
+        bool have_s = false;
+        if (do_theta) {
+            if ((rc = variant_pass(m))) return rc;
+            have_s = true;
+            if ((rc = theta_step(m, 1))) return rc;
+        }
+        if (c.learn_gt) {
+            // the reference recomputes AD@ID_prob, DP@ID_prob here (vireo_model.py:207-208);
+            // ID_prob has not changed since update_theta_size, so S is reused.
+            if (!have_s)
+                if ((rc = variant_pass(m))) return rc;
+            if ((rc = gt_step(m, 1))) return rc;
+        } else if (!m->w_valid) {
+            if ((rc = gt_step(m, 0))) return rc;
+        }
+    }
+    if ((rc = cell_pass(m))) return rc;
+    if ((rc = softmax_step(m, 1))) return rc;
+    return elbo_step(m, slot);
+}
+
+// psi / KL_theta (and, for fixed GT or BMM, W) consistent with the state just uploaded
+static int prepare(vrx_model* m) {
+    int rc;
+    if ((rc = theta_step(m, 0))) return rc;
+    if (m->cfg.kind == VRX_KIND_VIREO && !m->cfg.learn_gt)
+        if ((rc = gt_step(m, 0))) return rc;
+    return VRX_OK;
+}
+
+extern "C" int vrx_model_fit(vrx_model* m, int32_t max_iter, int32_t min_iter, double eps,
+                             int32_t delay_fit_theta, double* elbo_trace, int32_t* it_out,
+                             int32_t* warn_flags) {
+    VRX_REQUIRE(m && elbo_trace && it_out, "vrx_model_fit: null argument");
+    VRX_REQUIRE(max_iter >= 1 && max_iter <= kMaxTrace, "vrx_model_fit: max_iter must be in 1..%d",
+                kMaxTrace);
+    VRX_HIP(hipSetDevice(m->p->device));
+    hipStream_t s = m->p->stream;
+    int rc;
+    if ((rc = prepare(m))) return rc;
+    int flags = 0, it = 0;
+    double prev = 0.0;
+    for (it = 0; it < max_iter; ++it) {
+        const bool do_theta = m->cfg.kind == VRX_KIND_VIREO && m->cfg.learn_theta &&
+                              it >= delay_fit_theta;
+        if ((rc = enqueue_iteration(m, do_theta, it))) return rc;
+        // the convergence test only looks at it > min_iter (and needs ELBO[it-1])
+        if (it >= min_iter || it == max_iter - 1) {
+            VRX_HIP(hipMemcpyAsync(m->h_pin, m->d_elbo.p + it, sizeof(double), hipMemcpyDeviceToHost, s));
+            VRX_HIP(hipStreamSynchronize(s));
+            const double cur = m->h_pin[0];
+            if (it > min_iter) {
+                if (cur < prev - 1e-6) {
+                    flags |= 1;
+                } else if (it == max_iter - 1) {
+                    flags |= 2;
+                } else if (cur - prev < eps) {
+                    break;
+                }
+            }
+            prev = cur;
+        }
+    }
+    if (it == max_iter) it = max_iter - 1;  // Python leaves `it` at the last executed index
+    VRX_HIP(hipMemcpyAsync(elbo_trace, m->d_elbo.p, (size_t)(it + 1) * sizeof(double),
+                           hipMemcpyDeviceToHost, s));
+    VRX_HIP(hipStreamSynchronize(s));
+    if ((rc = prof_drain(m))) return rc;
+    *it_out = it;
+    if (warn_flags) *warn_flags = flags;
+    return VRX_OK;
+}
+
+extern "C" int vrx_model_run_iters(vrx_model* m, int32_t n_iter, int32_t theta_from_iter,
+                                   double* elbo_trace, double* ms_out) {
+    VRX_REQUIRE(m && n_iter >= 1 && n_iter <= kMaxTrace, "vrx_model_run_iters: bad argument");
+    VRX_HIP(hipSetDevice(m->p->device));
+    hipStream_t s = m->p->stream;
+    int rc;
+    if ((rc = prepare(m))) return rc;
+    VRX_HIP(hipEventRecord(m->t0, s));
+    for (int it = 0; it < n_iter; ++it) {
+        const bool do_theta = m->cfg.kind == VRX_KIND_VIREO && m->cfg.learn_theta &&
+                              it >= theta_from_iter;
+        if ((rc = enqueue_iteration(m, do_theta, it))) return rc;
+    }
+    VRX_HIP(hipEventRecord(m->t1, s));
+    VRX_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    VRX_HIP(hipEventElapsedTime(&ms, m->t0, m->t1));
+    if (ms_out) *ms_out = ms;
+    if (elbo_trace) {
+        VRX_HIP(hipMemcpy(elbo_trace, m->d_elbo.p, (size_t)n_iter * sizeof(double),
+                          hipMemcpyDeviceToHost));
+    }
+    return prof_drain(m);
+}
+
+extern "C" int vrx_model_step(vrx_model* m, int32_t which, double* elbo_out) {
+    VRX_REQUIRE(m, "vrx_model_step: null model");
+    VRX_HIP(hipSetDevice(m->p->device));
+    hipStream_t s = m->p->stream;
+    const auto& c = m->cfg;
+    int rc;
+    switch (which) {
+        case VRX_STEP_THETA:
+            if ((rc = variant_pass(m))) return rc;
+            if ((rc = theta_step(m, 1))) return rc;
+            break;
+        case VRX_STEP_GT:
+            VRX_REQUIRE(c.kind == VRX_KIND_VIREO, "vrx_model_step: GT step needs a Vireo model");
+            if ((rc = theta_step(m, 0))) return rc;
+            if ((rc = variant_pass(m))) return rc;
+            if ((rc = gt_step(m, 1))) return rc;
+            break;
+        case VRX_STEP_ID:
+        case VRX_STEP_LOGLIK:
+            if ((rc = theta_step(m, 0))) return rc;  // BMM: refreshes W as well
+            if (c.kind == VRX_KIND_VIREO)
+                if ((rc = gt_step(m, 0))) return rc;
+            if ((rc = cell_pass(m))) return rc;
+            if (which == VRX_STEP_ID)
+                if ((rc = softmax_step(m, 1))) return rc;
+            break;
+        case VRX_STEP_SOFTMAX:
+            if ((rc = softmax_step(m, 1))) return rc;
+            break;
+        case VRX_STEP_ELBO:
+            VRX_REQUIRE(elbo_out, "vrx_model_step: null elbo_out");
+            if ((rc = theta_step(m, 0))) return rc;
+            if (c.kind == VRX_KIND_VIREO)
+                if ((rc = gt_step(m, 0))) return rc;
+            if ((rc = softmax_step(m, 0))) return rc;
+            if ((rc = elbo_step(m, 0))) return rc;
+            VRX_HIP(hipMemcpyAsync(m->h_pin, m->d_elbo.p, sizeof(double), hipMemcpyDeviceToHost, s));
+            VRX_HIP(hipStreamSynchronize(s));
+            *elbo_out = m->h_pin[0];
+            break;
+        default:
+            vrx_set_error("vrx_model_step: unknown step %d", which);
+            return VRX_ERR_ARG;
+    }
+    VRX_HIP(hipStreamSynchronize(s));
+    return prof_drain(m);
+}
+
+extern "C" int vrx_model_profile(vrx_model* m, int32_t enable) {
+    VRX_REQUIRE(m, "vrx_model_profile: null model");
+    VRX_HIP(hipSetDevice(m->p->device));
+    if (enable && m->ev.empty()) {
+        m->ev.resize(2 * kEventPairs);
+        m->ev_kind.resize(kEventPairs);
+        for (auto& e : m->ev) VRX_HIP(hipEventCreate(&e));
+    }
+    m->prof = enable != 0;
+    m->ev_used = 0;
+    for (int i = 0; i < VRX_KERN_COUNT; ++i) {
+        m->prof_ms[i] = 0.0;
+        m->prof_n[i] = 0;
+    }
+    return VRX_OK;
+}
+
+extern "C" int vrx_model_profile_read(vrx_model* m, double* ms_total, int64_t* launches) {
+    VRX_REQUIRE(m && ms_total && launches, "vrx_model_profile_read: null argument");
+    VRX_HIP(hipSetDevice(m->p->device));
+    int rc = prof_drain(m);
+    if (rc) return rc;
+    for (int i = 0; i < VRX_KERN_COUNT; ++i) {
+        ms_total[i] = m->prof_ms[i];
+        launches[i] = m->prof_n[i];
+    }
+    return VRX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// one-shot cell log-likelihood against caller-supplied tables (doublet step)
+// ------------------------------------------------------------------------------------
+extern "C" int vrx_problem_cell_loglik(vrx_problem* p, int64_t n_col, int64_t n_class,
+                                       const double* GT, const double* psi1, const double* psi2,
+                                       const double* psis, int64_t psi_rows,
+                                       const double* ID_prior, int64_t id_rows, double* logLik,
+                                       double* prob_out) {
+    VRX_REQUIRE(p && GT && psi1 && psi2 && psis && logLik, "vrx_problem_cell_loglik: null argument");
+    VRX_REQUIRE(id_rows == 0 || id_rows == 1 || id_rows == p->n_cell,
+                "vrx_problem_cell_loglik: ID_prior must have 0, 1 or n_cell rows");
+    VRX_REQUIRE(id_rows == 0 || ID_prior, "vrx_problem_cell_loglik: null ID_prior");
+    VRX_REQUIRE(n_col >= 1 && n_class >= 1, "vrx_problem_cell_loglik: bad shape");
+    if (n_class > VRX_MAXT) {
+        vrx_set_error("vrx_problem_cell_loglik: %lld genotype classes unsupported (max %d)",
+                      (long long)n_class, VRX_MAXT);
+        return VRX_ERR_UNSUPPORTED;
+    }
+    VRX_REQUIRE(psi_rows == 1 || psi_rows == p->n_var, "vrx_problem_cell_loglik: psi rows must be 1 or n_var");
+    vrx_model_cfg cfg{};
+    cfg.kind = VRX_KIND_VIREO;
+    cfg.n_donor = (int32_t)n_col;
+    cfg.n_gt = (int32_t)n_class;
+    cfg.learn_gt = 0;
+    cfg.learn_theta = 0;
+    cfg.ase_mode = psi_rows == 1 ? 0 : 1;
+    vrx_model* m = nullptr;
+    int rc = vrx_model_create(p, &cfg, &m);
+    if (rc) return rc;
+    std::unique_ptr<vrx_model> guard(m);
+    hipStream_t s = p->stream;
+    const size_t th = (size_t)(psi_rows * n_class);
+    if ((rc = h2d(m, m->GT, GT, (size_t)m->NK * m->T))) return rc;
+    VRX_HIP(hipMemcpyAsync(m->psi.p, psi1, th * sizeof(double), hipMemcpyHostToDevice, s));
+    VRX_HIP(hipMemcpyAsync(m->psi.p + th, psi2, th * sizeof(double), hipMemcpyHostToDevice, s));
+    VRX_HIP(hipMemcpyAsync(m->psi.p + 2 * th, psis, th * sizeof(double), hipMemcpyHostToDevice, s));
+    if ((rc = gt_step(m, 0))) return rc;
+    if ((rc = cell_pass(m))) return rc;
+    if ((rc = d2h(m, logLik, m->LID, (size_t)(m->M * m->K)))) return rc;
+    if (prob_out) {
+        if (id_rows > 0) {
+            if ((rc = upload_log_rows(m, m->logq_id, ID_prior, id_rows, m->K))) return rc;
+            m->id_mode = id_rows == 1 ? 1 : 2;
+        }
+        if ((rc = softmax_step(m, 1))) return rc;
+        if ((rc = d2h(m, prob_out, m->ID, (size_t)(m->M * m->K)))) return rc;
+    }
+    VRX_HIP(hipStreamSynchronize(s));
+    return VRX_OK;
+}

@@ -1,0 +1,545 @@
+// Device code of libvireo_hip.so -- hand-written HIP for gfx950 (MI355X / CDNA4).
+//
+// The per-iteration work of the reference (vireoSNP/utils/vireo_model.py:251-264) is
+//   13 scipy SpMMs + 2 sparse subtractions + dense softmaxes + an ELBO reduction.
+// Here it is TWO streaming passes over the (ad,dp) matrix plus a few dense kernels:
+//
+//   variant pass  (spmm<KP,0>)  S[n,k]   = ( sum_m ad*ID[m,k] , sum_m dp*ID[m,k] )
+//   cell pass     (spmm<KP,1>)  LID[m,k] =   sum_n ad*W1[n,k] + dp*W2[n,k]
+//        with  W1 = sum_t GT[n,k,t](psi1_t - psi2_t),  W2 = sum_t GT[n,k,t](psi2_t - psis_t)
+//        (AD^T(GT psi1) + BD^T(GT psi2) - DP^T(GT psis)  regrouped by ad and dp)
+//
+// Both passes are HBM-bound integer streams (12 B per non-zero) with an fp64 gather of a
+// dense row per non-zero; nothing here is GEMM-shaped enough for MFMA (the K x T
+// contraction is a length-3 dot product).  All arithmetic is fp64; all reductions are
+// fixed-order (no atomics), so results are run-to-run deterministic.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+constexpr int VRX_BLOCK = 256;  // 4 wavefronts
+constexpr int VRX_WAVES = VRX_BLOCK / 64;
+constexpr int VRX_MAXT = 8;  // max genotype classes handled by the dense kernels
+
+// ------------------------------------------------------------------------------------
+// wave / block reductions (fixed butterfly order => deterministic)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+    return v;
+}
+
+// Sum NV values per thread over the 256-thread block; thread 0 writes out[0..NV).
+template <int NV>
+__device__ __forceinline__ void block_sum_store(const double (&v)[NV], double* out) {
+    __shared__ double sm[NV * VRX_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double r = wave_sum(v[i]);
+        if (lane == 0) sm[i * VRX_WAVES + wave] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            double r = 0.0;
+#pragma unroll
+            for (int w = 0; w < VRX_WAVES; ++w) r += sm[i * VRX_WAVES + w];
+            out[i] = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// special functions
+// ------------------------------------------------------------------------------------
+// digamma for x > 0: upward recurrence to x >= 10, then the asymptotic series
+// ln x - 1/(2x) - sum B_2k / (2k x^2k)  (the classic Cephes scheme scipy.special.digamma
+// uses away from its root; absolute accuracy ~1e-15 on the Beta shapes met here).
+__device__ __forceinline__ double vrx_digamma(double x) {
+    if (!(x > 0.0)) return __builtin_nan("");
+    double w = 0.0;
+    while (x < 10.0) {
+        w += 1.0 / x;
+        x += 1.0;
+    }
+    const double z = 1.0 / (x * x);
+    double y = 8.33333333333333333333e-2;
+    y = y * z - 2.10927960927960927961e-2;
+    y = y * z + 7.57575757575757575758e-3;
+    y = y * z - 4.16666666666666666667e-3;
+    y = y * z + 3.96825396825396825397e-3;
+    y = y * z - 8.33333333333333333333e-3;
+    y = y * z + 8.33333333333333333333e-2;
+    return log(x) - 0.5 / x - y * z - w;
+}
+
+__device__ __forceinline__ double vrx_betaln(double a, double b) {
+    return lgamma(a) + lgamma(b) - lgamma(a + b);
+}
+
+// KL( Beta(p1,p2) || Beta(q1,q2) ), term order of vireoSNP/utils/vireo_base.py:96-125
+// (cross(p,q) - cross(p,p)); d1,d2,ds are digamma(p1), digamma(p2), digamma(p1+p2).
+__device__ __forceinline__ double vrx_beta_kl(double p1, double p2, double q1, double q2,
+                                              double d1, double d2, double ds) {
+    const double cq = vrx_betaln(q1, q2) - (q1 - 1.0) * d1 - (q2 - 1.0) * d2 +
+                      ((q1 + q2) - 2.0) * ds;
+    const double cp = vrx_betaln(p1, p2) - (p1 - 1.0) * d1 - (p2 - 1.0) * d2 +
+                      ((p1 + p2) - 2.0) * ds;
+    return cq - cp;
+}
+
+// ------------------------------------------------------------------------------------
+// the sparse passes
+// ------------------------------------------------------------------------------------
+// One wavefront per segment.  The wave reads 64 entries (index + (ad,dp)) with one
+// coalesced load each, then walks them G = 64/KP at a time: a KP-lane group takes one
+// entry, lane kl of the group owns dense column k0+kl, so the gather of one dense row is
+// a single contiguous KP*8 (MODE 0) or KP*16 (MODE 1) byte read.  Entries are handed to
+// the groups by cross-lane permutes, never through memory.  Up to 16 gathers per lane are
+// issued back to back before the first FMA so that a wave keeps ~64 cache lines in flight.
+//   MODE 0 (variant pass): X = ID_prob (rows x K doubles);  out = double2 (sum ad*x, sum dp*x)
+//   MODE 1 (cell pass)   : X = W (rows x K double2);        out = double   sum ad*w1 + dp*w2
+template <int KP, int MODE, bool TAIL>
+__device__ __forceinline__ void vrx_spmm_batch(int id, int2 v, int nh, int g, int64_t kc, int K,
+                                               const double* __restrict__ X, double& a1,
+                                               double& a2) {
+    constexpr int G = 64 / KP;
+    constexpr int UN = KP < 16 ? KP : 16;
+#pragma unroll
+    for (int j0 = 0; j0 < KP; j0 += UN) {
+        if (TAIL && j0 * G >= nh) break;  // wave-uniform
+        double x0[UN], x1[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int r = __shfl(id, (j0 + u) * G + g, 64);  // padded entries carry id = 0
+            if (MODE == 0) {
+                x0[u] = X[(int64_t)r * K + kc];
+            } else {
+                const double2 w = reinterpret_cast<const double2*>(X)[(int64_t)r * K + kc];
+                x0[u] = w.x;
+                x1[u] = w.y;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int src = (j0 + u) * G + g;
+            const double ad = (double)__shfl(v.x, src, 64);
+            const double dp = (double)__shfl(v.y, src, 64);
+            double t1, t2 = 0.0;
+            if (MODE == 0) {
+                t1 = ad * x0[u];
+                t2 = dp * x0[u];
+            } else {
+                t1 = ad * x0[u] + dp * x1[u];
+            }
+            if (TAIL && src >= nh) t1 = t2 = 0.0;  // 0 * (inf|nan) must not leak in
+            a1 += t1;
+            if (MODE == 0) a2 += t2;
+        }
+    }
+}
+
+template <int KP, int MODE>
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_spmm(
+    int64_t n_seg, const int64_t* __restrict__ seg_begin, const int32_t* __restrict__ seg_len,
+    const int32_t* __restrict__ seg_dst, const int32_t* __restrict__ idx,
+    const int2* __restrict__ val, const double* __restrict__ X, int K, double* __restrict__ out,
+    double* __restrict__ partial) {
+    const int lane = threadIdx.x & 63;
+    const int64_t seg = (int64_t)blockIdx.x * VRX_WAVES + (threadIdx.x >> 6);
+    if (seg >= n_seg) return;
+    const int g = lane / KP, kl = lane % KP;
+    const int k = blockIdx.y * KP + kl;
+    const bool kok = k < K;
+    const int64_t kc = kok ? k : K - 1;  // padded lanes re-read the last column, never store
+    const int64_t b = seg_begin[seg];
+    const int len = seg_len[seg];
+    const long long* val8 = reinterpret_cast<const long long*>(val);
+    double a1 = 0.0, a2 = 0.0;
+    int off = 0;
+    // streamed once per pass: non-temporal loads keep L2 for the dense rows
+    for (; off + 64 <= len; off += 64) {
+        const int id = __builtin_nontemporal_load(idx + b + off + lane);
+        const long long pv = __builtin_nontemporal_load(val8 + b + off + lane);
+        vrx_spmm_batch<KP, MODE, false>(id, make_int2((int)(pv & 0xffffffffll), (int)(pv >> 32)),
+                                        64, g, kc, K, X, a1, a2);
+    }
+    if (off < len) {
+        int id = 0;
+        long long pv = 0;
+        if (off + lane < len) {
+            id = __builtin_nontemporal_load(idx + b + off + lane);
+            pv = __builtin_nontemporal_load(val8 + b + off + lane);
+        }
+        vrx_spmm_batch<KP, MODE, true>(id, make_int2((int)(pv & 0xffffffffll), (int)(pv >> 32)),
+                                       len - off, g, kc, K, X, a1, a2);
+    }
+#pragma unroll
+    for (int s = KP; s < 64; s <<= 1) {
+        a1 += __shfl_xor(a1, s, 64);
+        if (MODE == 0) a2 += __shfl_xor(a2, s, 64);
+    }
+    if (g == 0 && kok) {
+        const int d = seg_dst[seg];
+        double* base = d >= 0 ? out : partial;
+        const int64_t row = d >= 0 ? d : -(int64_t)d - 1;
+        if (MODE == 0)
+            reinterpret_cast<double2*>(base)[row * K + k] = make_double2(a1, a2);
+        else
+            base[row * K + k] = a1;
+    }
+}
+
+// Second stage for rows that were split over several segments: in-order sum of the slots.
+// VPE = values per element (2 for the variant pass, 1 for the cell pass).
+template <int VPE>
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_slots(int64_t n_multi, int K,
+                                                           const int32_t* __restrict__ multi_row,
+                                                           const int32_t* __restrict__ multi_ptr,
+                                                           const double* __restrict__ partial,
+                                                           double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    const int64_t per = (int64_t)K * VPE;
+    if (i >= n_multi * per) return;
+    const int64_t j = i / per, c = i - j * per;
+    double s = 0.0;
+    for (int q = multi_ptr[j]; q < multi_ptr[j + 1]; ++q) s += partial[(int64_t)q * per + c];
+    out[(int64_t)multi_row[j] * per + c] = s;
+}
+
+// ------------------------------------------------------------------------------------
+// theta  (Vireo.update_theta_size, vireoSNP/utils/vireo_model.py:165-185)
+// ------------------------------------------------------------------------------------
+// stage 1 (shared theta): per-block partial sums of S1*GT_t and S2*GT_t over all (n,k).
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_partial(int64_t NK, int T,
+                                                               const double2* __restrict__ S,
+                                                               const double* __restrict__ GT,
+                                                               double* __restrict__ part) {
+    double acc[2 * VRX_MAXT];
+#pragma unroll
+    for (int t = 0; t < 2 * VRX_MAXT; ++t) acc[t] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x; i < NK;
+         i += (int64_t)gridDim.x * VRX_BLOCK) {
+        const double2 s = S[i];
+        const double s1 = s.x, s2 = s.y - s.x;
+#pragma unroll
+        for (int t = 0; t < VRX_MAXT; ++t)
+            if (t < T) {
+                const double g = GT[i * T + t];
+                acc[t] += s1 * g;
+                acc[VRX_MAXT + t] += s2 * g;
+            }
+    }
+    block_sum_store<2 * VRX_MAXT>(acc, part + (int64_t)blockIdx.x * 2 * VRX_MAXT);
+}
+
+// Beta update + digammas + KL for ONE theta row.  psi is laid out [3][rows][T].
+// update == 0: only derive psi / KL from the current beta_mu, beta_sum.
+__device__ __forceinline__ double vrx_theta_row(int T, int update, int fix_sum, const double* add1,
+                                                const double* add2, const double* p1,
+                                                const double* p2, double* mu, double* sm,
+                                                double* psi1, double* psi2, double* psis) {
+    double kl = 0.0;
+    for (int t = 0; t < T; ++t) {
+        double m = mu[t], s = sm[t];
+        if (update) {
+            const double t1 = p1[t] + add1[t];
+            const double t2 = p2[t] + add2[t];
+            m = t1 / (t1 + t2);
+            if (!fix_sum) s = t1 + t2;
+            mu[t] = m;
+            sm[t] = s;
+        }
+        const double s1 = m * s, s2 = (1.0 - m) * s;  // theta_s1/theta_s2 properties
+        const double d1 = vrx_digamma(s1), d2 = vrx_digamma(s2), ds = vrx_digamma(s1 + s2);
+        psi1[t] = d1;
+        psi2[t] = d2;
+        psis[t] = ds;
+        kl += vrx_beta_kl(s1, s2, p1[t], p2[t], d1, d2, ds);
+    }
+    return kl;
+}
+
+// stage 2 (shared theta): one block sums the stage-1 partials in a fixed order.
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_final(int n_part, int T, int update,
+                                                             int fix_sum,
+                                                             const double* __restrict__ part,
+                                                             const double* __restrict__ prior1,
+                                                             const double* __restrict__ prior2,
+                                                             double* mu, double* sm, double* psi,
+                                                             double* kl_out) {
+    __shared__ double tot[2 * VRX_MAXT];
+    double acc[2 * VRX_MAXT];
+#pragma unroll
+    for (int t = 0; t < 2 * VRX_MAXT; ++t) acc[t] = 0.0;
+    if (update)
+        for (int b = threadIdx.x; b < n_part; b += VRX_BLOCK)
+#pragma unroll
+            for (int t = 0; t < 2 * VRX_MAXT; ++t) acc[t] += part[(int64_t)b * 2 * VRX_MAXT + t];
+    block_sum_store<2 * VRX_MAXT>(acc, tot);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        kl_out[0] = vrx_theta_row(T, update, fix_sum, tot, tot + VRX_MAXT, prior1, prior2, mu, sm,
+                                  psi, psi + T, psi + 2 * T);
+}
+
+// ASE mode: one theta row per variant (vireo_model.py:82,:177 axis=1).  Thread per variant.
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_ase(int64_t N, int K, int T, int update,
+                                                           int fix_sum,
+                                                           const double2* __restrict__ S,
+                                                           const double* __restrict__ GT,
+                                                           const double* __restrict__ prior1,
+                                                           const double* __restrict__ prior2,
+                                                           int prior_rows, double* mu, double* sm,
+                                                           double* psi, double* kl_part) {
+    const int64_t n = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    double kl[1] = {0.0};
+    if (n < N) {
+        double a1[VRX_MAXT], a2[VRX_MAXT];
+#pragma unroll
+        for (int t = 0; t < VRX_MAXT; ++t) a1[t] = a2[t] = 0.0;
+        if (update)
+            for (int k = 0; k < K; ++k) {
+                const double2 s = S[n * K + k];
+                const double s1 = s.x, s2 = s.y - s.x;
+#pragma unroll
+                for (int t = 0; t < VRX_MAXT; ++t)
+                    if (t < T) {
+                        const double g = GT[(n * K + k) * T + t];
+                        a1[t] += s1 * g;
+                        a2[t] += s2 * g;
+                    }
+            }
+        const int64_t pr = prior_rows == 1 ? 0 : n;
+        kl[0] = vrx_theta_row(T, update, fix_sum, a1, a2, prior1 + pr * T, prior2 + pr * T,
+                              mu + n * T, sm + n * T, psi + n * T, psi + (N + n) * T,
+                              psi + (2 * N + n) * T);
+    }
+    block_sum_store<1>(kl, kl_part + blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------
+// genotype posterior  (Vireo.update_GT_prob, vireo_model.py:204-219) fused with the
+// W1/W2 tables of the cell pass and the KL(GT || prior) partial of get_ELBO (:238).
+// Thread per (variant, donor).  learn == 0: GT is fixed, only W (and the KL) are derived.
+// gt_mode: 0 uniform prior (scalar log 1/T), 1 one (K,T) slab, 2 full (N,K,T).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_gt_update(
+    int64_t NK, int K, int T, int learn, int ase, int64_t N, const double2* __restrict__ S,
+    const double* __restrict__ psi, const double* __restrict__ logq, int gt_mode, double logq_uni,
+    double* __restrict__ GT, double2* __restrict__ W, double* __restrict__ kl_part) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    double kl[1] = {0.0};
+    if (i < NK) {
+        const int64_t n = i / K;
+        const int k = (int)(i - n * K);
+        const int64_t rows = ase ? N : 1, pr = ase ? n : 0;
+        const double* p1 = psi + pr * T;
+        const double* p2 = psi + (rows + pr) * T;
+        const double* ps = psi + (2 * rows + pr) * T;
+        double g[VRX_MAXT], lq[VRX_MAXT];
+#pragma unroll
+        for (int t = 0; t < VRX_MAXT; ++t)
+            if (t < T)
+                lq[t] = gt_mode == 0 ? logq_uni
+                                     : (gt_mode == 1 ? logq[k * T + t] : logq[i * T + t]);
+        if (learn) {
+            const double2 s = S[i];
+            const double s1 = s.x, ss = s.y, s2 = ss - s1;
+            double L[VRX_MAXT];
+            double mx = -__builtin_inf();
+#pragma unroll
+            for (int t = 0; t < VRX_MAXT; ++t)
+                if (t < T) {
+                    L[t] = (s1 * p1[t] + s2 * p2[t] - ss * ps[t]) + lq[t];
+                    mx = fmax(mx, L[t]);
+                }
+            double sum = 0.0;
+#pragma unroll
+            for (int t = 0; t < VRX_MAXT; ++t)
+                if (t < T) {
+                    L[t] -= mx;
+                    g[t] = exp(L[t]);
+                    sum += g[t];
+                }
+            const double lsum = log(sum);
+#pragma unroll
+            for (int t = 0; t < VRX_MAXT; ++t)
+                if (t < T) {
+                    g[t] = g[t] / sum;
+                    GT[i * T + t] = g[t];
+                    if (g[t] > 0.0) kl[0] += g[t] * ((L[t] - lsum) - lq[t]);
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < VRX_MAXT; ++t)
+                if (t < T) {
+                    g[t] = GT[i * T + t];
+                    if (g[t] > 0.0) kl[0] += g[t] * (log(g[t]) - lq[t]);
+                }
+        }
+        double w1 = 0.0, w2 = 0.0;
+#pragma unroll
+        for (int t = 0; t < VRX_MAXT; ++t)
+            if (t < T) {
+                w1 += g[t] * (p1[t] - p2[t]);
+                w2 += g[t] * (p2[t] - ps[t]);
+            }
+        W[i] = make_double2(w1, w2);
+    }
+    block_sum_store<1>(kl, kl_part + blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------
+// BinomMixtureVB theta  (bmm_model.py:133-144) fused with the digamma tables of
+// get_E_logLik (:118-130) and the KL_theta partial of get_ELBO (:166-172).
+// Thread per (variant, clone).  update == 0: derive W / KL from the current beta only.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_bmm_theta(int64_t NK, int update, int fix_sum,
+                                                           const double2* __restrict__ S,
+                                                           const double* __restrict__ prior1,
+                                                           const double* __restrict__ prior2,
+                                                           int prior_full, double* mu, double* sm,
+                                                           double2* __restrict__ W,
+                                                           double* __restrict__ kl_part) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    double kl[1] = {0.0};
+    if (i < NK) {
+        const double q1 = prior1[prior_full ? i : 0], q2 = prior2[prior_full ? i : 0];
+        double m = mu[i], s = sm[i];
+        if (update) {
+            const double2 a = S[i];
+            const double t1 = a.x + q1;
+            const double t2 = (a.y - a.x) + q2;
+            m = t1 / (t1 + t2);
+            if (!fix_sum) s = t1 + t2;
+            mu[i] = m;
+            sm[i] = s;
+        }
+        const double s1 = m * s, s2 = (1.0 - m) * s;
+        const double d1 = vrx_digamma(s1), d2 = vrx_digamma(s2), ds = vrx_digamma(s1 + s2);
+        W[i] = make_double2(d1 - d2, d2 - ds);
+        kl[0] = vrx_beta_kl(s1, s2, q1, q2, d1, d2, ds);
+    }
+    block_sum_store<1>(kl, kl_part + blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------
+// cell posterior  (Vireo.update_ID_prob vireo_model.py:198-199, bmm_model.py:153-154) fused
+// with the LB_p and KL(ID || prior) partials of get_ELBO (vireo_model.py:236-237).
+// A KP-lane group per cell; K > KP loops.  update == 0: ID_prob is left alone and only the
+// ELBO partials are formed from the stored ID_prob (get_ELBO on user-supplied state).
+// id_mode: 0 uniform prior, 1 one row of K, 2 full (M,K).
+// ------------------------------------------------------------------------------------
+template <int KP>
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_cell_softmax(
+    int64_t M, int K, int update, const double* __restrict__ LID, const double* __restrict__ logq,
+    int id_mode, double logq_uni, double* __restrict__ ID, double* __restrict__ part) {
+    const int64_t cell = ((int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x) / KP;
+    const int kl = threadIdx.x % KP;
+    double acc[2] = {0.0, 0.0};
+    const bool live = cell < M;
+    const double* Lr = LID + (live ? cell : 0) * (int64_t)K;
+    const double* qr = id_mode == 2 ? logq + (live ? cell : 0) * (int64_t)K : logq;
+    double mx = -__builtin_inf();
+    if (live)
+        for (int k = kl; k < K; k += KP) mx = fmax(mx, Lr[k] + (id_mode ? qr[k] : logq_uni));
+#pragma unroll
+    for (int s = 1; s < KP; s <<= 1) mx = fmax(mx, __shfl_xor(mx, s, 64));
+    double sum = 0.0;
+    if (live && update)
+        for (int k = kl; k < K; k += KP) sum += exp(Lr[k] + (id_mode ? qr[k] : logq_uni) - mx);
+#pragma unroll
+    for (int s = 1; s < KP; s <<= 1) sum += __shfl_xor(sum, s, 64);
+    if (live) {
+        const double lsum = update ? log(sum) : 0.0;
+        double* Ir = ID + cell * (int64_t)K;
+        for (int k = kl; k < K; k += KP) {
+            const double L = Lr[k];
+            const double lq = id_mode ? qr[k] : logq_uni;
+            double p, lp;
+            if (update) {
+                const double x = (L + lq) - mx;
+                p = exp(x) / sum;
+                lp = x - lsum;
+                Ir[k] = p;
+            } else {
+                p = Ir[k];
+                lp = log(p);
+            }
+            acc[0] += L * p;
+            if (p > 0.0) acc[1] += p * (lp - lq);
+        }
+    }
+    block_sum_store<2>(acc, part + (int64_t)blockIdx.x * 2);
+}
+
+// ------------------------------------------------------------------------------------
+// ELBO  = LB_p - KL_ID - KL_GT - KL_theta  (vireo_model.py:247-248, bmm_model.py:175)
+// One block; each term is the fixed-order sum of a partial array.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_elbo_final(const double* __restrict__ cell_part,
+                                                            int n_cell_part,
+                                                            const double* __restrict__ gt_part,
+                                                            int n_gt_part,
+                                                            const double* __restrict__ th_part,
+                                                            int n_th_part, double* elbo_out,
+                                                            double* parts_out) {
+    __shared__ double tot[4];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < n_cell_part; b += VRX_BLOCK) {
+        acc[0] += cell_part[2 * (int64_t)b];
+        acc[1] += cell_part[2 * (int64_t)b + 1];
+    }
+    for (int b = threadIdx.x; b < n_gt_part; b += VRX_BLOCK) acc[2] += gt_part[b];
+    for (int b = threadIdx.x; b < n_th_part; b += VRX_BLOCK) acc[3] += th_part[b];
+    block_sum_store<4>(acc, tot);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        elbo_out[0] = tot[0] - tot[1] - tot[2] - tot[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) parts_out[i] = tot[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// priors: row-normalised logs  (scipy.stats.entropy normalises q; np.log(prior) in the
+// softmax is shift-invariant, so one table serves both uses)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_log_rows(int64_t rows, int C,
+                                                          const double* __restrict__ p,
+                                                          double* __restrict__ logq) {
+    const int64_t r = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    if (r >= rows) return;
+    double s = 0.0;
+    for (int c = 0; c < C; ++c) s += p[r * C + c];
+    for (int c = 0; c < C; ++c) logq[r * C + c] = log(p[r * C + c] / s);
+}
+
+// ------------------------------------------------------------------------------------
+// binomial-coefficient constant  (get_binom_coeff, vireo_base.py:7-22)
+//   sum over dp>0 of float32( min( log C(dp, ad), 700 ) )
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_binom_partial(int64_t nnz,
+                                                               const int2* __restrict__ val,
+                                                               double* __restrict__ part) {
+    double acc[1] = {0.0};
+    for (int64_t e = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x; e < nnz;
+         e += (int64_t)gridDim.x * VRX_BLOCK) {
+        const int2 v = val[e];
+        if (v.y > 0) {
+            const double n = (double)v.y, k = (double)v.x;
+            double c = lgamma(n + 1.0) - lgamma(k + 1.0) - lgamma(n - k + 1.0);
+            if (c > 700.0) c = 700.0;
+            acc[0] += (double)(float)c;
+        }
+    }
+    block_sum_store<1>(acc, part + blockIdx.x);
+}

@@ -1,0 +1,133 @@
+"""Restart sharding across the GPUs of one node.
+
+The reference farms the n_init random restarts of vireo_wrap to a
+``multiprocessing.Pool`` and keeps ``argmax(ELBO_[-1])`` (vireoSNP/utils/vireo_wrap.py:74-91).
+Restarts are independent, so here they are sharded one process per GPU -- restart i runs
+on rank i % world -- and the ONLY exchange on the path is an all-gather of the per-restart
+ELBOs (a few hundred bytes over RCCL/xGMI) plus a broadcast of the winner's state.
+
+Backends
+  RcclComm   libvireo_hip.so's RCCL communicator (GPU box)
+  GlooComm   torch.distributed/gloo, used by the CPU-only tests of the sharding logic
+  LocalComm  world size 1
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+
+
+def env_rank_world():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0"))))
+
+
+class LocalComm:
+    rank, world = 0, 1
+
+    def allgather(self, local):
+        return np.asarray(local, dtype=np.float64).copy()
+
+    def bcast(self, arr, root):
+        return arr
+
+    def barrier(self):
+        pass
+
+
+class RcclComm:
+    """RCCL communicator behind the C ABI.  ``exchange(bytes_or_None) -> bytes`` must hand
+    rank 0's 128-byte unique id to every rank (any out-of-band channel: torch.distributed
+    store, a file, a socket)."""
+
+    def __init__(self, rank, world, device, exchange):
+        self.rank, self.world, self.device = rank, world, device
+        uid = (C.c_uint8 * _lib.UNIQUE_ID_BYTES)()
+        if rank == 0:
+            _lib.check(_lib.lib().vrx_comm_unique_id(uid))
+            raw = exchange(bytes(uid))
+        else:
+            raw = exchange(None)
+        uid = (C.c_uint8 * _lib.UNIQUE_ID_BYTES).from_buffer_copy(raw)
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().vrx_comm_create(device, rank, world, uid, C.byref(self._h)))
+
+    def allgather(self, local):
+        local = _lib.f64(local).ravel()
+        out = np.empty(local.size * self.world)
+        _lib.check(_lib.lib().vrx_comm_allgather_f64(self._h, _lib.dptr(local), local.size,
+                                                     _lib.dptr(out)))
+        return out
+
+    def bcast(self, arr, root):
+        buf = _lib.f64(arr).copy()
+        flat = buf.reshape(-1)
+        _lib.check(_lib.lib().vrx_comm_bcast_f64(self._h, _lib.dptr(flat), flat.size, int(root)))
+        return buf
+
+    def barrier(self):
+        _lib.check(_lib.lib().vrx_comm_barrier(self._h))
+
+    def close(self):
+        if self._h:
+            _lib.lib().vrx_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+class GlooComm:
+    """Same interface over an initialised torch.distributed process group (CPU tests)."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self._dist = dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def allgather(self, local):
+        import torch
+        t = torch.from_numpy(_lib.f64(local).ravel().copy())
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        self._dist.all_gather(outs, t)
+        return torch.cat(outs).numpy()
+
+    def bcast(self, arr, root):
+        import torch
+        t = torch.from_numpy(_lib.f64(arr).copy())
+        self._dist.broadcast(t, src=int(root))
+        return t.numpy()
+
+    def barrier(self):
+        self._dist.barrier()
+
+
+def torch_store_exchange():
+    """unique-id exchange through an initialised torch.distributed group (any backend)."""
+    import torch.distributed as dist
+
+    def exchange(raw):
+        box = [raw]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+    return exchange
+
+
+# ---- the sharding arithmetic (pure host logic, unit-tested on CPU) ---------------------
+def my_restarts(n_init, rank, world):
+    """restart indices fitted by ``rank``: i % world == rank."""
+    return list(range(rank, n_init, world))
+
+
+def gather_restart_elbos(comm, n_init, local_elbos):
+    """local_elbos: {restart index: ELBO_[-1]} of this rank -> full (n_init,) array, the
+    same on every rank, in restart order (so np.argmax's first-max rule matches the
+    reference's, vireo_wrap.py:90-91)."""
+    per = (n_init + comm.world - 1) // comm.world
+    send = np.full(per, -np.inf)
+    for j, i in enumerate(my_restarts(n_init, comm.rank, comm.world)):
+        send[j] = local_elbos[i]
+    got = np.asarray(comm.allgather(send)).reshape(comm.world, per)
+    out = np.empty(n_init)
+    for i in range(n_init):
+        out[i] = got[i % comm.world, i // comm.world]
+    return out
