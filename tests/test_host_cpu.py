@@ -156,3 +156,19 @@ def test_match_and_optimal_match():
     perm = np.array([2, 0, 3, 1])
     i0, i1 = optimal_match(X, X[:, perm, :] + 1e-3 * rng.random((50, 4, 3)))
     assert list(i0) == [0, 1, 2, 3] and list(perm[i1]) == [0, 1, 2, 3]
+
+
+def test_fast_generator_equals_oracle_generator():
+    """vireo_amd.synth (one packed sort) draws the same matrices as the oracle's scipy
+    construction of SURVEY.md 8(d)."""
+    from oracle import vireo_oracle as O
+    from vireo_amd import synth
+    from vireo_amd.counts import merge_counts
+    for (n, m, k, d) in [(300, 200, 3, 0.05), (2000, 1000, 4, 0.02)]:
+        w = synth.donor_workload(n, m, k, d, seed=0)
+        AD, DP = O.synth_donor(n, m, k, d, seed=0)
+        sAD, sDP = synth.as_scipy(w)
+        assert (sAD != AD).nnz == 0 and (sDP != DP).nnz == 0
+        shape, ptr, idx, a, dp = merge_counts(AD, DP)
+        assert np.array_equal(ptr, w["colptr"]) and np.array_equal(idx, w["rowidx"])
+        assert np.array_equal(a, w["ad"]) and np.array_equal(dp, w["dp"])

@@ -63,9 +63,17 @@ def merge_counts(AD, DP):
 class DeviceCounts:
     """(AD, DP) on one GPU, in both orientations (C handle ``vrx_problem``)."""
 
-    def __init__(self, AD, DP, device=0):
+    def __init__(self, AD, DP, device=None, _merged=None):
         _lib.require_gpu()
-        (self.n_var, self.n_cell), colptr, rowidx, ad, dp = merge_counts(AD, DP)
+        if device is None:
+            device = default_device()
+        if _merged is None:
+            _merged = merge_counts(AD, DP)
+        (self.n_var, self.n_cell), colptr, rowidx, ad, dp = _merged
+        colptr = np.ascontiguousarray(colptr, dtype=np.int64)
+        rowidx = np.ascontiguousarray(rowidx, dtype=np.int32)
+        ad = np.ascontiguousarray(ad, dtype=np.int32)
+        dp = np.ascontiguousarray(dp, dtype=np.int32)
         self.shape = (self.n_var, self.n_cell)
         self.nnz = int(rowidx.size)
         self.device = device
@@ -78,6 +86,13 @@ class DeviceCounts:
             dp.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(self._h)))
         self._binom = None
         self._fin = weakref.finalize(self, _lib.lib().vrx_problem_destroy, self._h)
+
+    @classmethod
+    def from_merged(cls, shape, colptr, rowidx, ad, dp, device=None):
+        """from an already merged CSC pattern carrying (ad, dp) per entry (row indices
+        strictly increasing inside each column; validated by the library)."""
+        return cls(None, None, device=device,
+                   _merged=((int(shape[0]), int(shape[1])), colptr, rowidx, ad, dp))
 
     @property
     def handle(self):
@@ -117,11 +132,19 @@ def _fingerprint(X):
     return (id(X), X.shape, X.ctypes.data, float(X.sum()))
 
 
-def device_counts(AD, DP=None, device=0):
+def default_device():
+    """VIREO_DEVICE, else LOCAL_RANK (one process per GPU under torchrun), else 0."""
+    import os
+    return int(os.environ.get("VIREO_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+
+
+def device_counts(AD, DP=None, device=None):
     """Accepts a DeviceCounts (returned as is) or an (AD, DP) pair in any of the
     reference's input formats."""
     if isinstance(AD, DeviceCounts):
         return AD
+    if device is None:
+        device = default_device()
     key = (_fingerprint(AD), _fingerprint(DP), device)
     hit = _cache.get(key)
     if hit is not None:

@@ -1,0 +1,62 @@
+"""Synthetic AD/DP workloads of BASELINE.json (generator fixed by SURVEY.md section 8(d)).
+
+Same random draws, in the same order, as ``oracle.vireo_oracle.synth_donor`` (tested equal
+in tests/test_host_cpu.py), but the COO -> CSC conversion is ONE sort of packed
+(column, row) keys carrying (ad << 32 | dp) instead of two scipy conversions, and the
+result is the merged (ad, dp) CSC that ``DeviceCounts.from_merged`` uploads directly.
+"""
+import numpy as np
+from scipy.sparse import csc_matrix
+
+CONFIGS = {
+    # name: (N variants, M cells, K donors, density)        BASELINE.json configs[1..3]
+    "c2": (10000, 5000, 4, 0.01),
+    "c3": (100000, 50000, 16, 0.02),
+    "mid": (50000, 20000, 16, 0.02),
+    "small": (2000, 1000, 4, 0.02),
+}
+
+
+def donor_workload(N, M, K, density, seed=0):
+    """-> dict(shape, colptr int64, rowidx int32, ad int32, dp int32) on DP's pattern
+    (duplicate (row, col) draws summed)."""
+    rng = np.random.default_rng(seed)
+    nnz_t = int(N * M * density)
+    r = rng.integers(0, N, nnz_t)
+    c = rng.integers(0, M, nnz_t)
+    dp = 1 + rng.poisson(1.0, nnz_t)
+    GT = rng.integers(0, 3, (N, K))
+    z = rng.integers(0, K, M)
+    theta = np.array([0.01, 0.5, 0.99])[GT[r, z[c]]]
+    ad = rng.binomial(dp, theta)
+    del theta
+    key = c * np.int64(N) + r
+    del r, c
+    val = dp.astype(np.int64) | (ad.astype(np.int64) << 32)
+    del dp, ad
+    order = np.argsort(key, kind="stable")
+    key = key[order]
+    val = val[order]
+    del order
+    first = np.empty(nnz_t, dtype=bool)
+    first[0] = True
+    np.not_equal(key[1:], key[:-1], out=first[1:])
+    starts = np.flatnonzero(first)
+    del first
+    val = np.add.reduceat(val, starts)       # duplicates: both 32-bit fields add, no carry
+    key = key[starts]
+    col = key // N
+    rowidx = (key - col * N).astype(np.int32)
+    colptr = np.zeros(M + 1, dtype=np.int64)
+    np.cumsum(np.bincount(col, minlength=M), out=colptr[1:])
+    return dict(shape=(N, M), colptr=colptr, rowidx=rowidx,
+                ad=(val >> 32).astype(np.int32), dp=(val & 0xFFFFFFFF).astype(np.int32))
+
+
+def as_scipy(w):
+    """(AD, DP) int64 CSC like scipy's coo->csc of the generator (AD's zeros dropped)."""
+    DP = csc_matrix((w["dp"].astype(np.int64), w["rowidx"], w["colptr"]), shape=w["shape"])
+    AD = csc_matrix((w["ad"].astype(np.int64), w["rowidx"].copy(), w["colptr"].copy()),
+                    shape=w["shape"])
+    AD.eliminate_zeros()
+    return AD, DP
