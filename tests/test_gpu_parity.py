@@ -298,6 +298,31 @@ def test_config2_vs_oracle(va):
     assert np.array_equal(np.argmax(dev.ID_prob, 1), np.argmax(ref.ID_prob, 1))
 
 
+@pytest.mark.parametrize("fmt,tiles_c,tiles_v", [(0, 1, 1), (1, 1, 1), (2, 1, 1), (0, 4, 2),
+                                                  (1, 16, 8), (2, 24, 16), (0, 3, 5)])
+def test_entry_formats_and_tiling_vs_oracle(va, monkeypatch, fmt, tiles_c, tiles_v):
+    """every entry format (4/8/12 B per non-zero) and tiled, XCD-ordered segment tables give
+    the oracle's result; K=6 takes the 2-columns-per-lane variant pass, K=5 the 1-column one."""
+    from vireo_amd.counts import DeviceCounts
+    monkeypatch.setenv("VIREO_ENTRY_FMT", str(fmt))
+    monkeypatch.setenv("VIREO_TILES_CELL", str(tiles_c))
+    monkeypatch.setenv("VIREO_TILES_VAR", str(tiles_v))
+    AD, DP = O.synth_donor(1500, 900, 4, 0.05, seed=3)
+    counts = DeviceCounts(AD, DP)
+    for K in (6, 5):
+        np.random.seed(7)
+        ref = O.vireo_new(900, 1500, K)
+        np.random.seed(7)
+        dev = va.Vireo(n_var=1500, n_cell=900, n_donor=K)
+        O.vireo_fit(ref, AD, DP, max_iter=8)
+        dev.fit(counts, None, max_iter=8, verbose=False)
+        assert len(dev.ELBO_) == len(ref.ELBO_)
+        close(dev.ELBO_, ref.ELBO_)
+        close(dev.ID_prob, ref.ID_prob)
+        close(dev.GT_prob, ref.GT_prob)
+    close(counts.binom_const(), O.binom_const(AD, DP), rtol=1e-6)
+
+
 def test_determinism(va):
     AD, DP = O.synth_donor(3000, 2000, 16, 0.03, seed=5)
     runs = []

@@ -60,17 +60,22 @@ struct DevBuf {
 
 // One orientation of the (ad, dp) matrix plus its segment table.
 //   rows       : the OUTPUT dimension of a sparse pass over this orientation
-//   idx[e]     : index along the CONTRACTED dimension
-//   val[e]     : (ad, dp)
-// A segment is a contiguous run of one row's entries, at most seg_cap long; one wavefront
-// reduces one segment.  Rows with exactly one segment write their result in place
-// (seg_dst >= 0: the row), rows split over several segments write partial sums into
-// slots (seg_dst = -(slot+1)) that `multi_*` lists for the in-order second stage.
+//   ent        : the entries, (index along the CONTRACTED dimension, ad, dp) packed in
+//                fmt + 1 32-bit words each (VRX_FMT_* in vrx_kernels.h)
+// A segment is a contiguous run of one row's entries inside ONE tile of the contracted
+// dimension, at most seg_cap long; one wavefront reduces one segment.  Tiles bound the
+// slab of the dense operand a pass gathers from (so that it stays in an XCD's 4 MiB L2);
+// the segment arrays are stored in LAUNCH ORDER: workgroup b runs on XCD b % 8 (observed
+// dispatch rule, used for speed only), so the segments of tile t are laid out to land on
+// XCD t % 8.  seg_len < 0 marks padding.  Rows with exactly one segment write their result
+// in place (seg_dst >= 0: the row); rows with several write partial sums into slots
+// (seg_dst = -(slot+1)) that `multi_*` lists for the in-order second stage.
 struct Orient {
     int64_t n_rows = 0, n_contract = 0, nnz = 0;
-    DevBuf<int32_t> idx;
-    DevBuf<int2> val;
-    int64_t n_seg = 0;
+    int fmt = 2;
+    int n_tiles = 1;
+    DevBuf<uint32_t> ent;
+    int64_t n_seg = 0;  // including padding
     DevBuf<int64_t> seg_begin;
     DevBuf<int32_t> seg_len;
     DevBuf<int32_t> seg_dst;

@@ -54,51 +54,148 @@ extern "C" int vrx_device_info(int device, char* name, int name_len, int* n_cu,
 // ------------------------------------------------------------------------------------
 // problem
 // ------------------------------------------------------------------------------------
-static constexpr int kSegCap = 4096;  // entries per segment (one wavefront each)
+static constexpr int kSegCap = 4096;     // entries per segment (one wavefront each)
+static constexpr int kXcd = 8;           // XCDs per MI355X; workgroup b is observed on XCD b % 8
+static constexpr double kSlabBytes = 1.6e6;  // dense-operand slab per tile (fits a 4 MiB L2)
 
-// Build the segment table of one orientation from its row pointer array and upload all.
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+// number of tiles over the contracted dimension for a dense operand of `row_bytes` per
+// contracted index (nominal K = 16): 1, 2, 4, 8 or a multiple of 8
+static int pick_tiles(int64_t n_contract, double row_bytes, const char* env) {
+    int t = env_int(env, 0);
+    if (t <= 0) t = (int)std::lround(n_contract * row_bytes / kSlabBytes);
+    if (t <= 1) return 1;
+    if (t <= kXcd) {
+        int p = 1;
+        while (p < t) p <<= 1;
+        return p;
+    }
+    return (t + kXcd - 1) / kXcd * kXcd;
+}
+
+// Pack the entries of one orientation, build its tiled / XCD-ordered segment table, upload.
+//   contract_count[i] = number of entries with contracted index i (for equal-nnz tiles)
 static int build_orient(Orient& o, int64_t n_rows, int64_t n_contract, const int64_t* ptr,
-                        const int32_t* idx, const int2* val, hipStream_t s) {
+                        const int32_t* idx, const int2* val, const int64_t* contract_ptr,
+                        int n_tiles, int fmt, hipStream_t s) {
     o.n_rows = n_rows;
     o.n_contract = n_contract;
     o.nnz = ptr[n_rows];
-    std::vector<int64_t> seg_begin;
-    std::vector<int32_t> seg_len, seg_dst, multi_row, multi_ptr;
-    seg_begin.reserve(n_rows);
-    seg_len.reserve(n_rows);
-    seg_dst.reserve(n_rows);
+    o.fmt = fmt;
+    o.n_tiles = n_tiles;
+    // ---- entries ------------------------------------------------------------------
+    const int ew = fmt + 1;
+    std::vector<uint32_t> ent((size_t)o.nnz * ew);
+    for (int64_t e = 0; e < o.nnz; ++e) {
+        const uint32_t id = (uint32_t)idx[e], ad = (uint32_t)val[e].x, dp = (uint32_t)val[e].y;
+        if (fmt == VRX_FMT_P32) {
+            ent[(size_t)e] = (id << 12) | (ad << 6) | dp;
+        } else if (fmt == VRX_FMT_P64) {
+            ent[(size_t)e * 2] = id;
+            ent[(size_t)e * 2 + 1] = ad | (dp << 16);
+        } else {
+            ent[(size_t)e * 3] = id;
+            ent[(size_t)e * 3 + 1] = ad;
+            ent[(size_t)e * 3 + 2] = dp;
+        }
+    }
+    // ---- tile boundaries: equal entry counts ------------------------------------------
+    std::vector<int64_t> bound((size_t)n_tiles + 1, n_contract);
+    bound[0] = 0;
+    for (int t = 1; t < n_tiles; ++t) {
+        const int64_t want = o.nnz * t / n_tiles;
+        bound[(size_t)t] = std::lower_bound(contract_ptr, contract_ptr + n_contract + 1, want) -
+                           contract_ptr;
+        if (bound[(size_t)t] > n_contract) bound[(size_t)t] = n_contract;
+        if (bound[(size_t)t] < bound[(size_t)t - 1]) bound[(size_t)t] = bound[(size_t)t - 1];
+    }
+    // ---- segments, grouped per tile -----------------------------------------------------
+    struct Seg {
+        int64_t begin;
+        int32_t len, dst;
+    };
+    std::vector<std::vector<Seg>> per_tile((size_t)n_tiles);
+    std::vector<int32_t> multi_row, multi_ptr;
     multi_ptr.push_back(0);
     int64_t slots = 0;
+    std::vector<Seg> row_segs;
+    std::vector<int> row_tile;
     for (int64_t r = 0; r < n_rows; ++r) {
-        const int64_t len = ptr[r + 1] - ptr[r];
-        if (len <= 0) continue;  // empty row: its output stays 0 (buffers are zero-filled)
-        const int64_t parts = (len + kSegCap - 1) / kSegCap;
-        if (parts == 1) {
-            seg_begin.push_back(ptr[r]);
-            seg_len.push_back((int32_t)len);
-            seg_dst.push_back((int32_t)r);
-            continue;
+        const int64_t lo = ptr[r], hi = ptr[r + 1];
+        if (hi <= lo) continue;  // empty row: its output stays 0 (buffers are zero-filled)
+        row_segs.clear();
+        row_tile.clear();
+        int64_t at = lo;
+        for (int t = 0; t < n_tiles && at < hi; ++t) {
+            const int64_t end = n_tiles == 1 ? hi
+                                             : std::lower_bound(idx + at, idx + hi,
+                                                                (int32_t)std::min<int64_t>(bound[(size_t)t + 1], INT32_MAX)) - idx;
+            int64_t len = end - at;
+            if (len <= 0) continue;
+            const int64_t parts = (len + kSegCap - 1) / kSegCap;
+            int64_t chunk = (len + parts - 1) / parts;
+            if (parts > 1) chunk = (chunk + 63) / 64 * 64;
+            for (int64_t b = 0; b < len; b += chunk) {
+                row_segs.push_back({at + b, (int32_t)std::min(chunk, len - b), 0});
+                row_tile.push_back(t);
+            }
+            at = end;
         }
-        int64_t chunk = (len + parts - 1) / parts;
-        chunk = (chunk + 63) / 64 * 64;
-        for (int64_t b = 0; b < len; b += chunk) {
-            seg_begin.push_back(ptr[r] + b);
-            seg_len.push_back((int32_t)std::min(chunk, len - b));
-            seg_dst.push_back((int32_t)(-(slots + 1)));
-            ++slots;
+        if (row_segs.size() == 1) {
+            row_segs[0].dst = (int32_t)r;
+        } else {
+            for (auto& sg : row_segs) sg.dst = (int32_t)(-(++slots));
+            multi_row.push_back((int32_t)r);
+            multi_ptr.push_back((int32_t)slots);
         }
-        multi_row.push_back((int32_t)r);
-        multi_ptr.push_back((int32_t)slots);
+        for (size_t i = 0; i < row_segs.size(); ++i) per_tile[(size_t)row_tile[i]].push_back(row_segs[i]);
     }
-    if (slots >= INT32_MAX || (int64_t)seg_begin.size() >= INT32_MAX) {
+    if (slots >= INT32_MAX) {
         vrx_set_error("too many segments");
         return VRX_ERR_UNSUPPORTED;
     }
-    o.n_seg = (int64_t)seg_begin.size();
+    // ---- launch order: tile t -> XCD t % 8 (tiles < 8: each tile shared by 8/n_tiles XCDs)
+    std::vector<std::vector<Seg>> per_xcd(kXcd);
+    if (n_tiles >= kXcd) {
+        for (int t = 0; t < n_tiles; ++t) {
+            auto& dst = per_xcd[(size_t)(t % kXcd)];
+            dst.insert(dst.end(), per_tile[(size_t)t].begin(), per_tile[(size_t)t].end());
+        }
+    } else {
+        const int share = kXcd / n_tiles;  // XCDs per tile
+        for (int t = 0; t < n_tiles; ++t) {
+            const auto& src = per_tile[(size_t)t];
+            for (size_t i = 0; i < src.size(); ++i) {
+                const int x = t + n_tiles * (int)((i / VRX_WAVES) % share);
+                per_xcd[(size_t)x].push_back(src[i]);
+            }
+        }
+    }
+    size_t longest = 0;
+    for (auto& v : per_xcd) longest = std::max(longest, v.size());
+    const size_t blocks_per_xcd = (longest + VRX_WAVES - 1) / VRX_WAVES;
+    const size_t total = blocks_per_xcd * kXcd * VRX_WAVES;
+    std::vector<int64_t> seg_begin(total, 0);
+    std::vector<int32_t> seg_len(total, -1), seg_dst(total, 0);
+    for (int x = 0; x < kXcd; ++x)
+        for (size_t i = 0; i < per_xcd[(size_t)x].size(); ++i) {
+            const size_t pos = ((i / VRX_WAVES) * kXcd + (size_t)x) * VRX_WAVES + i % VRX_WAVES;
+            seg_begin[pos] = per_xcd[(size_t)x][i].begin;
+            seg_len[pos] = per_xcd[(size_t)x][i].len;
+            seg_dst[pos] = per_xcd[(size_t)x][i].dst;
+        }
+    if (total >= (size_t)INT32_MAX) {
+        vrx_set_error("too many segments");
+        return VRX_ERR_UNSUPPORTED;
+    }
+    o.n_seg = (int64_t)total;
     o.n_multi = (int64_t)multi_row.size();
     o.n_slots = slots;
-    VRX_HIP(o.idx.upload(idx, (size_t)o.nnz, s));
-    VRX_HIP(o.val.upload(val, (size_t)o.nnz, s));
+    VRX_HIP(o.ent.upload(ent.data(), ent.size(), s));
     VRX_HIP(o.seg_begin.upload(seg_begin.data(), seg_begin.size(), s));
     VRX_HIP(o.seg_len.upload(seg_len.data(), seg_len.size(), s));
     VRX_HIP(o.seg_dst.upload(seg_dst.data(), seg_dst.size(), s));
@@ -139,6 +236,7 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
     std::vector<int2> cval((size_t)nnz);
     std::vector<int64_t> rptr((size_t)n_var + 1, 0);
     p->n_vars.assign((size_t)n_cell, 0);
+    int32_t max_count = 0;
     for (int64_t c = 0; c < n_cell; ++c) {
         if (colptr[c + 1] < colptr[c]) {
             vrx_set_error("vrx_problem_create: colptr not monotone at column %lld", (long long)c);
@@ -158,6 +256,7 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
             }
             prev = r;
             cval[(size_t)e] = make_int2(ad[e], dp[e]);
+            max_count = std::max(max_count, std::max(ad[e], dp[e]));
             ++rptr[(size_t)r + 1];
             nv += dp[e] > 0;
         }
@@ -177,9 +276,21 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
                 rval[(size_t)q] = cval[(size_t)e];
             }
     }
-    int rc = build_orient(p->by_cell, n_cell, n_var, colptr, rowidx, cval.data(), p->stream);
+    // narrowest entry format that holds the counts and the contracted index
+    auto pick_fmt = [&](int64_t n_contract) {
+        int f = VRX_FMT_WIDE;
+        if (max_count < (1 << 16)) f = VRX_FMT_P64;
+        if (max_count < 64 && n_contract <= (1 << 20)) f = VRX_FMT_P32;
+        const int forced = env_int("VIREO_ENTRY_FMT", -1);
+        return forced >= f && forced <= VRX_FMT_WIDE ? forced : f;  // may only widen
+    };
+    const int tiles_c = pick_tiles(n_var, 256.0, "VIREO_TILES_CELL");   // W rows: 16 x 16 B
+    const int tiles_v = pick_tiles(n_cell, 128.0, "VIREO_TILES_VAR");   // ID rows: 16 x 8 B
+    int rc = build_orient(p->by_cell, n_cell, n_var, colptr, rowidx, cval.data(), rptr.data(),
+                          tiles_c, pick_fmt(n_var), p->stream);
     if (rc) return rc;
-    rc = build_orient(p->by_var, n_var, n_cell, rptr.data(), ridx.data(), rval.data(), p->stream);
+    rc = build_orient(p->by_var, n_var, n_cell, rptr.data(), ridx.data(), rval.data(), colptr,
+                      tiles_v, pick_fmt(n_cell), p->stream);
     if (rc) return rc;
     *out = p.release();
     return VRX_OK;
@@ -200,7 +311,13 @@ extern "C" int vrx_problem_binom_const(vrx_problem* p, double* sum_out) {
                                               (int64_t)p->n_cu * 8);
         DevBuf<double> part;
         VRX_HIP(part.alloc((size_t)nb));
-        vrx_binom_partial<<<nb, VRX_BLOCK, 0, p->stream>>>(p->nnz, p->by_cell.val.p, part.p);
+        const Orient& o = p->by_cell;
+        if (o.fmt == VRX_FMT_P32)
+            vrx_binom_partial<VRX_FMT_P32><<<nb, VRX_BLOCK, 0, p->stream>>>(p->nnz, o.ent.p, part.p);
+        else if (o.fmt == VRX_FMT_P64)
+            vrx_binom_partial<VRX_FMT_P64><<<nb, VRX_BLOCK, 0, p->stream>>>(p->nnz, o.ent.p, part.p);
+        else
+            vrx_binom_partial<VRX_FMT_WIDE><<<nb, VRX_BLOCK, 0, p->stream>>>(p->nnz, o.ent.p, part.p);
         VRX_HIP(hipGetLastError());
         std::vector<double> h((size_t)nb);
         VRX_HIP(hipMemcpyAsync(h.data(), part.p, (size_t)nb * sizeof(double), hipMemcpyDeviceToHost,
@@ -268,9 +385,9 @@ struct vrx_model {
     }
 };
 
-static int pick_kp(int K) {
+static int pick_kp(int K, int cap = 64) {
     int kp = 1;
-    while (kp < K && kp < 64) kp <<= 1;
+    while (kp < K && kp < cap) kp <<= 1;
     return kp;
 }
 
@@ -509,29 +626,50 @@ extern "C" int vrx_model_set_prior(vrx_model* m, const double* ID_prior, int64_t
 // ------------------------------------------------------------------------------------
 // launches
 // ------------------------------------------------------------------------------------
+template <int LPE, int CPL, int MODE>
+static void launch_spmm_fmt(const Orient& o, dim3 grid, hipStream_t s, const double* X, int K,
+                            double* out, double* partial) {
+#define VRX_GO(F)                                                                              \
+    vrx_spmm<LPE, CPL, MODE, F><<<grid, VRX_BLOCK, 0, s>>>(o.n_seg, o.seg_begin.p, o.seg_len.p, \
+                                                           o.seg_dst.p, o.ent.p, X, K, out,    \
+                                                           partial)
+    if (o.fmt == VRX_FMT_P32)
+        VRX_GO(VRX_FMT_P32);
+    else if (o.fmt == VRX_FMT_P64)
+        VRX_GO(VRX_FMT_P64);
+    else
+        VRX_GO(VRX_FMT_WIDE);
+#undef VRX_GO
+}
+
 template <int MODE>
 static int launch_spmm(vrx_model* m, const Orient& o, const double* X, int K, double* out,
                        double* partial) {
     if (o.n_seg == 0) return VRX_OK;
     hipStream_t s = m->p->stream;
-    const int kp = pick_kp(K);
-    dim3 grid((unsigned)((o.n_seg + VRX_WAVES - 1) / VRX_WAVES), (unsigned)((K + kp - 1) / kp));
-#define VRX_SPMM_CASE(KPV)                                                                       \
-    case KPV:                                                                                    \
-        vrx_spmm<KPV, MODE><<<grid, VRX_BLOCK, 0, s>>>(o.n_seg, o.seg_begin.p, o.seg_len.p,      \
-                                                       o.seg_dst.p, o.idx.p, o.val.p, X, K, out, \
-                                                       partial);                                 \
-        break;
-    switch (kp) {
-        VRX_SPMM_CASE(1)
-        VRX_SPMM_CASE(2)
-        VRX_SPMM_CASE(4)
-        VRX_SPMM_CASE(8)
-        VRX_SPMM_CASE(16)
-        VRX_SPMM_CASE(32)
-        VRX_SPMM_CASE(64)
+    // lanes per entry x columns per lane: 16 B per lane wherever the layout allows
+    const int cpl = (MODE == 0 && K % 2 == 0) ? 2 : 1;
+    const int lpe = pick_kp((K + cpl - 1) / cpl, 16 / cpl);
+    const int cols = lpe * cpl;
+    dim3 grid((unsigned)(o.n_seg / VRX_WAVES), (unsigned)((K + cols - 1) / cols));
+    if (cpl == 2) {
+        if (MODE == 0) {  // (guard keeps the CPL=2 cell-pass templates from being instantiated)
+            switch (lpe) {
+                case 1: launch_spmm_fmt<1, 2, 0>(o, grid, s, X, K, out, partial); break;
+                case 2: launch_spmm_fmt<2, 2, 0>(o, grid, s, X, K, out, partial); break;
+                case 4: launch_spmm_fmt<4, 2, 0>(o, grid, s, X, K, out, partial); break;
+                default: launch_spmm_fmt<8, 2, 0>(o, grid, s, X, K, out, partial); break;
+            }
+        }
+    } else {
+        switch (lpe) {
+            case 1: launch_spmm_fmt<1, 1, MODE>(o, grid, s, X, K, out, partial); break;
+            case 2: launch_spmm_fmt<2, 1, MODE>(o, grid, s, X, K, out, partial); break;
+            case 4: launch_spmm_fmt<4, 1, MODE>(o, grid, s, X, K, out, partial); break;
+            case 8: launch_spmm_fmt<8, 1, MODE>(o, grid, s, X, K, out, partial); break;
+            default: launch_spmm_fmt<16, 1, MODE>(o, grid, s, X, K, out, partial); break;
+        }
     }
-#undef VRX_SPMM_CASE
     VRX_HIP(hipGetLastError());
     if (o.n_multi > 0) {
         constexpr int VPE = MODE == 0 ? 2 : 1;

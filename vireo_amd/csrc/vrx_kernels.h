@@ -96,102 +96,162 @@ __device__ __forceinline__ double vrx_beta_kl(double p1, double p2, double q1, d
 // ------------------------------------------------------------------------------------
 // the sparse passes
 // ------------------------------------------------------------------------------------
-// One wavefront per segment.  The wave reads 64 entries (index + (ad,dp)) with one
-// coalesced load each, then walks them G = 64/KP at a time: a KP-lane group takes one
-// entry, lane kl of the group owns dense column k0+kl, so the gather of one dense row is
-// a single contiguous KP*8 (MODE 0) or KP*16 (MODE 1) byte read.  Entries are handed to
-// the groups by cross-lane permutes, never through memory.  Up to 16 gathers per lane are
-// issued back to back before the first FMA so that a wave keeps ~64 cache lines in flight.
-//   MODE 0 (variant pass): X = ID_prob (rows x K doubles);  out = double2 (sum ad*x, sum dp*x)
-//   MODE 1 (cell pass)   : X = W (rows x K double2);        out = double   sum ad*w1 + dp*w2
-template <int KP, int MODE, bool TAIL>
-__device__ __forceinline__ void vrx_spmm_batch(int id, int2 v, int nh, int g, int64_t kc, int K,
-                                               const double* __restrict__ X, double& a1,
-                                               double& a2) {
-    constexpr int G = 64 / KP;
-    constexpr int UN = KP < 16 ? KP : 16;
+// Entry formats (chosen per orientation when the problem is uploaded):
+//   VRX_FMT_P32   one 32-bit word   index:20 | ad:6 | dp:6      ( 4 B / non-zero)
+//   VRX_FMT_P64   two words         index:32 , ad:16 | dp:16    ( 8 B / non-zero)
+//   VRX_FMT_WIDE  three words       index , ad , dp             (12 B / non-zero)
+// Narrower formats cut the HBM stream and, more importantly, the cross-lane permutes
+// per step (1 / 2 / 3).
+enum { VRX_FMT_P32 = 0, VRX_FMT_P64 = 1, VRX_FMT_WIDE = 2 };
+
+template <int FMT>
+struct VrxWords {
+    uint32_t w[FMT + 1];
+};
+
+template <int FMT>
+__device__ __forceinline__ VrxWords<FMT> vrx_load_words(const uint32_t* __restrict__ ent,
+                                                        int64_t at, bool ok) {
+    VrxWords<FMT> e;
 #pragma unroll
-    for (int j0 = 0; j0 < KP; j0 += UN) {
-        if (TAIL && j0 * G >= nh) break;  // wave-uniform
-        double x0[UN], x1[UN];
+    for (int i = 0; i <= FMT; ++i) e.w[i] = 0;  // padded entries: index 0, ad = dp = 0
+    if (ok) {  // streamed once per pass: non-temporal, keep L2 for the dense rows
+        if (FMT == VRX_FMT_P32) {
+            e.w[0] = __builtin_nontemporal_load(ent + at);
+        } else if (FMT == VRX_FMT_P64) {
+            const unsigned long long v =
+                __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(ent) + at);
+            e.w[0] = (uint32_t)v;
+            e.w[1] = (uint32_t)(v >> 32);
+        } else {
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int r = __shfl(id, (j0 + u) * G + g, 64);  // padded entries carry id = 0
-            if (MODE == 0) {
-                x0[u] = X[(int64_t)r * K + kc];
-            } else {
-                const double2 w = reinterpret_cast<const double2*>(X)[(int64_t)r * K + kc];
-                x0[u] = w.x;
-                x1[u] = w.y;
-            }
+            for (int i = 0; i < 3; ++i) e.w[i] = __builtin_nontemporal_load(ent + at * 3 + i);
         }
+    }
+    return e;
+}
+
+template <int FMT>
+__device__ __forceinline__ void vrx_unpack(const VrxWords<FMT>& e, uint32_t& id, int& ad, int& dp) {
+    if (FMT == VRX_FMT_P32) {
+        id = e.w[0] >> 12;
+        ad = (int)((e.w[0] >> 6) & 63u);
+        dp = (int)(e.w[0] & 63u);
+    } else if (FMT == VRX_FMT_P64) {
+        id = e.w[0];
+        ad = (int)(e.w[FMT >= 1 ? 1 : 0] & 0xffffu);
+        dp = (int)(e.w[FMT >= 1 ? 1 : 0] >> 16);
+    } else {
+        id = e.w[0];
+        ad = (int)e.w[FMT >= 1 ? 1 : 0];
+        dp = (int)e.w[FMT >= 2 ? 2 : 0];
+    }
+}
+
+// One wavefront per segment.  The wave reads 64 entries with one coalesced load (prefetched
+// one batch ahead), then walks them G = 64/LPE at a time: an LPE-lane group takes one entry
+// and each lane of the group owns CPL adjacent dense columns, so the gather of one dense row
+// is a single contiguous read of 16 B per lane wherever the layout allows:
+//   MODE 0 (variant pass): X = ID_prob (rows x K doubles), CPL = 2 for even K (double2 per
+//           lane) else 1;  out = S[row][k] = double2 (sum ad*x, sum dp*x)
+//   MODE 1 (cell pass)   : X = W (rows x K double2 (w1,w2)), CPL = 1;
+//           out = LID[row][k] = sum ad*w1 + dp*w2
+// Entries reach the groups through cross-lane permutes, never through memory.  The L1-miss
+// path (one 128-B line every ~3.6 clk per CU) bounds this kernel, which is why the segment
+// table is tiled over the contracted dimension and launched XCD-aware (vrx_engine.hip).
+// LPE*CPL <= 16 columns per block; wider K is covered by blockIdx.y column chunks.
+template <int LPE, int CPL, int MODE, int FMT, bool TAIL>
+__device__ __forceinline__ void vrx_spmm_batch(const VrxWords<FMT>& e, int nh, int g, uint32_t kc,
+                                               uint32_t K, const double* __restrict__ X,
+                                               double (&a1)[CPL], double (&a2)[CPL]) {
+    constexpr int G = 64 / LPE;
+    double x0[LPE][CPL], x1[MODE == 1 ? LPE : 1][CPL];
+    int ads[LPE], dps[LPE];
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int src = (j0 + u) * G + g;
-            const double ad = (double)__shfl(v.x, src, 64);
-            const double dp = (double)__shfl(v.y, src, 64);
-            double t1, t2 = 0.0;
-            if (MODE == 0) {
-                t1 = ad * x0[u];
-                t2 = dp * x0[u];
+    for (int u = 0; u < LPE; ++u) {
+        if (TAIL && u * G >= nh) break;  // wave-uniform
+        VrxWords<FMT> q;
+#pragma unroll
+        for (int i = 0; i <= FMT; ++i) q.w[i] = (uint32_t)__shfl((int)e.w[i], u * G + g, 64);
+        uint32_t r;
+        vrx_unpack<FMT>(q, r, ads[u], dps[u]);
+        if (MODE == 0) {
+            if (CPL == 2) {
+                const double2 v = *reinterpret_cast<const double2*>(X + (r * K + kc));
+                x0[u][0] = v.x;
+                x0[u][CPL - 1] = v.y;
             } else {
-                t1 = ad * x0[u] + dp * x1[u];
+                x0[u][0] = X[r * K + kc];
             }
-            if (TAIL && src >= nh) t1 = t2 = 0.0;  // 0 * (inf|nan) must not leak in
-            a1 += t1;
-            if (MODE == 0) a2 += t2;
+        } else {
+            const double2 v = reinterpret_cast<const double2*>(X)[r * K + kc];
+            x0[u][0] = v.x;
+            x1[u][0] = v.y;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < LPE; ++u) {
+        if (TAIL && u * G >= nh) break;
+        const double ad = (double)ads[u], dp = (double)dps[u];
+        const bool live = !TAIL || (u * G + g < nh);  // 0 * (inf|nan) must not leak in
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            if (MODE == 0) {
+                a1[c] += live ? ad * x0[u][c] : 0.0;
+                a2[c] += live ? dp * x0[u][c] : 0.0;
+            } else {
+                a1[c] += live ? ad * x0[u][c] + dp * x1[u][c] : 0.0;
+            }
         }
     }
 }
 
-template <int KP, int MODE>
+template <int LPE, int CPL, int MODE, int FMT>
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_spmm(
     int64_t n_seg, const int64_t* __restrict__ seg_begin, const int32_t* __restrict__ seg_len,
-    const int32_t* __restrict__ seg_dst, const int32_t* __restrict__ idx,
-    const int2* __restrict__ val, const double* __restrict__ X, int K, double* __restrict__ out,
-    double* __restrict__ partial) {
+    const int32_t* __restrict__ seg_dst, const uint32_t* __restrict__ ent,
+    const double* __restrict__ X, int K, double* __restrict__ out, double* __restrict__ partial) {
+    static_assert(LPE * CPL <= 16 && (MODE == 0 || CPL == 1), "layout");
     const int lane = threadIdx.x & 63;
     const int64_t seg = (int64_t)blockIdx.x * VRX_WAVES + (threadIdx.x >> 6);
     if (seg >= n_seg) return;
-    const int g = lane / KP, kl = lane % KP;
-    const int k = blockIdx.y * KP + kl;
-    const bool kok = k < K;
-    const int64_t kc = kok ? k : K - 1;  // padded lanes re-read the last column, never store
-    const int64_t b = seg_begin[seg];
     const int len = seg_len[seg];
-    const long long* val8 = reinterpret_cast<const long long*>(val);
-    double a1 = 0.0, a2 = 0.0;
-    int off = 0;
-    // streamed once per pass: non-temporal loads keep L2 for the dense rows
-    for (; off + 64 <= len; off += 64) {
-        const int id = __builtin_nontemporal_load(idx + b + off + lane);
-        const long long pv = __builtin_nontemporal_load(val8 + b + off + lane);
-        vrx_spmm_batch<KP, MODE, false>(id, make_int2((int)(pv & 0xffffffffll), (int)(pv >> 32)),
-                                        64, g, kc, K, X, a1, a2);
-    }
-    if (off < len) {
-        int id = 0;
-        long long pv = 0;
-        if (off + lane < len) {
-            id = __builtin_nontemporal_load(idx + b + off + lane);
-            pv = __builtin_nontemporal_load(val8 + b + off + lane);
-        }
-        vrx_spmm_batch<KP, MODE, true>(id, make_int2((int)(pv & 0xffffffffll), (int)(pv >> 32)),
-                                       len - off, g, kc, K, X, a1, a2);
-    }
+    if (len < 0) return;  // padding of the XCD-aware launch order
+    const int g = lane / LPE, kl = lane % LPE;
+    const int k = (blockIdx.y * LPE + kl) * CPL;
+    const bool kok = k < K;
+    const uint32_t kc = kok ? k : K - CPL;  // padded lanes re-read the last columns, never store
+    const int64_t b = seg_begin[seg] + lane;
+    double a1[CPL], a2[CPL];
 #pragma unroll
-    for (int s = KP; s < 64; s <<= 1) {
-        a1 += __shfl_xor(a1, s, 64);
-        if (MODE == 0) a2 += __shfl_xor(a2, s, 64);
+    for (int c = 0; c < CPL; ++c) a1[c] = a2[c] = 0.0;
+    VrxWords<FMT> nxt = vrx_load_words<FMT>(ent, b, lane < len);
+    int off = 0;
+    for (; off + 64 <= len; off += 64) {
+        const VrxWords<FMT> cur = nxt;
+        nxt = vrx_load_words<FMT>(ent, b + off + 64, off + 64 + lane < len);
+        vrx_spmm_batch<LPE, CPL, MODE, FMT, false>(cur, 64, g, kc, (uint32_t)K, X, a1, a2);
     }
+    if (off < len)
+        vrx_spmm_batch<LPE, CPL, MODE, FMT, true>(nxt, len - off, g, kc, (uint32_t)K, X, a1, a2);
+#pragma unroll
+    for (int s = LPE; s < 64; s <<= 1)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            a1[c] += __shfl_xor(a1[c], s, 64);
+            if (MODE == 0) a2[c] += __shfl_xor(a2[c], s, 64);
+        }
     if (g == 0 && kok) {
         const int d = seg_dst[seg];
         double* base = d >= 0 ? out : partial;
         const int64_t row = d >= 0 ? d : -(int64_t)d - 1;
-        if (MODE == 0)
-            reinterpret_cast<double2*>(base)[row * K + k] = make_double2(a1, a2);
-        else
-            base[row * K + k] = a1;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            if (MODE == 0)
+                reinterpret_cast<double2*>(base)[row * K + k + c] = make_double2(a1[c], a2[c]);
+            else
+                base[row * K + k + c] = a1[c];
+        }
     }
 }
 
@@ -527,15 +587,18 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_log_rows(int64_t rows, int C,
 // binomial-coefficient constant  (get_binom_coeff, vireo_base.py:7-22)
 //   sum over dp>0 of float32( min( log C(dp, ad), 700 ) )
 // ------------------------------------------------------------------------------------
+template <int FMT>
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_binom_partial(int64_t nnz,
-                                                               const int2* __restrict__ val,
+                                                               const uint32_t* __restrict__ ent,
                                                                double* __restrict__ part) {
     double acc[1] = {0.0};
     for (int64_t e = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x; e < nnz;
          e += (int64_t)gridDim.x * VRX_BLOCK) {
-        const int2 v = val[e];
-        if (v.y > 0) {
-            const double n = (double)v.y, k = (double)v.x;
+        uint32_t id;
+        int ad, dp;
+        vrx_unpack<FMT>(vrx_load_words<FMT>(ent, e, true), id, ad, dp);
+        if (dp > 0) {
+            const double n = (double)dp, k = (double)ad;
             double c = lgamma(n + 1.0) - lgamma(k + 1.0) - lgamma(n - k + 1.0);
             if (c > 700.0) c = 700.0;
             acc[0] += (double)(float)c;

@@ -14,6 +14,9 @@ CONFIGS = {
     "c3": (100000, 50000, 16, 0.02),
     "mid": (50000, 20000, 16, 0.02),
     "small": (2000, 1000, 4, 0.02),
+    # locality probes (same nnz and nnz/row as c3, dense operand of ONE pass fits an XCD's L2)
+    "l2c": (6250, 50000, 16, 0.32),     # W  = 1.6 MB
+    "l2v": (100000, 6250, 16, 0.16),    # ID = 0.8 MB
 }
 
 
