@@ -114,12 +114,20 @@ def main():
         dm.set_state(host.ID_prob, host.GT_prob, host.beta_mu, host.beta_sum)
         if not args.no_cpu:
             dt, elbo_cpu, st = cpu_baseline_leg(w, K, seed=1)
+            # after ONE iteration from a random start the posteriors are still uniform to
+            # ~3e-7, so a few cells have a top-2 gap below fp64 summation-order noise; they
+            # are counted separately
+            srt = np.sort(st.ID_prob, axis=1)
+            near_tie = (srt[:, -1] - srt[:, -2]) <= 1e-9 * srt[:, -1]
+            differ = ID1.argmax(1) != st.ID_prob.argmax(1)
             parity = dict(elbo_gpu=float(first[0]), elbo_cpu=float(elbo_cpu),
                           elbo_rel_err=float(abs(first[0] - elbo_cpu) / abs(elbo_cpu)),
                           id_prob_max_rel_err=float(np.max(
                               np.abs(ID1 - st.ID_prob) / np.maximum(st.ID_prob, 1e-300))),
-                          assignments_identical=bool(
-                              np.array_equal(ID1.argmax(1), st.ID_prob.argmax(1))))
+                          assignment_mismatches=int(differ.sum()),
+                          near_tie_cells=int(near_tie.sum()),
+                          assignments_identical_outside_near_ties=bool(
+                              not np.any(differ & ~near_tie)))
             cpu = dict(value=1.0 / dt, unit="EM iterations/s", cores=1, kind="port",
                        sample="1 full-size EM iteration (theta+GT+ID+ELBO) of the NumPy/SciPy "
                               "oracle (the reference's 13 SpMM + 2 sparse-subtract op sequence, "
