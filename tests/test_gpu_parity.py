@@ -323,6 +323,30 @@ def test_entry_formats_and_tiling_vs_oracle(va, monkeypatch, fmt, tiles_c, tiles
     close(counts.binom_const(), O.binom_const(AD, DP), rtol=1e-6)
 
 
+@pytest.mark.parametrize("fmt,blocks", [(0, 2048), (1, 1), (2, 40)])
+def test_lds_resident_passes_vs_oracle(va, monkeypatch, fmt, blocks):
+    """the LDS-resident (two-dimensionally tiled) passes, forced on a small ragged problem:
+    one or many contracted ranges, K = 16 / 12 / 8 / 4 (both passes in LDS; 4, 4 (one idle),
+    2 and 1 lanes per row) and K = 9 (not a multiple of 4: global-gather kernels)."""
+    from vireo_amd.counts import DeviceCounts
+    monkeypatch.setenv("VIREO_LDS", "1")
+    monkeypatch.setenv("VIREO_LDS_BLOCKS", str(blocks))
+    monkeypatch.setenv("VIREO_ENTRY_FMT", str(fmt))
+    AD, DP = _ragged_case(seed=4)
+    counts = DeviceCounts(AD, DP)
+    for K in (16, 12, 8, 4, 9):
+        np.random.seed(11)
+        ref = O.vireo_new(AD.shape[1], AD.shape[0], K)
+        np.random.seed(11)
+        dev = va.Vireo(n_var=AD.shape[0], n_cell=AD.shape[1], n_donor=K)
+        O.vireo_fit(ref, AD, DP, max_iter=7)
+        dev.fit(counts, None, max_iter=7, verbose=False)
+        assert len(dev.ELBO_) == len(ref.ELBO_)
+        close(dev.ELBO_, ref.ELBO_)
+        close(dev.ID_prob, ref.ID_prob)
+        close(dev.GT_prob, ref.GT_prob)
+
+
 def test_determinism(va):
     AD, DP = O.synth_donor(3000, 2000, 16, 0.03, seed=5)
     runs = []

@@ -70,7 +70,21 @@ struct DevBuf {
 // XCD t % 8.  seg_len < 0 marks padding.  Rows with exactly one segment write their result
 // in place (seg_dst >= 0: the row); rows with several write partial sums into slots
 // (seg_dst = -(slot+1)) that `multi_*` lists for the in-order second stage.
+// Tiled copy of one orientation for the LDS-resident pass (vrx_spmm_lds): entries ordered
+// (row tile, wave, slab, row, index) with slab-local indices; bnd holds per wave the stream
+// offset of every (slab, row) segment start (+ one end marker).
+struct TiledStream {
+    bool ready = false;
+    int rw = 0, slab_rows = 0, n_slab = 0, n_tile = 0;
+    int pad = 4;  // every (slab,row) segment is padded to this many entries (= entries/step)
+    int n_range = 1, slabs_per_range = 0;
+    DevBuf<uint32_t> ent;
+    DevBuf<int64_t> wave_start;
+    DevBuf<int32_t> bnd;
+};
+
 struct Orient {
+    TiledStream tiled;
     int64_t n_rows = 0, n_contract = 0, nnz = 0;
     int fmt = 2;
     int n_tiles = 1;

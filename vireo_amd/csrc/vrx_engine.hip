@@ -205,6 +205,74 @@ static int build_orient(Orient& o, int64_t n_rows, int64_t n_contract, const int
     return VRX_OK;
 }
 
+// Tiled entry stream for vrx_spmm_lds (see vrx_kernels.h): rw rows per wave, 16 waves per
+// tile, slabs of slab_rows contracted indices.
+static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const int2* val, int rw,
+                       int slab_rows, int pad, hipStream_t s) {
+    TiledStream& t = o.tiled;
+    t.pad = pad;
+    t.rw = rw;
+    t.slab_rows = slab_rows;
+    t.n_slab = (int)((o.n_contract + slab_rows - 1) / slab_rows);
+    const int64_t tile_rows = 16 * (int64_t)rw;
+    t.n_tile = (int)((o.n_rows + tile_rows - 1) / tile_rows);
+    const int want = env_int("VIREO_LDS_BLOCKS", 2048);
+    int n_range = std::max(1, std::min(t.n_slab, (want + t.n_tile - 1) / t.n_tile));
+    t.slabs_per_range = (t.n_slab + n_range - 1) / n_range;
+    t.n_range = (t.n_slab + t.slabs_per_range - 1) / t.slabs_per_range;
+    const int64_t n_wave = (int64_t)t.n_tile * 16;
+    const int64_t per_wave = (int64_t)t.n_slab * rw + 1;
+    if (n_wave * per_wave >= ((int64_t)1 << 40)) {
+        vrx_set_error("tiled stream too large");
+        return VRX_ERR_UNSUPPORTED;
+    }
+    std::vector<uint32_t> ent;
+    ent.reserve((size_t)(o.nnz * 1.3) + 1024);
+    std::vector<int64_t> wave_start((size_t)n_wave);
+    std::vector<int32_t> bnd((size_t)(n_wave * per_wave));
+    std::vector<int64_t> cursor((size_t)rw);
+    int64_t cur = 0;  // position in the padded stream, in entries
+    for (int64_t w = 0; w < n_wave; ++w) {
+        const int64_t r0 = w * rw;
+        while (cur % pad) {  // every wave's stream starts 16-B aligned (dwordx4 ring refills)
+            ent.push_back(0u);
+            ++cur;
+        }
+        wave_start[(size_t)w] = cur;
+        for (int c = 0; c < rw; ++c) cursor[(size_t)c] = r0 + c < o.n_rows ? ptr[r0 + c] : 0;
+        int32_t* b = bnd.data() + w * per_wave;
+        for (int sl = 0; sl < t.n_slab; ++sl) {
+            const int64_t lim = (int64_t)(sl + 1) * slab_rows, base = (int64_t)sl * slab_rows;
+            for (int c = 0; c < rw; ++c) {
+                const int64_t rel = cur - wave_start[(size_t)w];
+                if (rel >= INT32_MAX - 64) {
+                    vrx_set_error("tiled stream: wave stream >= 2^31 entries");
+                    return VRX_ERR_UNSUPPORTED;
+                }
+                b[(int64_t)sl * rw + c] = (int32_t)rel;
+                if (r0 + c >= o.n_rows) continue;
+                const int64_t hi = ptr[r0 + c + 1];
+                int64_t& at = cursor[(size_t)c];
+                while (at < hi && idx[at] < lim) {
+                    const uint32_t id = (uint32_t)(idx[at] - base), ad = (uint32_t)val[at].x,
+                                   dp = (uint32_t)val[at].y;
+                    ent.push_back((id << 22) | (ad << 11) | dp);  // index:10 | ad:11 | dp:11
+                    ++cur;
+                    ++at;
+                }
+            }
+        }
+        b[(int64_t)t.n_slab * rw] = (int32_t)(cur - wave_start[(size_t)w]);
+    }
+    for (int i = 0; i < 8; ++i) ent.push_back(0u);  // slack for the last dwordx4 refill
+    VRX_HIP(t.ent.upload(ent.data(), ent.size(), s));
+    VRX_HIP(t.wave_start.upload(wave_start.data(), wave_start.size(), s));
+    VRX_HIP(t.bnd.upload(bnd.data(), bnd.size(), s));
+    VRX_HIP(hipStreamSynchronize(s));
+    t.ready = true;
+    return VRX_OK;
+}
+
 extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int64_t nnz,
                                   const int64_t* colptr, const int32_t* rowidx, const int32_t* ad,
                                   const int32_t* dp, vrx_problem** out) {
@@ -292,6 +360,16 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
     rc = build_orient(p->by_var, n_var, n_cell, rptr.data(), ridx.data(), rval.data(), colptr,
                       tiles_v, pick_fmt(n_cell), p->stream);
     if (rc) return rc;
+    // LDS-resident passes (vrx_spmm_lds): EXPERIMENTAL, opt-in with VIREO_LDS=1.  Parity-tested,
+    // but on MI355X they do not yet beat the L2-tiled global-gather kernels.
+    if (max_count < 2048 && env_int("VIREO_LDS", 0) == 1) {
+        // cell pass: slabs of 512 W rows (128 KiB at K = 16); variant pass: 1024 ID rows
+        rc = build_tiled(p->by_cell, colptr, rowidx, cval.data(), VRX_LDS_RW, 512, 4, p->stream);
+        if (rc) return rc;
+        rc = build_tiled(p->by_var, rptr.data(), ridx.data(), rval.data(), VRX_LDS_RW, 1024, 4,
+                         p->stream);
+        if (rc) return rc;
+    }
     *out = p.release();
     return VRX_OK;
 }
@@ -358,6 +436,7 @@ struct vrx_model {
     DevBuf<double> W;    // [N][K] double2  (W1, W2)
     DevBuf<double> LID;  // [M][K]          logLik_ID
     DevBuf<double> PV, PC;  // split-row partial slots
+    DevBuf<double> RV, RC;  // per-range partials of the LDS-resident passes
     // priors
     DevBuf<double> logq_id, logq_gt, prior1, prior2, tmp;
     int id_mode = 0, gt_mode = 0;
@@ -420,6 +499,9 @@ static int prof_drain(vrx_model* m) {
     return VRX_OK;
 }
 
+template <int MODE>
+static bool lds_eligible(const Orient& o, int K);
+
 extern "C" int vrx_model_create(vrx_problem* p, const vrx_model_cfg* cfg, vrx_model** out) {
     VRX_REQUIRE(p && cfg && out, "vrx_model_create: null argument");
     *out = nullptr;
@@ -460,6 +542,10 @@ extern "C" int vrx_model_create(vrx_problem* p, const vrx_model_cfg* cfg, vrx_mo
     VRX_HIP(m->W.alloc((size_t)m->NK * 2));
     VRX_HIP(m->PV.alloc((size_t)(p->by_var.n_slots * m->K * 2)));
     VRX_HIP(m->PC.alloc((size_t)(p->by_cell.n_slots * m->K)));
+    if (lds_eligible<0>(p->by_var, m->K) && p->by_var.tiled.n_range > 1)
+        VRX_HIP(m->RV.alloc((size_t)(p->by_var.tiled.n_range * m->NK * 2)));
+    if (lds_eligible<1>(p->by_cell, m->K) && p->by_cell.tiled.n_range > 1)
+        VRX_HIP(m->RC.alloc((size_t)(p->by_cell.tiled.n_range * m->M * m->K)));
     // rows without entries are never written by the passes: zero once
     VRX_HIP(hipMemsetAsync(m->S.p, 0, (size_t)m->NK * 2 * sizeof(double), s));
     VRX_HIP(hipMemsetAsync(m->LID.p, 0, (size_t)(m->M * m->K) * sizeof(double), s));
@@ -642,6 +728,47 @@ static void launch_spmm_fmt(const Orient& o, dim3 grid, hipStream_t s, const dou
 #undef VRX_GO
 }
 
+// LDS-resident pass: K a multiple of 4 up to 16 (4 columns per lane), counts < 2048 (checked
+// when the tiled stream is built)
+template <int MODE>
+static bool lds_eligible(const Orient& o, int K) {
+    static const int mask = env_int("VIREO_LDS_PASS", 3);  // bit 0: variant pass, bit 1: cell pass
+    return o.tiled.ready && (mask >> MODE & 1) && K <= 16 && K % 4 == 0;
+}
+
+template <int LPE, int MODE>
+static int launch_lds_one(const Orient& o, hipStream_t s, const double* X, int K, double* dst) {
+    const TiledStream& t = o.tiled;
+    const size_t lds = (size_t)t.slab_rows * K * (MODE == 1 ? 16 : 8) + 16 * VRX_RING * 4;
+    dim3 grid((unsigned)t.n_tile, (unsigned)t.n_range);
+    auto kern = vrx_spmm_lds<LPE, MODE>;
+    VRX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    kern<<<grid, 1024, lds, s>>>(t.ent.p, t.wave_start.p, t.bnd.p, t.n_slab, t.slab_rows,
+                                 t.slabs_per_range, o.n_contract, o.n_rows, X, K, dst);
+    VRX_HIP(hipGetLastError());
+    return VRX_OK;
+}
+
+template <int MODE>
+static int launch_spmm_lds(vrx_model* m, const Orient& o, const double* X, int K, double* out,
+                           double* range_partial) {
+    hipStream_t s = m->p->stream;
+    const TiledStream& t = o.tiled;
+    constexpr int NV = MODE == 0 ? 2 : 1;
+    double* dst = t.n_range == 1 ? out : range_partial;
+    int rc;
+    rc = launch_lds_one<4, MODE>(o, s, X, K, dst);  // 4-lane groups; K < 16 leaves lanes idle
+    if (rc) return rc;
+    if (t.n_range > 1) {
+        const int64_t n = o.n_rows * K * NV;
+        vrx_sum_ranges<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
+            n, t.n_range, range_partial, out);
+        VRX_HIP(hipGetLastError());
+    }
+    return VRX_OK;
+}
+
 template <int MODE>
 static int launch_spmm(vrx_model* m, const Orient& o, const double* X, int K, double* out,
                        double* partial) {
@@ -684,12 +811,16 @@ static int launch_spmm(vrx_model* m, const Orient& o, const double* X, int K, do
 // S <- (AD @ ID_prob, DP @ ID_prob)        vireo_model.py:169-170,207-208; bmm_model.py:137-138
 static int variant_pass(vrx_model* m) {
     ProfScope ps(m, VRX_KERN_VARIANT_PASS);
+    if (lds_eligible<0>(m->p->by_var, m->K))
+        return launch_spmm_lds<0>(m, m->p->by_var, m->ID.p, m->K, m->S.p, m->RV.p);
     return launch_spmm<0>(m, m->p->by_var, m->ID.p, m->K, m->S.p, m->PV.p);
 }
 
 // LID <- AD^T W1 + DP^T W2                 vireo_model.py:190-196; bmm_model.py:125-129
 static int cell_pass(vrx_model* m) {
     ProfScope ps(m, VRX_KERN_CELL_PASS);
+    if (lds_eligible<1>(m->p->by_cell, m->K))
+        return launch_spmm_lds<1>(m, m->p->by_cell, m->W.p, m->K, m->LID.p, m->RC.p);
     return launch_spmm<1>(m, m->p->by_cell, m->W.p, m->K, m->LID.p, m->PC.p);
 }
 

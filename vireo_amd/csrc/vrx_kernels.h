@@ -255,6 +255,216 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_spmm(
     }
 }
 
+// ------------------------------------------------------------------------------------
+// LDS-resident variant of the sparse passes (large problems, K in {4,8,12,16}, counts < 2048)
+// ------------------------------------------------------------------------------------
+// The global-gather kernel above is bound by the L1-miss path: every non-zero pulls one or
+// two 128-B lines through the vector cache.  Here the dense operand is streamed through
+// LDS instead (ds_read_b128: 4 clk per KiB against ~29 clk for a gathering
+// global_load_dwordx4), which needs BOTH dimensions tiled:
+//   * a workgroup (16 waves) owns a tile of 16*RW output rows; wave w owns RW of them;
+//   * the contracted dimension is cut into slabs of `slab_rows` dense rows (<= 128 KiB);
+//     the workgroup walks the slabs of its range in order, staging each slab into LDS with
+//     coalesced loads issued one slab ahead (register prefetch);
+//   * inside a wave, LPE = K/4 lanes form a group that owns ONE output row at a time
+//     (G = 64/LPE rows per round, RW/G rounds) and each lane owns 4 columns of it, so the
+//     per-entry overhead (unpack, convert, address) is paid by 4 lanes instead of 16 and a
+//     row's sums never leave its lanes: no cross-lane traffic at all;
+//   * entries are stored in tiled order (tile, wave, slab, row), one 32-bit word each
+//     (slab-local index:10 | ad:11 | dp:11), so every wave reads ONE contiguous stream; it
+//     is staged through a 512-entry LDS ring in 256-entry chunks prefetched two chunks
+//     ahead; bnd[] holds, per wave, the stream offset of every (slab, row) segment;
+//   * a group walks its own segment two entries per trip; the trip count of a round is the
+//     longest of its G segments (shorter ones run masked) -- with ~10 entries per segment
+//     that costs ~1.7 slots per entry, which the 4x lower per-slot cost more than repays;
+//   * the 4 columns of a lane are visited in a group-dependent rotation so that the
+//     16 lanes serviced together by ds_read_b128 hit 16 different 16-B bank slots.
+// Output: one partial array per contracted range (summed in fixed order afterwards).
+constexpr int VRX_RING = 512;   // entries per wave
+constexpr int VRX_CHUNK = 256;  // entries per refill (64 lanes x dwordx4)
+constexpr int VRX_LDS_RW = 48;  // output rows per wave (tile = 768 rows)
+
+template <int LPE, int MODE>
+__global__ __launch_bounds__(1024) void vrx_spmm_lds(
+    const uint32_t* __restrict__ ent, const int64_t* __restrict__ wave_start,
+    const int32_t* __restrict__ bnd, int n_slab, int slab_rows, int slabs_per_range,
+    int64_t n_contract, int64_t n_rows, const double* __restrict__ X, int K,
+    double* __restrict__ out) {
+    constexpr int RW = VRX_LDS_RW;
+    constexpr int G = 64 / LPE;            // rows per round
+    constexpr int NR = RW / G;             // rounds
+    constexpr int XD = MODE == 1 ? 2 : 1;  // doubles per (contracted row, column)
+    constexpr int NQ = 2 * XD;             // 16-B reads per lane per entry (4 columns)
+    constexpr int PF = 8;                  // 16-B prefetch registers per thread: 128 KiB / 1024
+    constexpr int NV = MODE == 0 ? 2 : 1;  // accumulated values per column
+    constexpr int U = 2;                   // entries per trip and group
+    static_assert(RW % G == 0 && RW < 64, "rows per wave");
+    extern __shared__ __attribute__((aligned(16))) char vrx_smem[];
+    double* slab = reinterpret_cast<double*>(vrx_smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slab_doubles = slab_rows * K * XD;
+    uint32_t* ring = reinterpret_cast<uint32_t*>(slab + slab_doubles) + wave * VRX_RING;
+    const int tile = blockIdx.x;
+    const int s_lo = blockIdx.y * slabs_per_range;
+    const int s_hi = min(s_lo + slabs_per_range, n_slab);
+    if (s_lo >= s_hi) return;
+    const int g = lane / LPE, kl = lane % LPE;
+    const bool kok = kl * 4 < K;  // K is a multiple of 4
+    const int64_t wid = (int64_t)tile * 16 + wave;
+    const int32_t* bw = bnd + wid * ((int64_t)n_slab * RW + 1);
+    const uint32_t* stream = ent + wave_start[wid];
+    // byte offset, inside a dense row, of the q-th 16-B slice this lane reads (rotated by g)
+    int qoff[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) qoff[q] = (kok ? kl : 0) * (NQ * 16) + ((q + g) % NQ) * 16;
+    const int row_bytes = K * XD * 8;
+
+    double acc[NR][NQ][2];  // [round][slice][half]: cell pass (w1,w2)->1 value; variant: 2 cols x2
+    double acc2[NR][NQ][2];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[r][q][0] = acc[r][q][1] = acc2[r][q][0] = acc2[r][q][1] = 0.0;
+
+    // ---- slab prefetch (global -> registers), one slab ahead ---------------------------
+    double2 pf[PF];
+    auto slab_fetch = [&](int s) {
+        const int64_t row0 = (int64_t)s * slab_rows;
+        const int64_t rows = min((int64_t)slab_rows, n_contract - row0);
+        const int n16 = (int)(rows * K * XD / 2);
+        const double2* src = reinterpret_cast<const double2*>(X + row0 * K * XD);
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int at = threadIdx.x + i * 1024;
+            pf[i] = at < n16 ? src[at] : make_double2(0.0, 0.0);
+        }
+    };
+    auto slab_store = [&]() {
+        double2* dst = reinterpret_cast<double2*>(slab);
+        const int n16 = slab_doubles / 2;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int at = threadIdx.x + i * 1024;
+            if (at < n16) dst[at] = pf[i];
+        }
+    };
+
+    // ---- entry stream: ring of 512 entries refilled 256 at a time, 2 chunks ahead ---------
+    const int stream_lo = __builtin_amdgcn_readfirstlane(bw[(int64_t)s_lo * RW]) & ~3;
+    const int stream_end = __builtin_amdgcn_readfirstlane(bw[(int64_t)s_hi * RW]);
+    int staged_end = stream_lo;
+    auto chunk_load = [&](int from) {  // entries [from + 4*lane, +4); zero beyond the stream
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (from + 4 * lane < stream_end)  // (the stream is padded to a multiple of 4 words)
+            v = *reinterpret_cast<const uint4*>(stream + from + 4 * lane);
+        return v;
+    };
+    uint4 pre0 = chunk_load(stream_lo), pre1 = chunk_load(stream_lo + VRX_CHUNK);
+    auto stage_chunk = [&]() {
+        *reinterpret_cast<uint4*>(ring + ((staged_end + 4 * lane) & (VRX_RING - 1))) = pre0;
+        staged_end += VRX_CHUNK;
+        pre0 = pre1;
+        pre1 = chunk_load(staged_end + VRX_CHUNK);
+    };
+    // one entry of this group's segment: word -> 4 column slices -> FMAs
+    auto entry = [&](uint32_t w, double (&a)[NQ][2], double (&a2)[NQ][2]) {
+        const double ad = (double)((w >> 11) & 2047u), dp = (double)(w & 2047u);
+        const char* rowp = reinterpret_cast<const char*>(slab) + (w >> 22) * row_bytes;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const double2 x = *reinterpret_cast<const double2*>(rowp + qoff[q]);
+            if (MODE == 1) {  // x = (w1, w2) of one column
+                a[q][0] = fma(ad, x.x, a[q][0]);
+                a[q][0] = fma(dp, x.y, a[q][0]);
+            } else {  // x = ID_prob of two adjacent columns
+                a[q][0] = fma(ad, x.x, a[q][0]);
+                a[q][1] = fma(ad, x.y, a[q][1]);
+                a2[q][0] = fma(dp, x.x, a2[q][0]);
+                a2[q][1] = fma(dp, x.y, a2[q][1]);
+            }
+        }
+    };
+
+    int bvec = bw[(int64_t)s_lo * RW + min(lane, RW)];
+    slab_fetch(s_lo);
+    for (int s = s_lo; s < s_hi; ++s) {
+        __syncthreads();  // every wave is done reading the previous slab
+        slab_store();
+        if (s + 1 < s_hi) slab_fetch(s + 1);
+        const int bcur = bvec;
+        if (s + 1 < s_hi) bvec = bw[(int64_t)(s + 1) * RW + min(lane, RW)];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int p0 = __builtin_amdgcn_readlane(bcur, r * G);
+            const int pE = __builtin_amdgcn_readlane(bcur, r * G + G);
+            const int my_at = __shfl(bcur, r * G + g, 64);
+            const int my_e = __shfl(bcur, r * G + g + 1, 64);
+            if (pE - p0 <= VRX_CHUNK - 64) {
+                while (staged_end < min(pE, stream_end)) stage_chunk();
+                int longest = my_e - my_at;
+#pragma unroll
+                for (int sft = 32; sft >= LPE; sft >>= 1)
+                    longest = max(longest, __shfl_xor(longest, sft, 64));
+                longest = __builtin_amdgcn_readfirstlane(longest);
+                for (int j = 0; j < longest; j += U) {
+                    uint32_t w[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int pos = my_at + j + u;
+                        w[u] = ring[pos & (VRX_RING - 1)];
+                        if (pos >= my_e) w[u] = 0u;  // index 0, ad = dp = 0
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) entry(w[u], acc[r], acc2[r]);
+                }
+            } else {  // a round spanning more than the ring can hold: one row at a time
+                for (int q = 0; q < G; ++q) {
+                    int at = __builtin_amdgcn_readlane(bcur, r * G + q);
+                    const int e = __builtin_amdgcn_readlane(bcur, r * G + q + 1);
+                    for (; at < e; ++at) {
+                        while (staged_end <= at) stage_chunk();
+                        const uint32_t w = g == q ? ring[at & (VRX_RING - 1)] : 0u;
+                        entry(w, acc[r], acc2[r]);
+                    }
+                }
+            }
+        }
+    }
+    // ---- every group holds the complete sums of its rows: store them ------------------------
+    double* dst = out + (int64_t)blockIdx.y * n_rows * K * NV;
+    if (kok) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int64_t row = ((int64_t)tile * 16 + wave) * RW + r * G + g;
+            if (row < n_rows) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int slice = kl * NQ + (q + g) % NQ;  // 16-B slice of the dense row
+                    if (MODE == 1) {
+                        dst[row * K + slice] = acc[r][q][0];
+                    } else {  // columns 2*slice, 2*slice+1; S[row][k] = (s1, ss)
+                        double2* o = reinterpret_cast<double2*>(dst) + row * K + 2 * slice;
+                        o[0] = make_double2(acc[r][q][0], acc2[r][q][0]);
+                        o[1] = make_double2(acc[r][q][1], acc2[r][q][1]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// partial[range][...] summed over the contracted ranges in order
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_ranges(int64_t n, int n_range,
+                                                            const double* __restrict__ partial,
+                                                            double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int r = 0; r < n_range; ++r) s += partial[(int64_t)r * n + i];
+    out[i] = s;
+}
+
 // Second stage for rows that were split over several segments: in-order sum of the slots.
 // VPE = values per element (2 for the variant pass, 1 for the cell pass).
 template <int VPE>
