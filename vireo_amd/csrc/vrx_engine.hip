@@ -205,64 +205,73 @@ static int build_orient(Orient& o, int64_t n_rows, int64_t n_contract, const int
     return VRX_OK;
 }
 
-// Tiled entry stream for vrx_spmm_lds (see vrx_kernels.h): rw rows per wave, 16 waves per
-// tile, slabs of slab_rows contracted indices.
-static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const int2* val, int rw,
-                       int slab_rows, int pad, hipStream_t s) {
+// Tiled entry stream for vrx_spmm_lds (see vrx_kernels.h): VRX_LDS_RW rows per wave handled
+// 16 at a time (a round), 16 waves per tile, slabs of slab_rows contracted indices; inside a
+// round the words are trip-major and zero-padded to the round's longest row.
+static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const int2* val,
+                       int slab_rows, hipStream_t s) {
+    constexpr int RW = VRX_LDS_RW, G = 16, NR = RW / G, U = 2;
     TiledStream& t = o.tiled;
-    t.pad = pad;
-    t.rw = rw;
+    t.pad = 4;
+    t.rw = RW;
     t.slab_rows = slab_rows;
     t.n_slab = (int)((o.n_contract + slab_rows - 1) / slab_rows);
-    const int64_t tile_rows = 16 * (int64_t)rw;
+    const int64_t tile_rows = 16 * (int64_t)RW;
     t.n_tile = (int)((o.n_rows + tile_rows - 1) / tile_rows);
-    const int want = env_int("VIREO_LDS_BLOCKS", 2048);
+    const int want = env_int("VIREO_LDS_BLOCKS", 1024);
     int n_range = std::max(1, std::min(t.n_slab, (want + t.n_tile - 1) / t.n_tile));
     t.slabs_per_range = (t.n_slab + n_range - 1) / n_range;
     t.n_range = (t.n_slab + t.slabs_per_range - 1) / t.slabs_per_range;
     const int64_t n_wave = (int64_t)t.n_tile * 16;
-    const int64_t per_wave = (int64_t)t.n_slab * rw + 1;
-    if (n_wave * per_wave >= ((int64_t)1 << 40)) {
-        vrx_set_error("tiled stream too large");
-        return VRX_ERR_UNSUPPORTED;
-    }
+    const int64_t per_wave = (int64_t)t.n_slab * NR + 1;
     std::vector<uint32_t> ent;
-    ent.reserve((size_t)(o.nnz * 1.3) + 1024);
+    ent.reserve((size_t)(o.nnz * 1.9) + 1024);
     std::vector<int64_t> wave_start((size_t)n_wave);
     std::vector<int32_t> bnd((size_t)(n_wave * per_wave));
-    std::vector<int64_t> cursor((size_t)rw);
-    int64_t cur = 0;  // position in the padded stream, in entries
+    std::vector<int64_t> cursor((size_t)RW), seg_lo((size_t)G), seg_hi((size_t)G);
     for (int64_t w = 0; w < n_wave; ++w) {
-        const int64_t r0 = w * rw;
-        while (cur % pad) {  // every wave's stream starts 16-B aligned (dwordx4 ring refills)
-            ent.push_back(0u);
-            ++cur;
-        }
-        wave_start[(size_t)w] = cur;
-        for (int c = 0; c < rw; ++c) cursor[(size_t)c] = r0 + c < o.n_rows ? ptr[r0 + c] : 0;
+        const int64_t r0 = w * RW;
+        while (ent.size() % 4) ent.push_back(0u);  // 16-B aligned start (dwordx4 refills)
+        const int64_t start = (int64_t)ent.size();
+        wave_start[(size_t)w] = start;
+        for (int c = 0; c < RW; ++c) cursor[(size_t)c] = r0 + c < o.n_rows ? ptr[r0 + c] : 0;
         int32_t* b = bnd.data() + w * per_wave;
         for (int sl = 0; sl < t.n_slab; ++sl) {
             const int64_t lim = (int64_t)(sl + 1) * slab_rows, base = (int64_t)sl * slab_rows;
-            for (int c = 0; c < rw; ++c) {
-                const int64_t rel = cur - wave_start[(size_t)w];
-                if (rel >= INT32_MAX - 64) {
-                    vrx_set_error("tiled stream: wave stream >= 2^31 entries");
+            for (int r = 0; r < NR; ++r) {
+                const int64_t rel = (int64_t)ent.size() - start;
+                if (rel >= INT32_MAX - 4096) {
+                    vrx_set_error("tiled stream: wave stream >= 2^31 words");
                     return VRX_ERR_UNSUPPORTED;
                 }
-                b[(int64_t)sl * rw + c] = (int32_t)rel;
-                if (r0 + c >= o.n_rows) continue;
-                const int64_t hi = ptr[r0 + c + 1];
-                int64_t& at = cursor[(size_t)c];
-                while (at < hi && idx[at] < lim) {
-                    const uint32_t id = (uint32_t)(idx[at] - base), ad = (uint32_t)val[at].x,
-                                   dp = (uint32_t)val[at].y;
-                    ent.push_back((id << 22) | (ad << 11) | dp);  // index:10 | ad:11 | dp:11
-                    ++cur;
-                    ++at;
+                b[(int64_t)sl * NR + r] = (int32_t)rel;
+                int64_t longest = 0;
+                for (int g = 0; g < G; ++g) {
+                    const int64_t row = r0 + (int64_t)r * G + g;
+                    int64_t lo = 0, hi = 0;
+                    if (row < o.n_rows) {
+                        lo = hi = cursor[(size_t)(r * G + g)];
+                        const int64_t stop = ptr[row + 1];
+                        while (hi < stop && idx[hi] < lim) ++hi;
+                        cursor[(size_t)(r * G + g)] = hi;
+                    }
+                    seg_lo[(size_t)g] = lo;
+                    seg_hi[(size_t)g] = hi;
+                    longest = std::max(longest, hi - lo);
                 }
+                longest = (longest + U - 1) / U * U;
+                for (int64_t j = 0; j < longest; ++j)
+                    for (int g = 0; g < G; ++g) {
+                        const int64_t e = seg_lo[(size_t)g] + j;
+                        uint32_t word = 0u;  // padding: index 0, ad = dp = 0
+                        if (e < seg_hi[(size_t)g])
+                            word = ((uint32_t)(idx[e] - base) << 22) | ((uint32_t)val[e].x << 11) |
+                                   (uint32_t)val[e].y;
+                        ent.push_back(word);
+                    }
             }
         }
-        b[(int64_t)t.n_slab * rw] = (int32_t)(cur - wave_start[(size_t)w]);
+        b[(int64_t)t.n_slab * NR] = (int32_t)((int64_t)ent.size() - start);
     }
     for (int i = 0; i < 8; ++i) ent.push_back(0u);  // slack for the last dwordx4 refill
     VRX_HIP(t.ent.upload(ent.data(), ent.size(), s));
@@ -364,10 +373,9 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
     // but on MI355X they do not yet beat the L2-tiled global-gather kernels.
     if (max_count < 2048 && env_int("VIREO_LDS", 0) == 1) {
         // cell pass: slabs of 512 W rows (128 KiB at K = 16); variant pass: 1024 ID rows
-        rc = build_tiled(p->by_cell, colptr, rowidx, cval.data(), VRX_LDS_RW, 512, 4, p->stream);
+        rc = build_tiled(p->by_cell, colptr, rowidx, cval.data(), 512, p->stream);
         if (rc) return rc;
-        rc = build_tiled(p->by_var, rptr.data(), ridx.data(), rval.data(), VRX_LDS_RW, 1024, 4,
-                         p->stream);
+        rc = build_tiled(p->by_var, rptr.data(), ridx.data(), rval.data(), 1024, p->stream);
         if (rc) return rc;
     }
     *out = p.release();

@@ -270,13 +270,14 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_spmm(
 //     (G = 64/LPE rows per round, RW/G rounds) and each lane owns 4 columns of it, so the
 //     per-entry overhead (unpack, convert, address) is paid by 4 lanes instead of 16 and a
 //     row's sums never leave its lanes: no cross-lane traffic at all;
-//   * entries are stored in tiled order (tile, wave, slab, row), one 32-bit word each
-//     (slab-local index:10 | ad:11 | dp:11), so every wave reads ONE contiguous stream; it
-//     is staged through a 512-entry LDS ring in 256-entry chunks prefetched two chunks
-//     ahead; bnd[] holds, per wave, the stream offset of every (slab, row) segment;
-//   * a group walks its own segment two entries per trip; the trip count of a round is the
-//     longest of its G segments (shorter ones run masked) -- with ~10 entries per segment
-//     that costs ~1.7 slots per entry, which the 4x lower per-slot cost more than repays;
+//   * entries are one 32-bit word each (slab-local index:10 | ad:11 | dp:11), stored in
+//     tiled order (tile, wave, slab, round) and TRIP-MAJOR inside a round: word j*G + g is
+//     the j-th entry of group g's row, zero words padding every row to the round's longest
+//     (rounded up to 2).  Every wave thus reads ONE contiguous stream in lock-step with its
+//     compute, staged through a 512-word LDS ring in 256-word chunks prefetched two chunks
+//     ahead; bnd[] holds, per wave, the stream offset of every (slab, round).  With ~10
+//     entries per row and slab the padding costs ~1.7 slots per entry, which the 4x lower
+//     per-slot instruction count more than repays;
 //   * the 4 columns of a lane are visited in a group-dependent rotation so that the
 //     16 lanes serviced together by ds_read_b128 hit 16 different 16-B bank slots.
 // Output: one partial array per contracted range (summed in fixed order afterwards).
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     const int g = lane / LPE, kl = lane % LPE;
     const bool kok = kl * 4 < K;  // K is a multiple of 4
     const int64_t wid = (int64_t)tile * 16 + wave;
-    const int32_t* bw = bnd + wid * ((int64_t)n_slab * RW + 1);
+    const int32_t* bw = bnd + wid * ((int64_t)n_slab * NR + 1);
     const uint32_t* stream = ent + wave_start[wid];
     // byte offset, inside a dense row, of the q-th 16-B slice this lane reads (rotated by g)
     int qoff[NQ];
@@ -350,8 +351,8 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     };
 
     // ---- entry stream: ring of 512 entries refilled 256 at a time, 2 chunks ahead ---------
-    const int stream_lo = __builtin_amdgcn_readfirstlane(bw[(int64_t)s_lo * RW]) & ~3;
-    const int stream_end = __builtin_amdgcn_readfirstlane(bw[(int64_t)s_hi * RW]);
+    const int stream_lo = __builtin_amdgcn_readfirstlane(bw[(int64_t)s_lo * NR]);
+    const int stream_end = __builtin_amdgcn_readfirstlane(bw[(int64_t)s_hi * NR]);
     int staged_end = stream_lo;
     auto chunk_load = [&](int from) {  // entries [from + 4*lane, +4); zero beyond the stream
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -385,49 +386,28 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
         }
     };
 
-    int bvec = bw[(int64_t)s_lo * RW + min(lane, RW)];
+    int bvec = bw[(int64_t)s_lo * NR + min(lane, NR)];
     slab_fetch(s_lo);
     for (int s = s_lo; s < s_hi; ++s) {
         __syncthreads();  // every wave is done reading the previous slab
         slab_store();
         if (s + 1 < s_hi) slab_fetch(s + 1);
         const int bcur = bvec;
-        if (s + 1 < s_hi) bvec = bw[(int64_t)(s + 1) * RW + min(lane, RW)];
+        if (s + 1 < s_hi) bvec = bw[(int64_t)(s + 1) * NR + min(lane, NR)];
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            const int p0 = __builtin_amdgcn_readlane(bcur, r * G);
-            const int pE = __builtin_amdgcn_readlane(bcur, r * G + G);
-            const int my_at = __shfl(bcur, r * G + g, 64);
-            const int my_e = __shfl(bcur, r * G + g + 1, 64);
-            if (pE - p0 <= VRX_CHUNK - 64) {
-                while (staged_end < min(pE, stream_end)) stage_chunk();
-                int longest = my_e - my_at;
+            // the round's entries are stored trip-major: word (base + j*G + g) is the j-th
+            // entry of the row owned by group g (zero words where that row is shorter)
+            const int base = __builtin_amdgcn_readlane(bcur, r);
+            const int end = __builtin_amdgcn_readlane(bcur, r + 1);
+            for (int at = base; at < end; at += U * G) {
+                if (at + U * G > staged_end) stage_chunk();  // wave-uniform, once per 256 words
+                uint32_t w[U];
 #pragma unroll
-                for (int sft = 32; sft >= LPE; sft >>= 1)
-                    longest = max(longest, __shfl_xor(longest, sft, 64));
-                longest = __builtin_amdgcn_readfirstlane(longest);
-                for (int j = 0; j < longest; j += U) {
-                    uint32_t w[U];
+                for (int u = 0; u < U; ++u) w[u] = ring[(at + u * G + g) & (VRX_RING - 1)];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int pos = my_at + j + u;
-                        w[u] = ring[pos & (VRX_RING - 1)];
-                        if (pos >= my_e) w[u] = 0u;  // index 0, ad = dp = 0
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; ++u) entry(w[u], acc[r], acc2[r]);
-                }
-            } else {  // a round spanning more than the ring can hold: one row at a time
-                for (int q = 0; q < G; ++q) {
-                    int at = __builtin_amdgcn_readlane(bcur, r * G + q);
-                    const int e = __builtin_amdgcn_readlane(bcur, r * G + q + 1);
-                    for (; at < e; ++at) {
-                        while (staged_end <= at) stage_chunk();
-                        const uint32_t w = g == q ? ring[at & (VRX_RING - 1)] : 0u;
-                        entry(w, acc[r], acc2[r]);
-                    }
-                }
+                for (int u = 0; u < U; ++u) entry(w[u], acc[r], acc2[r]);
             }
         }
     }
