@@ -156,6 +156,7 @@ def main():
     dm.profile(False)
 
     if rank == 0:
+        kinfo = dm.info()
         B = algorithmic_bytes(N, M, K, T, nnz)
         avg_v = ms[_lib.KERN_VARIANT_PASS] / max(n[_lib.KERN_VARIANT_PASS], 1)
         avg_c = ms[_lib.KERN_CELL_PASS] / max(n[_lib.KERN_CELL_PASS], 1)
@@ -177,8 +178,11 @@ def main():
                        "restart_elbos": [float(x) for x in np.ravel(last_elbos)],
                        "best_restart": int(np.argmax(last_elbos)),
                        "host_setup_s": {"generate": round(t_gen, 1), "upload+transpose": round(t_up, 1)}},
-            "roofline": {"bound": "hbm", "kernel": "vrx_spmm<%d,%d> (%s pass)"
-                         % (dm.K if dm.K in (1, 2, 4, 8, 16, 32, 64) else 0, 1 if dom == "cell" else 0, dom),
+            "roofline": {"bound": "hbm",
+                         "kernel": "%s (%s pass)" % (
+                             "vrx_spmm_lds<4,%d>" % (dom == "cell") if kinfo["lds_" + dom]
+                             else "vrx_spmm<..,%d,fmt%d>" % (dom == "cell", kinfo["fmt_" + dom]), dom),
+                         "kernel_info": kinfo,
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": B[dom],

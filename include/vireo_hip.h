@@ -157,6 +157,12 @@ int vrx_problem_cell_loglik(vrx_problem* p, int64_t n_col, int64_t n_class,
 #define VRX_KERN_CELL_PASS 1    /* cell-major sparse pass (AD,DP)^T*W                 */
 #define VRX_KERN_DENSE 2        /* all dense/epilogue kernels together                */
 #define VRX_KERN_COUNT 3
+/* which kernels this model's passes run: info[0]/[1] = 1 if the variant/cell pass is
+ * LDS-resident (vrx_spmm_lds) else 0 (vrx_spmm, global gathers); info[2]/[3] = entry format
+ * of the variant/cell orientation (0: 4 B, 1: 8 B, 2: 12 B per non-zero); info[4]/[5] =
+ * L2 tiles of the variant/cell orientation; info[6]/[7] = contracted ranges of the
+ * LDS-resident variant/cell pass. */
+int vrx_model_info(vrx_model* m, int32_t* info8);
 int vrx_model_profile(vrx_model* m, int32_t enable);
 int vrx_model_profile_read(vrx_model* m, double* ms_total /* VRX_KERN_COUNT */,
                            int64_t* launches /* VRX_KERN_COUNT */);

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvireo_hip.so")
+LIB_PATH = os.environ.get("VIREO_LIB", os.path.join(_HERE, "libvireo_hip.so"))  # (override: A/B builds)
 
 KIND_VIREO, KIND_BMM = 0, 1
 STEP_THETA, STEP_GT, STEP_ID, STEP_LOGLIK, STEP_ELBO, STEP_SOFTMAX = 1, 2, 3, 4, 5, 6
@@ -56,6 +56,7 @@ SIGNATURES = {
     "vrx_model_get_elbo_parts": (C.c_int, [_P, _D]),
     "vrx_problem_cell_loglik": (C.c_int, [_P, C.c_int64, C.c_int64, _D, _D, _D, _D, C.c_int64, _D,
                                           C.c_int64, _D, _D]),
+    "vrx_model_info": (C.c_int, [_P, _I32]),
     "vrx_model_profile": (C.c_int, [_P, C.c_int32]),
     "vrx_model_profile_read": (C.c_int, [_P, _D, _I64]),
     "vrx_model_run_iters": (C.c_int, [_P, C.c_int32, C.c_int32, _D, _D]),

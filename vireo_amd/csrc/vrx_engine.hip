@@ -210,7 +210,7 @@ static int build_orient(Orient& o, int64_t n_rows, int64_t n_contract, const int
 // round the words are trip-major and zero-padded to the round's longest row.
 static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const int2* val,
                        int slab_rows, hipStream_t s) {
-    constexpr int RW = VRX_LDS_RW, G = 16, NR = RW / G, U = 2;
+    constexpr int RW = VRX_LDS_RW, G = 16, NR = RW / G, U = VRX_LDS_U;
     TiledStream& t = o.tiled;
     t.pad = 4;
     t.rw = RW;
@@ -218,10 +218,11 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
     t.n_slab = (int)((o.n_contract + slab_rows - 1) / slab_rows);
     const int64_t tile_rows = 16 * (int64_t)RW;
     t.n_tile = (int)((o.n_rows + tile_rows - 1) / tile_rows);
+    // one workgroup per CU at a time (LDS), so the grid should fill whole rounds of CUs:
+    // the largest n_range with n_tile * n_range <= target (4 rounds of 256 CUs by default)
     const int want = env_int("VIREO_LDS_BLOCKS", 1024);
-    int n_range = std::max(1, std::min(t.n_slab, (want + t.n_tile - 1) / t.n_tile));
-    t.slabs_per_range = (t.n_slab + n_range - 1) / n_range;
-    t.n_range = (t.n_slab + t.slabs_per_range - 1) / t.slabs_per_range;
+    t.n_range = std::max(1, std::min(t.n_slab, want / std::max(1, t.n_tile)));
+    t.slabs_per_range = (t.n_slab + t.n_range - 1) / t.n_range;  // (upper bound; kernel splits evenly)
     const int64_t n_wave = (int64_t)t.n_tile * 16;
     const int64_t per_wave = (int64_t)t.n_slab * NR + 1;
     std::vector<uint32_t> ent;
@@ -369,9 +370,11 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
     rc = build_orient(p->by_var, n_var, n_cell, rptr.data(), ridx.data(), rval.data(), colptr,
                       tiles_v, pick_fmt(n_cell), p->stream);
     if (rc) return rc;
-    // LDS-resident passes (vrx_spmm_lds): EXPERIMENTAL, opt-in with VIREO_LDS=1.  Parity-tested,
-    // but on MI355X they do not yet beat the L2-tiled global-gather kernels.
-    if (max_count < 2048 && env_int("VIREO_LDS", 0) == 1) {
+    // LDS-resident passes (vrx_spmm_lds) pay off on large problems (two-dimensional tiling,
+    // one 160 KiB workgroup per CU); VIREO_LDS=0/1 forces them off/on.
+    const int lds = env_int("VIREO_LDS", -1);
+    if (max_count < 2048 &&
+        (lds == 1 || (lds != 0 && nnz >= (int64_t)env_int("VIREO_LDS_MIN_NNZ", 4000000)))) {
         // cell pass: slabs of 512 W rows (128 KiB at K = 16); variant pass: 1024 ID rows
         rc = build_tiled(p->by_cell, colptr, rowidx, cval.data(), 512, p->stream);
         if (rc) return rc;
@@ -1063,6 +1066,20 @@ extern "C" int vrx_model_step(vrx_model* m, int32_t which, double* elbo_out) {
     }
     VRX_HIP(hipStreamSynchronize(s));
     return prof_drain(m);
+}
+
+extern "C" int vrx_model_info(vrx_model* m, int32_t* info) {
+    VRX_REQUIRE(m && info, "vrx_model_info: null argument");
+    const Orient &v = m->p->by_var, &c = m->p->by_cell;
+    info[0] = lds_eligible<0>(v, m->K);
+    info[1] = lds_eligible<1>(c, m->K);
+    info[2] = v.fmt;
+    info[3] = c.fmt;
+    info[4] = v.n_tiles;
+    info[5] = c.n_tiles;
+    info[6] = v.tiled.ready ? v.tiled.n_range : 0;
+    info[7] = c.tiled.ready ? c.tiled.n_range : 0;
+    return VRX_OK;
 }
 
 extern "C" int vrx_model_profile(vrx_model* m, int32_t enable) {

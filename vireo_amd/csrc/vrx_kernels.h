@@ -283,7 +283,14 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_spmm(
 // Output: one partial array per contracted range (summed in fixed order afterwards).
 constexpr int VRX_RING = 512;   // entries per wave
 constexpr int VRX_CHUNK = 256;  // entries per refill (64 lanes x dwordx4)
-constexpr int VRX_LDS_RW = 48;  // output rows per wave (tile = 768 rows)
+#ifndef VRX_LDS_RW_DEF
+#define VRX_LDS_RW_DEF 48
+#endif
+#ifndef VRX_LDS_U_DEF
+#define VRX_LDS_U_DEF 4
+#endif
+constexpr int VRX_LDS_RW = VRX_LDS_RW_DEF;  // output rows per wave (tile = 16 x this)
+constexpr int VRX_LDS_U = VRX_LDS_U_DEF;    // entries per trip and group; rows are padded to it
 
 template <int LPE, int MODE>
 __global__ __launch_bounds__(1024) void vrx_spmm_lds(
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     constexpr int NQ = 2 * XD;             // 16-B reads per lane per entry (4 columns)
     constexpr int PF = 8;                  // 16-B prefetch registers per thread: 128 KiB / 1024
     constexpr int NV = MODE == 0 ? 2 : 1;  // accumulated values per column
-    constexpr int U = 2;                   // entries per trip and group
+    constexpr int U = VRX_LDS_U;           // entries per trip and group
     static_assert(RW % G == 0 && RW < 64, "rows per wave");
     extern __shared__ __attribute__((aligned(16))) char vrx_smem[];
     double* slab = reinterpret_cast<double*>(vrx_smem);
@@ -306,8 +313,9 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     const int slab_doubles = slab_rows * K * XD;
     uint32_t* ring = reinterpret_cast<uint32_t*>(slab + slab_doubles) + wave * VRX_RING;
     const int tile = blockIdx.x;
-    const int s_lo = blockIdx.y * slabs_per_range;
-    const int s_hi = min(s_lo + slabs_per_range, n_slab);
+    // contracted range of this workgroup: slabs split as evenly as possible over gridDim.y
+    const int s_lo = (int)((int64_t)blockIdx.y * n_slab / gridDim.y);
+    const int s_hi = (int)((int64_t)(blockIdx.y + 1) * n_slab / gridDim.y);
     if (s_lo >= s_hi) return;
     const int g = lane / LPE, kl = lane % LPE;
     const bool kok = kl * 4 < K;  // K is a multiple of 4

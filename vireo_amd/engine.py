@@ -121,6 +121,14 @@ class DeviceModel:
         _lib.check(_lib.lib().vrx_model_get_elbo_parts(self._h, dptr(p)))
         return p
 
+    def info(self):
+        """which kernels / formats / tilings this model's passes use (vrx_model_info)"""
+        a = np.zeros(8, dtype=np.int32)
+        _lib.check(_lib.lib().vrx_model_info(self._h, a.ctypes.data_as(C.POINTER(C.c_int32))))
+        return dict(lds_variant=bool(a[0]), lds_cell=bool(a[1]), fmt_variant=int(a[2]),
+                    fmt_cell=int(a[3]), tiles_variant=int(a[4]), tiles_cell=int(a[5]),
+                    ranges_variant=int(a[6]), ranges_cell=int(a[7]))
+
     # ---- timing -----------------------------------------------------------------------
     def profile(self, enable=True):
         _lib.check(_lib.lib().vrx_model_profile(self._h, int(enable)))
