@@ -1,0 +1,116 @@
+"""Full-size GPU checks at BASELINE.json's sizes (configs[2] and configs[4]).
+
+The oracle cannot run whole fits at these sizes in test time, so parity is established by
+(1) size-independent properties of the fitted state, (2) run-to-run bitwise determinism,
+(3) recovery of the planted structure of the synthetic data, and (4) ONE oracle iteration
+started from the GPU's fitted state, compared with one GPU iteration from the same state
+(rtol 1e-5, identical assignments) -- at a fitted state the posteriors are well separated,
+so the comparison is not dominated by near-ties as it is after a random start.
+"""
+import numpy as np
+import pytest
+
+from oracle import vireo_oracle as O
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def va():
+    import vireo_amd
+    from vireo_amd import _lib
+    _lib.require_gpu()
+    return vireo_amd
+
+
+def test_config3_fit_properties_and_one_step_parity(va):
+    from vireo_amd import synth
+    from vireo_amd.counts import DeviceCounts
+    N, M, K, dens = synth.CONFIGS["c3"]
+    w = synth.donor_workload(N, M, K, dens, seed=0)
+    counts = DeviceCounts.from_merged(w["shape"], w["colptr"], w["rowidx"], w["ad"], w["dp"])
+
+    def fit():
+        np.random.seed(1)
+        m = va.Vireo(n_var=N, n_cell=M, n_donor=K)
+        m.fit(counts, None, min_iter=5, max_iter=20, delay_fit_theta=3, verbose=False)
+        return m
+
+    m = fit()
+    # (1) properties
+    np.testing.assert_allclose(m.ID_prob.sum(1), 1.0, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(m.GT_prob.sum(2), 1.0, rtol=0, atol=1e-12)
+    assert np.all(np.isfinite(m.ELBO_)) and len(m.ELBO_) >= 6
+    gain = np.diff(m.ELBO_)
+    assert np.all(gain[3:] > -1e-6 * np.abs(m.ELBO_[4:])), "ELBO decreased after theta kicked in"
+    assert np.all((m.beta_mu > 0) & (m.beta_mu < 1)) and np.all(m.beta_sum > 0)
+    # (2) bitwise determinism of the whole fit
+    m2 = fit()
+    assert np.array_equal(m.ELBO_, m2.ELBO_) and np.array_equal(m.ID_prob, m2.ID_prob)
+    # (3) the planted donors are recovered: the generator's z (SURVEY.md 8d draw order)
+    rng = np.random.default_rng(0)
+    nnz_t = int(N * M * dens)
+    rng.integers(0, N, nnz_t); rng.integers(0, M, nnz_t); rng.poisson(1.0, nnz_t)
+    rng.integers(0, 3, (N, K))
+    z = rng.integers(0, K, M)
+    lab = m.ID_prob.argmax(1)
+    conf = np.zeros((K, K), int)
+    np.add.at(conf, (z, lab), 1)
+    purity = conf.max(1).sum() / M
+    print("c3 fit: %d ELBO entries, purity %.4f" % (len(m.ELBO_), purity))
+    assert purity > 0.99
+    # (4) one oracle iteration from the fitted state vs one GPU iteration from the same state
+    AD, DP = synth.as_scipy(w)
+    st = O.vireo_new(M, N, K, ID_prob_init=m.ID_prob, GT_prob_init=m.GT_prob,
+                     beta_mu_init=m.beta_mu.copy(), beta_sum_init=m.beta_sum.copy())
+    st.ID_prob, st.GT_prob = m.ID_prob.copy(), m.GT_prob.copy()
+    O.vireo_theta_step(st, AD, DP)
+    O.vireo_gt_step(st, AD, DP)
+    L = O.vireo_id_step(st, AD, DP)
+    elbo_ref = O.vireo_elbo(st, L)
+    m.update_theta_size(counts, None)
+    m.update_GT_prob(counts, None)
+    Lg = m.update_ID_prob(counts, None)
+    elbo_gpu = m.get_ELBO(Lg, counts, None)
+    np.testing.assert_allclose(m.beta_mu, st.beta_mu, rtol=RTOL)
+    np.testing.assert_allclose(m.beta_sum, st.beta_sum, rtol=RTOL)
+    np.testing.assert_allclose(m.GT_prob, st.GT_prob, rtol=RTOL, atol=1e-290)
+    np.testing.assert_allclose(m.ID_prob, st.ID_prob, rtol=RTOL, atol=1e-290)
+    np.testing.assert_allclose(Lg, L, rtol=1e-9)
+    np.testing.assert_allclose(elbo_gpu, elbo_ref, rtol=RTOL)
+    assert np.array_equal(m.ID_prob.argmax(1), st.ID_prob.argmax(1))
+
+
+def test_config5_clone_mode_vs_oracle(va):
+    """BinomMixtureVB at N=200 x M=200k, K=8 (BASELINE.json configs[4]): three iterations
+    from the same seeded start against the oracle."""
+    AD, DP = O.synth_clone(200, 200000, 8, seed=0)
+    np.random.seed(1)
+    ref = O.bmm_new(200000, 200, 8)
+    ID0 = ref.ID_prob.copy()
+    O.bmm_fit_vb(ref, AD, DP, max_iter=3, min_iter=1)
+    dev = va.BinomMixtureVB(n_var=200, n_cell=200000, n_donor=8, ID_prob_init=ID0)
+    dev._fit_BV(AD, DP, max_iter=3, min_iter=1, verbose=False)
+    assert len(dev.ELBO_iters) == len(ref.ELBO_iters) == 2
+    np.testing.assert_allclose(dev.ELBO_iters, ref.ELBO_iters, rtol=RTOL)
+    np.testing.assert_allclose(dev.beta_mu, ref.beta_mu, rtol=RTOL)
+    np.testing.assert_allclose(dev.beta_sum, ref.beta_sum, rtol=RTOL)
+    np.testing.assert_allclose(dev.ID_prob, ref.ID_prob, rtol=RTOL, atol=1e-290)
+    assert np.array_equal(dev.ID_prob.argmax(1), ref.ID_prob.argmax(1))
+    np.testing.assert_allclose(va.device_counts(AD, DP).binom_const(), O.binom_const(AD, DP),
+                               rtol=1e-6)
+
+
+def test_rccl_communicator_world1(va):
+    """the RCCL path of the restart shard (libvireo_hip's vrx_comm_*) on the one GPU of this
+    box: unique id, ncclCommInitRank, all-gather, broadcast, barrier."""
+    from vireo_amd.dist import RcclComm, gather_restart_elbos
+    comm = RcclComm(0, 1, 0, lambda raw: raw)
+    out = comm.allgather(np.array([1.5, -2.0, 3.25]))
+    assert np.array_equal(out, [1.5, -2.0, 3.25])
+    x = np.arange(12.0).reshape(3, 4)
+    assert np.array_equal(comm.bcast(x, 0), x)
+    comm.barrier()
+    assert np.array_equal(gather_restart_elbos(comm, 3, {0: 1.0, 1: 7.0, 2: 7.0}), [1, 7, 7])
+    comm.close()

@@ -113,6 +113,7 @@ class Vireo():
         if counts.shape != (self.n_var, self.n_cell):
             raise ValueError("AD/DP have shape %s but the model was built for (%d, %d)"
                              % (counts.shape, self.n_var, self.n_cell))
+        self._last_counts = counts
         dm = DeviceModel(counts, _lib.KIND_VIREO, self.n_donor, n_gt=self.n_GT,
                          learn_gt=self.learn_GT, learn_theta=self.learn_theta,
                          ase_mode=self.ASE_mode, fix_beta_sum=self.fix_beta_sum)
@@ -161,9 +162,11 @@ class Vireo():
     def get_ELBO(self, logLik_ID, AD=None, DP=None):
         """Evidence lower bound of the current parameters (vireo_model.py:222-248).
         logLik_ID None -> recomputed from AD, DP (:227-234)."""
-        if AD is None or DP is None:
-            raise ValueError("vireo_amd: get_ELBO needs AD and DP to locate the device "
-                             "problem (the reference ignores them when logLik_ID is given)")
+        if AD is None:          # like the reference: get_ELBO(logLik_ID) right after an update
+            AD = getattr(self, "_last_counts", None)
+            if AD is None:
+                raise ValueError("vireo_amd: get_ELBO needs AD and DP (no earlier fit/update "
+                                 "call on this object to take the device problem from)")
         dm, _ = self._device_model(AD, DP)
         if logLik_ID is None:
             dm.step(_lib.STEP_LOGLIK)
