@@ -165,6 +165,17 @@ def main():
         avg = max(avg_c, avg_v)
         ach = B[dom] / (avg * 1e-3) / 1e9
         info = _lib.device_info(local)
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this
+        # process; the figure comes from the committed rocprofv3 --pmc run of this same
+        # command (profiles/traffic_<config>.json) and is null when none matches.
+        traffic, traffic_src = None, None
+        kname = ("vrx_spmm_lds<4,%d>" % (dom == "cell")) if kinfo["lds_" + dom] else None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
+        if kname and os.path.exists(tpath):
+            rec = json.load(open(tpath)).get("kernels", {}).get(kname)
+            if rec:
+                traffic = rec["traffic_bytes"]
+                traffic_src = "profiles/traffic_%s.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)" % args.config
         out = {
             "metric": "EM iterations/sec", "value": world * args.steps / wall_max,
             "unit": "EM iterations/s", "n_gpus": world, "steps": args.steps,
@@ -184,7 +195,8 @@ def main():
                              else "vrx_spmm<..,%d,fmt%d>" % (dom == "cell", kinfo["fmt_" + dom]), dom),
                          "kernel_info": kinfo,
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": B[dom],
                          "avg_launch_ms": avg,
                          "per_iteration_ms": {"variant_pass": avg_v, "cell_pass": avg_c,
