@@ -136,6 +136,12 @@ int vrx_model_set_loglik(vrx_model* m, const double* logLik_ID);
  * LB_p, KL_ID, KL_GT, KL_theta (vireo_model.py:236-245) */
 int vrx_model_get_elbo_parts(vrx_model* m, double* parts4);
 
+/* Expected reads per variant and donor: AD @ ID_prob and DP @ ID_prob, (n_var x n_col) each
+ * -- one variant pass.  Replaces the two products the command line makes for the donor VCF
+ * (vireoSNP/vireo.py:240-241, "cell_dat['AD'] * res_vireo['ID_prob']"). */
+int vrx_problem_donor_reads(vrx_problem* p, int64_t n_col, const double* ID_prob,
+                            double* AD_reads, double* DP_reads);
+
 /* One-shot cell log-likelihood against caller-supplied genotype/theta tables:
  *   logLik[m,c] = sum_n sum_g GT[n,c,g] * (AD[n,m] psi1[g] + BD[n,m] psi2[g] - DP[n,m] psis[g])
  * with psi*(n_rows_psi x G): the 3*G transposed products of predict_doublet

@@ -1,0 +1,41 @@
+"""Run the REFERENCE ``vireo`` command (build container only, /root/reference) on its bundled
+demo data -- the five modes of examples/demo.sh with --randSeed 2 -- and keep the text
+outputs as fixtures under tests/golden/cli/.  The input files under tests/golden/data/ are
+copies of the reference's own demo data files (data, not source)."""
+import gzip
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DATA = os.path.join(HERE, "data")
+OUT = os.path.join(HERE, "cli")
+MODES = {
+    "mode1_noGT": ["-c", DATA + "/cellSNP_mat", "-N", "4"],
+    "mode2_PL": ["-c", DATA + "/cells.cellSNP.vcf.gz", "-d", DATA + "/donors.cellSNP.vcf.gz", "-N", "4"],
+    "mode3_part": ["-c", DATA + "/cells.cellSNP.vcf.gz", "-d", DATA + "/donors.two.cellSNP.vcf.gz", "-N", "4"],
+    "mode4_learn": ["-c", DATA + "/cells.cellSNP.vcf.gz", "-d", DATA + "/donors.cellSNP.vcf.gz", "-N", "4",
+                    "--forceLearnGT"],
+    "mode5_PL3": ["-c", DATA + "/cells.cellSNP.vcf.gz", "-d", DATA + "/donors.cellSNP.vcf.gz", "-N", "3"],
+    "mode1_M1_noDoublet": ["-c", DATA + "/cellSNP_mat", "-N", "4", "-M", "1", "--noDoublet"],
+}
+KEEP = ["donor_ids.tsv", "summary.tsv", "_log.txt"]
+
+for name, args in MODES.items():
+    tmp = "/tmp/vireo_cli_gold_" + name
+    shutil.rmtree(tmp, ignore_errors=True)
+    env = dict(os.environ, PYTHONPATH="/root/reference", MPLBACKEND="Agg")
+    subprocess.run([sys.executable, "-m", "vireoSNP.vireo"] + args +
+                   ["-o", tmp, "--randSeed", "2", "--noPlot"], env=env, check=True,
+                   stdout=subprocess.DEVNULL)
+    dst = os.path.join(OUT, name)
+    os.makedirs(dst, exist_ok=True)
+    for f in KEEP:
+        shutil.copy(os.path.join(tmp, f), os.path.join(dst, f))
+    vcf = os.path.join(tmp, "GT_donors.vireo.vcf.gz")
+    if os.path.exists(vcf):            # keep decompressed text re-gzipped deterministically
+        with gzip.open(vcf, "rt") as src, open(os.path.join(dst, "GT_donors.vireo.vcf"), "w") as d:
+            d.write(src.read())
+        subprocess.run(["gzip", "-nf", os.path.join(dst, "GT_donors.vireo.vcf")], check=True)
+    print(name, sorted(os.listdir(dst)))

@@ -1,0 +1,83 @@
+"""CPU tests of the command-line I/O layer (no GPU compute): the loaders reproduce the
+reference loaders' outputs (fixtures captured in the build container), the option surface
+is the reference's, and the writers' text layout matches a reference output file."""
+import contextlib
+import io
+import os
+
+import numpy as np
+
+from tests import gold
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DATA = os.path.join(HERE, "golden", "data")
+
+
+def _quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def test_cell_vcf_and_folder_load_the_same_matrices():
+    from vireo_amd import vireo as V
+    AD, DP = gold.c1()
+    for src in (DATA + "/cells.cellSNP.vcf.gz", DATA + "/cellSNP_mat"):
+        opts, _ = V.build_parser().parse_args(["-c", src])
+        d = _quiet(V.load_cells, opts)
+        assert (d["AD"].tocsc() != AD).nnz == 0 and (d["DP"].tocsc() != DP).nnz == 0
+        assert len(d["samples"]) == 952 and len(d["variants"]) == 3784
+        assert d["variants"][0] == "1_1065797_G_C"
+
+
+def test_donor_vcf_genotype_probabilities():
+    from vireo_amd import vcf_utils, io_utils, vireo as V
+    g = gold.load("cli_inputs")
+    opts, _ = V.build_parser().parse_args(["-c", DATA + "/cells.cellSNP.vcf.gz"])
+    cells = _quiet(V.load_cells, opts)
+    donors = vcf_utils.load_VCF(DATA + "/donors.cellSNP.vcf.gz", biallelic_only=True,
+                                sparse=False, format_list=["PL"])
+    assert donors["samples"] == ["MantonCB1", "MantonCB2", "MantonCB3", "MantonCB4"]
+    cells, donors = _quiet(io_utils.match_donor_VCF, cells, donors)
+    assert len(cells["variants"]) == int(g["n_matched"]) == cells["AD"].shape[0]
+    GPb = vcf_utils.parse_donor_GPb(donors["GenoINFO"]["PL"], "PL")
+    assert np.array_equal(GPb, g["donor_GPb"])            # bit-identical to the reference's
+    gt = vcf_utils.parse_donor_GPb([["0/1", "1|1", "./.", "0/0"]], "GT")
+    assert np.array_equal(gt[0], [[0, 1, 0], [0, 0, 1], [1 / 3] * 3, [1, 0, 0]])
+
+
+def test_option_surface_matches_reference():
+    from vireo_amd import vireo as V
+    p = V.build_parser()
+    flags = {o for opt in p._get_all_options() for o in opt._long_opts + opt._short_opts}
+    for f in ["--cellData", "-c", "--nDonor", "-N", "--outDir", "-o", "--vartrixData",
+              "--donorFile", "-d", "--genoTag", "-t", "--noDoublet", "--nInit", "-M",
+              "--extraDonor", "--extraDonorMode", "--forceLearnGT", "--ASEmode", "--noPlot",
+              "--randSeed", "--cellRange", "--callAmbientRNAs", "--nproc", "-p"]:
+        assert f in flags, f
+    o, _ = p.parse_args([])
+    assert (o.n_init, o.geno_tag, o.n_extra_donor, o.extra_donor_mode, o.nproc) == \
+        (50, "PL", 0, "distance", 1)
+
+
+def test_writers_layout(tmp_path):
+    """write_donor_id on a golden vireo_wrap result: header, thresholds and number formats
+    as in the reference's donor_ids.tsv / summary.tsv."""
+    from vireo_amd import io_utils
+    g = gold.load("c1_wrap_seed2_init4")
+    AD, DP = gold.c1()
+    n_vars = np.asarray((DP > 0).sum(axis=0)).ravel()
+    names = ["donor%d" % i for i in range(4)]
+    cells = ["cell%d" % i for i in range(AD.shape[1])]
+    res = dict(ID_prob=g["ID_prob"], doublet_prob=g["doublet_prob"], doublet_LLR=g["doublet_LLR"],
+               LB_doublet=float(g["LB_doublet"]), theta_shapes=g["theta_shapes"])
+    _quiet(io_utils.write_donor_id, str(tmp_path), names, cells, n_vars, res)
+    rows = [l.rstrip("\n").split("\t") for l in open(tmp_path / "donor_ids.tsv")]
+    assert rows[0] == ["cell", "donor_id", "prob_max", "prob_doublet", "n_vars", "best_singlet",
+                       "best_doublet", "doublet_logLikRatio"]
+    assert len(rows) == 953 and rows[1][2] == "%.2e" % g["ID_prob"][0].max()
+    labels = {r[1] for r in rows[1:]}
+    assert labels <= set(names) | {"doublet", "unassigned"}
+    summ = open(tmp_path / "summary.tsv").read().split("\n")
+    assert summ[0] == "Var1\tFreq" and sum(int(l.split("\t")[1]) for l in summ[1:] if l) == 952
+    assert open(tmp_path / "_log.txt").read().startswith("logLik: %.3e\n" % g["LB_doublet"])
+    assert os.path.exists(tmp_path / "prob_singlet.tsv.gz")

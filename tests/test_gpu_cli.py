@@ -1,0 +1,83 @@
+"""The ``vireo`` command end to end on the GPU against the text outputs of the reference
+command (tests/golden/cli/, produced by tests/golden/make_cli_golden.py): the five modes of
+the reference's examples/demo.sh plus a single-init / no-doublet run, --randSeed 2."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DATA = os.path.join(HERE, "golden", "data")
+GOLD = os.path.join(HERE, "golden", "cli")
+
+MODES = {
+    "mode1_noGT": ["-c", DATA + "/cellSNP_mat", "-N", "4"],
+    "mode2_PL": ["-c", DATA + "/cells.cellSNP.vcf.gz", "-d", DATA + "/donors.cellSNP.vcf.gz",
+                 "-N", "4"],
+    "mode3_part": ["-c", DATA + "/cells.cellSNP.vcf.gz", "-d",
+                   DATA + "/donors.two.cellSNP.vcf.gz", "-N", "4"],
+    "mode4_learn": ["-c", DATA + "/cells.cellSNP.vcf.gz", "-d", DATA + "/donors.cellSNP.vcf.gz",
+                    "-N", "4", "--forceLearnGT"],
+    "mode5_PL3": ["-c", DATA + "/cells.cellSNP.vcf.gz", "-d", DATA + "/donors.cellSNP.vcf.gz",
+                  "-N", "3"],
+    "mode1_M1_noDoublet": ["-c", DATA + "/cellSNP_mat", "-N", "4", "-M", "1", "--noDoublet"],
+}
+
+
+def _table(path):
+    with open(path) as f:
+        return [line.rstrip("\n").split("\t") for line in f]
+
+
+def _num_close(a, b, rtol):
+    try:
+        x, y = float(a), float(b)
+    except ValueError:
+        return a == b
+    return abs(x - y) <= rtol * max(abs(x), abs(y)) + 1e-12
+
+
+@pytest.mark.parametrize("mode", sorted(MODES))
+def test_cli_matches_reference_outputs(mode, tmp_path, capsys):
+    from vireo_amd import _lib
+    from vireo_amd.vireo import main
+    _lib.require_gpu()
+    out = str(tmp_path / mode)
+    main(MODES[mode] + ["-o", out, "--randSeed", "2", "--noPlot"])
+    capsys.readouterr()
+    ref = os.path.join(GOLD, mode)
+
+    # summary.tsv: identical text (the donor / doublet / unassigned counts)
+    assert open(out + "/summary.tsv").read() == open(ref + "/summary.tsv").read()
+
+    # donor_ids.tsv: identical labels; printed probabilities (3 significant digits) may
+    # differ in the last printed digit when a value sits on a rounding boundary
+    got, want = _table(out + "/donor_ids.tsv"), _table(ref + "/donor_ids.tsv")
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert [g[i] for i in (0, 1, 4, 5, 6)] == [w[i] for i in (0, 1, 4, 5, 6)]
+        assert _num_close(g[2], w[2], 2e-2) and _num_close(g[3], w[3], 2e-2)
+        assert abs(float(g[7]) - float(w[7])) <= 2e-3 if g[7] != "doublet_logLikRatio" else True
+
+    # _log.txt: logLik line identical, theta shapes to 1e-6 relative
+    glog, wlog = open(out + "/_log.txt").read().split("\n"), open(ref + "/_log.txt").read().split("\n")
+    assert glog[0] == wlog[0]
+    gth = np.array(" ".join(glog[2:]).replace("[", " ").replace("]", " ").split(), float)
+    wth = np.array(" ".join(wlog[2:]).replace("[", " ").replace("]", " ").split(), float)
+    np.testing.assert_allclose(gth, wth, rtol=1e-6)
+
+    # estimated donor genotypes: identical VCF text where the reference writes one
+    ref_vcf = ref + "/GT_donors.vireo.vcf.gz"
+    assert os.path.exists(out + "/GT_donors.vireo.vcf.gz") == os.path.exists(ref_vcf)
+    if os.path.exists(ref_vcf):
+        g = gzip.open(out + "/GT_donors.vireo.vcf.gz", "rt").read().split("\n")
+        w = gzip.open(ref_vcf, "rt").read().split("\n")
+        assert len(g) == len(w)
+        diff = [i for i, (a, b) in enumerate(zip(g, w)) if a != b]
+        # PL / AD / DP are integers rounded from floats: allow a handful of off-by-one cells
+        assert len(diff) <= max(3, len(w) // 1000), diff[:5]
+    for name in ("prob_singlet.tsv.gz", "prob_doublet.tsv.gz"):
+        assert os.path.exists(out + "/" + name)

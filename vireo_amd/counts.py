@@ -113,6 +113,18 @@ class DeviceCounts:
         _lib.check(_lib.lib().vrx_problem_n_vars(self._h, out.ctypes.data_as(C.POINTER(C.c_int32))))
         return out
 
+    def donor_reads(self, ID_prob):
+        """(AD @ ID_prob, DP @ ID_prob), each (n_var, n_donor): the expected reads per donor
+        the command line writes to GT_donors.vireo.vcf.gz (vireo.py:240-241)."""
+        ID = _lib.f64(ID_prob)
+        if ID.ndim != 2 or ID.shape[0] != self.n_cell:
+            raise ValueError("ID_prob has shape %s" % (ID.shape,))
+        A = np.empty((self.n_var, ID.shape[1]))
+        D = np.empty((self.n_var, ID.shape[1]))
+        _lib.check(_lib.lib().vrx_problem_donor_reads(self._h, ID.shape[1], _lib.dptr(ID),
+                                                      _lib.dptr(A), _lib.dptr(D)))
+        return A, D
+
     def close(self):
         self._fin()
 

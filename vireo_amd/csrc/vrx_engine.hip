@@ -458,6 +458,8 @@ struct vrx_model {
     DevBuf<double> d_elbo, d_parts;
     double* h_pin = nullptr;  // pinned staging for scalar read-backs
     bool w_valid = false;     // W matches (GT, psi) on the device
+    bool s_pending = false;   // S still sits in RV as per-range partials (sum fused downstream)
+    bool l_pending = false;   // logLik_ID still sits in RC as per-range partials
     // profiling
     bool prof = false;
     std::vector<hipEvent_t> ev;
@@ -763,7 +765,7 @@ static int launch_lds_one(const Orient& o, hipStream_t s, const double* X, int K
 
 template <int MODE>
 static int launch_spmm_lds(vrx_model* m, const Orient& o, const double* X, int K, double* out,
-                           double* range_partial) {
+                           double* range_partial, bool defer_sum) {
     hipStream_t s = m->p->stream;
     const TiledStream& t = o.tiled;
     constexpr int NV = MODE == 0 ? 2 : 1;
@@ -771,7 +773,7 @@ static int launch_spmm_lds(vrx_model* m, const Orient& o, const double* X, int K
     int rc;
     rc = launch_lds_one<4, MODE>(o, s, X, K, dst);  // 4-lane groups; K < 16 leaves lanes idle
     if (rc) return rc;
-    if (t.n_range > 1) {
+    if (t.n_range > 1 && !defer_sum) {
         const int64_t n = o.n_rows * K * NV;
         vrx_sum_ranges<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
             n, t.n_range, range_partial, out);
@@ -820,19 +822,44 @@ static int launch_spmm(vrx_model* m, const Orient& o, const double* X, int K, do
 }
 
 // S <- (AD @ ID_prob, DP @ ID_prob)        vireo_model.py:169-170,207-208; bmm_model.py:137-138
-static int variant_pass(vrx_model* m) {
+static int variant_pass(vrx_model* m, bool defer_sum = false) {
     ProfScope ps(m, VRX_KERN_VARIANT_PASS);
-    if (lds_eligible<0>(m->p->by_var, m->K))
-        return launch_spmm_lds<0>(m, m->p->by_var, m->ID.p, m->K, m->S.p, m->RV.p);
+    if (lds_eligible<0>(m->p->by_var, m->K)) {
+        m->s_pending = defer_sum && m->p->by_var.tiled.n_range > 1;
+        return launch_spmm_lds<0>(m, m->p->by_var, m->ID.p, m->K, m->S.p, m->RV.p, defer_sum);
+    }
     return launch_spmm<0>(m, m->p->by_var, m->ID.p, m->K, m->S.p, m->PV.p);
 }
 
 // LID <- AD^T W1 + DP^T W2                 vireo_model.py:190-196; bmm_model.py:125-129
-static int cell_pass(vrx_model* m) {
+static int cell_pass(vrx_model* m, bool defer_sum = false) {
     ProfScope ps(m, VRX_KERN_CELL_PASS);
-    if (lds_eligible<1>(m->p->by_cell, m->K))
-        return launch_spmm_lds<1>(m, m->p->by_cell, m->W.p, m->K, m->LID.p, m->RC.p);
+    if (lds_eligible<1>(m->p->by_cell, m->K)) {
+        m->l_pending = defer_sum && m->p->by_cell.tiled.n_range > 1;
+        return launch_spmm_lds<1>(m, m->p->by_cell, m->W.p, m->K, m->LID.p, m->RC.p, defer_sum);
+    }
     return launch_spmm<1>(m, m->p->by_cell, m->W.p, m->K, m->LID.p, m->PC.p);
+}
+
+// a consumer that cannot fuse the range sum forms S / logLik_ID explicitly
+static int resolve_S(vrx_model* m) {
+    if (!m->s_pending) return VRX_OK;
+    const int64_t n = m->NK * 2;
+    vrx_sum_ranges<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, m->p->stream>>>(
+        n, m->p->by_var.tiled.n_range, m->RV.p, m->S.p);
+    VRX_HIP(hipGetLastError());
+    m->s_pending = false;
+    return VRX_OK;
+}
+
+static int resolve_LID(vrx_model* m) {
+    if (!m->l_pending) return VRX_OK;
+    const int64_t n = m->M * m->K;
+    vrx_sum_ranges<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, m->p->stream>>>(
+        n, m->p->by_cell.tiled.n_range, m->RC.p, m->LID.p);
+    VRX_HIP(hipGetLastError());
+    m->l_pending = false;
+    return VRX_OK;
 }
 
 // theta update (update=1) or just psi/KL from the current beta (update=0)
@@ -840,6 +867,10 @@ static int theta_step(vrx_model* m, int update) {
     ProfScope ps(m, VRX_KERN_DENSE);
     hipStream_t s = m->p->stream;
     const auto& c = m->cfg;
+    if (c.kind == VRX_KIND_BMM || c.ase_mode) {
+        int rc = resolve_S(m);  // only the shared-theta kernel fuses the range sum
+        if (rc) return rc;
+    }
     if (c.kind == VRX_KIND_BMM) {
         vrx_bmm_theta<<<m->nb_nk, VRX_BLOCK, 0, s>>>(
             m->NK, update, c.fix_beta_sum, reinterpret_cast<const double2*>(m->S.p), m->prior1.p,
@@ -854,9 +885,12 @@ static int theta_step(vrx_model* m, int update) {
         m->w_valid = false;
     } else {
         if (update) {
+            const int nr = m->s_pending ? m->p->by_var.tiled.n_range : 0;
             vrx_theta_partial<<<m->nb_theta, VRX_BLOCK, 0, s>>>(
-                m->NK, m->T, reinterpret_cast<const double2*>(m->S.p), m->GT.p, m->part_theta.p);
+                m->NK, m->T, reinterpret_cast<double2*>(m->S.p), nr,
+                reinterpret_cast<const double2*>(m->RV.p), m->GT.p, m->part_theta.p);
             VRX_HIP(hipGetLastError());
+            m->s_pending = false;
         }
         vrx_theta_final<<<1, VRX_BLOCK, 0, s>>>(m->nb_theta, m->T, update, c.fix_beta_sum,
                                                  m->part_theta.p, m->prior1.p, m->prior2.p, m->mu.p,
@@ -870,6 +904,10 @@ static int theta_step(vrx_model* m, int update) {
 // GT softmax (learn=1) or W/KL from the fixed GT (learn=0); always refreshes W
 static int gt_step(vrx_model* m, int learn) {
     ProfScope ps(m, VRX_KERN_DENSE);
+    if (learn) {
+        int rc = resolve_S(m);
+        if (rc) return rc;
+    }
     vrx_gt_update<<<m->nb_nk, VRX_BLOCK, 0, m->p->stream>>>(
         m->NK, m->K, m->T, learn, m->cfg.ase_mode, m->N, reinterpret_cast<const double2*>(m->S.p),
         m->psi.p, m->logq_gt.p, m->gt_mode, -std::log((double)m->T), m->GT.p,
@@ -883,11 +921,14 @@ static int softmax_step(vrx_model* m, int update) {
     ProfScope ps(m, VRX_KERN_DENSE);
     hipStream_t s = m->p->stream;
     const double lu = -std::log((double)m->K);
+    const int nr = m->l_pending ? m->p->by_cell.tiled.n_range : 0;  // fused sum of the partials
+    m->l_pending = false;
 #define VRX_SM_CASE(KPV)                                                                        \
     case KPV:                                                                                   \
-        vrx_cell_softmax<KPV><<<m->nb_cell, VRX_BLOCK, 0, s>>>(m->M, m->K, update, m->LID.p,    \
-                                                               m->logq_id.p, m->id_mode, lu,    \
-                                                               m->ID.p, m->part_cell.p);        \
+        vrx_cell_softmax<KPV><<<m->nb_cell, VRX_BLOCK, 0, s>>>(m->M, m->K, update, m->LID.p, nr,\
+                                                               m->RC.p, m->logq_id.p,           \
+                                                               m->id_mode, lu, m->ID.p,         \
+                                                               m->part_cell.p);                 \
         break;
     switch (m->KP) {
         VRX_SM_CASE(1)
@@ -919,12 +960,12 @@ static int enqueue_iteration(vrx_model* m, bool do_theta, int slot) {
     int rc;
     const auto& c = m->cfg;
     if (c.kind == VRX_KIND_BMM) {
-        if ((rc = variant_pass(m))) return rc;
+        if ((rc = variant_pass(m, true))) return rc;
         if ((rc = theta_step(m, 1))) return rc;  // also refreshes W (digamma tables)
     } else {
         bool have_s = false;
         if (do_theta) {
-            if ((rc = variant_pass(m))) return rc;
+            if ((rc = variant_pass(m, true))) return rc;  // range sum fused into the theta kernel
             have_s = true;
             if ((rc = theta_step(m, 1))) return rc;
         }
@@ -932,13 +973,13 @@ static int enqueue_iteration(vrx_model* m, bool do_theta, int slot) {
             // the reference recomputes AD@ID_prob, DP@ID_prob here (vireo_model.py:207-208);
             // ID_prob has not changed since update_theta_size, so S is reused.
             if (!have_s)
-                if ((rc = variant_pass(m))) return rc;
+                if ((rc = variant_pass(m, true))) return rc;
             if ((rc = gt_step(m, 1))) return rc;
         } else if (!m->w_valid) {
             if ((rc = gt_step(m, 0))) return rc;
         }
     }
-    if ((rc = cell_pass(m))) return rc;
+    if ((rc = cell_pass(m, true))) return rc;  // range sum fused into the softmax kernel
     if ((rc = softmax_step(m, 1))) return rc;
     return elbo_step(m, slot);
 }
@@ -1114,6 +1155,29 @@ extern "C" int vrx_model_profile_read(vrx_model* m, double* ms_total, int64_t* l
 // ------------------------------------------------------------------------------------
 // one-shot cell log-likelihood against caller-supplied tables (doublet step)
 // ------------------------------------------------------------------------------------
+extern "C" int vrx_problem_donor_reads(vrx_problem* p, int64_t n_col, const double* ID_prob,
+                                       double* AD_reads, double* DP_reads) {
+    VRX_REQUIRE(p && ID_prob && AD_reads && DP_reads, "vrx_problem_donor_reads: null argument");
+    VRX_REQUIRE(n_col >= 1, "vrx_problem_donor_reads: bad shape");
+    vrx_model_cfg cfg{};
+    cfg.kind = VRX_KIND_BMM;  // no genotype layer needed: only ID_prob and S
+    cfg.n_donor = (int32_t)n_col;
+    vrx_model* m = nullptr;
+    int rc = vrx_model_create(p, &cfg, &m);
+    if (rc) return rc;
+    std::unique_ptr<vrx_model> guard(m);
+    if ((rc = h2d(m, m->ID, ID_prob, (size_t)(m->M * m->K)))) return rc;
+    if ((rc = variant_pass(m))) return rc;
+    std::vector<double> S((size_t)m->NK * 2);
+    if ((rc = d2h(m, S.data(), m->S, S.size()))) return rc;
+    VRX_HIP(hipStreamSynchronize(p->stream));
+    for (int64_t i = 0; i < m->NK; ++i) {
+        AD_reads[i] = S[(size_t)i * 2];
+        DP_reads[i] = S[(size_t)i * 2 + 1];
+    }
+    return VRX_OK;
+}
+
 extern "C" int vrx_problem_cell_loglik(vrx_problem* p, int64_t n_col, int64_t n_class,
                                        const double* GT, const double* psi1, const double* psi2,
                                        const double* psis, int64_t psi_rows,

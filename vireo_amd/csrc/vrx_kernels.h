@@ -474,8 +474,11 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_slots(int64_t n_multi, int 
 // theta  (Vireo.update_theta_size, vireoSNP/utils/vireo_model.py:165-185)
 // ------------------------------------------------------------------------------------
 // stage 1 (shared theta): per-block partial sums of S1*GT_t and S2*GT_t over all (n,k).
-__global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_partial(int64_t NK, int T,
-                                                               const double2* __restrict__ S,
+// n_range > 0: S has not been formed yet -- it is the in-order sum of the n_range partial
+// arrays the LDS-resident variant pass left in `ranges` (fused here to save a launch).
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_partial(int64_t NK, int T, double2* S,
+                                                               int n_range,
+                                                               const double2* __restrict__ ranges,
                                                                const double* __restrict__ GT,
                                                                double* __restrict__ part) {
     double acc[2 * VRX_MAXT];
@@ -483,7 +486,18 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_partial(int64_t NK, int T
     for (int t = 0; t < 2 * VRX_MAXT; ++t) acc[t] = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x; i < NK;
          i += (int64_t)gridDim.x * VRX_BLOCK) {
-        const double2 s = S[i];
+        double2 s;
+        if (n_range > 0) {
+            s = make_double2(0.0, 0.0);
+            for (int r = 0; r < n_range; ++r) {
+                const double2 v = ranges[(int64_t)r * NK + i];
+                s.x += v.x;
+                s.y += v.y;
+            }
+            S[i] = s;
+        } else {
+            s = S[i];
+        }
         const double s1 = s.x, s2 = s.y - s.x;
 #pragma unroll
         for (int t = 0; t < VRX_MAXT; ++t)
@@ -695,16 +709,26 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_bmm_theta(int64_t NK, int updat
 // A KP-lane group per cell; K > KP loops.  update == 0: ID_prob is left alone and only the
 // ELBO partials are formed from the stored ID_prob (get_ELBO on user-supplied state).
 // id_mode: 0 uniform prior, 1 one row of K, 2 full (M,K).
+// n_range > 0: logLik_ID has not been formed yet -- it is the in-order sum of the n_range
+// partial arrays the LDS-resident cell pass left in `ranges` (fused here to save a launch;
+// every lane sums, stores and later re-reads only its own columns).
 // ------------------------------------------------------------------------------------
 template <int KP>
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_cell_softmax(
-    int64_t M, int K, int update, const double* __restrict__ LID, const double* __restrict__ logq,
-    int id_mode, double logq_uni, double* __restrict__ ID, double* __restrict__ part) {
+    int64_t M, int K, int update, double* LID, int n_range, const double* __restrict__ ranges,
+    const double* __restrict__ logq, int id_mode, double logq_uni, double* __restrict__ ID,
+    double* __restrict__ part) {
     const int64_t cell = ((int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x) / KP;
     const int kl = threadIdx.x % KP;
     double acc[2] = {0.0, 0.0};
     const bool live = cell < M;
-    const double* Lr = LID + (live ? cell : 0) * (int64_t)K;
+    double* Lr = LID + (live ? cell : 0) * (int64_t)K;
+    if (live && n_range > 0)
+        for (int k = kl; k < K; k += KP) {
+            double t = 0.0;
+            for (int r = 0; r < n_range; ++r) t += ranges[((int64_t)r * M + cell) * K + k];
+            Lr[k] = t;
+        }
     const double* qr = id_mode == 2 ? logq + (live ? cell : 0) * (int64_t)K : logq;
     double mx = -__builtin_inf();
     if (live)
