@@ -149,6 +149,11 @@ def main():
               learn_GT=True, n_extra_donor=0, check_doublet=True)
     wrap_case("c1_wrap_seed2_nodoublet", n_donor=3, n_init=2, random_seed=2,
               check_doublet=False)
+    # extra-donor search (donor_select, vireo_wrap.py:95-105) and ASE mode through the wrap
+    wrap_case("c1_wrap_extra1_dist", n_donor=4, n_init=3, random_seed=2, n_extra_donor=1)
+    wrap_case("c1_wrap_extra2_size", n_donor=3, n_init=2, random_seed=5, n_extra_donor=2,
+              extra_donor_mode="size")
+    wrap_case("c1_wrap_ase", n_donor=4, n_init=2, random_seed=2, ASE_mode=True)
 
     # ---- BinomMixtureVB on mitoDNA (notebook known answer) ------------------
     b = BinomMixtureVB(n_var=mAD.shape[0], n_cell=mAD.shape[1], n_donor=3)

@@ -126,6 +126,10 @@ def test_gt_prior(va, tag, learn):
     ("c1_wrap_seed2_init4", dict(n_donor=4, n_init=4, random_seed=2)),
     ("c1_wrap_seed2_nodoublet", dict(n_donor=3, n_init=2, random_seed=2, check_doublet=False)),
     ("c1_wrap_seed1_init50", dict(n_donor=4, n_init=50, random_seed=1)),
+    ("c1_wrap_extra1_dist", dict(n_donor=4, n_init=3, random_seed=2, n_extra_donor=1)),
+    ("c1_wrap_extra2_size", dict(n_donor=3, n_init=2, random_seed=5, n_extra_donor=2,
+                                 extra_donor_mode="size")),
+    ("c1_wrap_ase", dict(n_donor=4, n_init=2, random_seed=2, ASE_mode=True)),
 ])
 def test_wrap(va, name, kw, capsys):
     g = gold.load(name)
