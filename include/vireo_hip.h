@@ -136,6 +136,19 @@ int vrx_model_set_loglik(vrx_model* m, const double* logLik_ID);
  * LB_p, KL_ID, KL_GT, KL_theta (vireo_model.py:236-245) */
 int vrx_model_get_elbo_parts(vrx_model* m, double* parts4);
 
+/* Doublet scoring with a fitted model, the device form of predict_doublet
+ * (vireoSNP/utils/vireo_doublet.py:11-82): the genotype table of all donor pairs
+ * (add_doublet_GT, :105-136) is formed on the fly inside the kernel that builds the cell
+ * pass's W tables; logLik / prob_out are (n_cell x C), C = K + K(K-1)/2 (singlets first,
+ * pairs in itertools.combinations order).  psi*: digammas of the T + T(T-1)/2 class thetas
+ * of add_doublet_theta (:85-102), (psi_rows x G).  n_gt <= 3. */
+int vrx_problem_doublet(vrx_problem* p, int64_t n_donor, int64_t n_gt,
+                        const double* GT_prob /* n_var x n_donor x n_gt */,
+                        const double* psi1, const double* psi2, const double* psis,
+                        int64_t psi_rows /* 1 or n_var */,
+                        const double* ID_prior, int64_t id_rows,
+                        double* logLik, double* prob_out /* may be NULL */);
+
 /* Expected reads per variant and donor: AD @ ID_prob and DP @ ID_prob, (n_var x n_col) each
  * -- one variant pass.  Replaces the two products the command line makes for the donor VCF
  * (vireoSNP/vireo.py:240-241, "cell_dat['AD'] * res_vireo['ID_prob']"). */

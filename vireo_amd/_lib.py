@@ -55,6 +55,8 @@ SIGNATURES = {
     "vrx_model_set_loglik": (C.c_int, [_P, _D]),
     "vrx_model_get_elbo_parts": (C.c_int, [_P, _D]),
     "vrx_problem_donor_reads": (C.c_int, [_P, C.c_int64, _D, _D, _D]),
+    "vrx_problem_doublet": (C.c_int, [_P, C.c_int64, C.c_int64, _D, _D, _D, _D, C.c_int64, _D,
+                                      C.c_int64, _D, _D]),
     "vrx_problem_cell_loglik": (C.c_int, [_P, C.c_int64, C.c_int64, _D, _D, _D, _D, C.c_int64, _D,
                                           C.c_int64, _D, _D]),
     "vrx_model_info": (C.c_int, [_P, _I32]),

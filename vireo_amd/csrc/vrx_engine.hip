@@ -1155,6 +1155,59 @@ extern "C" int vrx_model_profile_read(vrx_model* m, double* ms_total, int64_t* l
 // ------------------------------------------------------------------------------------
 // one-shot cell log-likelihood against caller-supplied tables (doublet step)
 // ------------------------------------------------------------------------------------
+extern "C" int vrx_problem_doublet(vrx_problem* p, int64_t n_donor, int64_t n_gt,
+                                   const double* GT_prob, const double* psi1, const double* psi2,
+                                   const double* psis, int64_t psi_rows, const double* ID_prior,
+                                   int64_t id_rows, double* logLik, double* prob_out) {
+    VRX_REQUIRE(p && GT_prob && psi1 && psi2 && psis && logLik, "vrx_problem_doublet: null argument");
+    VRX_REQUIRE(n_donor >= 2 && n_gt >= 1 && n_gt <= 3,
+                "vrx_problem_doublet: needs n_donor >= 2 and n_GT <= 3");
+    VRX_REQUIRE(psi_rows == 1 || psi_rows == p->n_var, "vrx_problem_doublet: psi rows must be 1 or n_var");
+    const int64_t C = n_donor + n_donor * (n_donor - 1) / 2;
+    const int G = (int)(n_gt + n_gt * (n_gt - 1) / 2);
+    VRX_REQUIRE(id_rows == 0 || id_rows == 1 || id_rows == p->n_cell,
+                "vrx_problem_doublet: ID_prior must have 0, 1 or n_cell rows");
+    VRX_REQUIRE(id_rows == 0 || ID_prior, "vrx_problem_doublet: null ID_prior");
+    vrx_model_cfg cfg{};
+    cfg.kind = VRX_KIND_VIREO;
+    cfg.n_donor = (int32_t)C;
+    cfg.n_gt = 1;  // the pair classes live in registers; no N x C x G tensor
+    vrx_model* m = nullptr;
+    int rc = vrx_model_create(p, &cfg, &m);
+    if (rc) return rc;
+    std::unique_ptr<vrx_model> guard(m);
+    hipStream_t s = p->stream;
+    DevBuf<double> gt, psi;
+    DevBuf<int2> pairs;
+    std::vector<int2> hp;
+    for (int a = 0; a < n_donor; ++a)
+        for (int b = a + 1; b < n_donor; ++b) hp.push_back(make_int2(a, b));  // combinations order
+    const size_t n_gt_el = (size_t)(p->n_var * n_donor * n_gt), th = (size_t)(psi_rows * G);
+    VRX_HIP(gt.upload(GT_prob, n_gt_el, s));
+    VRX_HIP(pairs.upload(hp.data(), hp.size(), s));
+    VRX_HIP(psi.alloc(3 * th));
+    VRX_HIP(hipMemcpyAsync(psi.p, psi1, th * sizeof(double), hipMemcpyHostToDevice, s));
+    VRX_HIP(hipMemcpyAsync(psi.p + th, psi2, th * sizeof(double), hipMemcpyHostToDevice, s));
+    VRX_HIP(hipMemcpyAsync(psi.p + 2 * th, psis, th * sizeof(double), hipMemcpyHostToDevice, s));
+    const int64_t n = p->n_var * C;
+    vrx_doublet_w<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
+        p->n_var, (int)n_donor, (int)n_gt, (int)C, psi_rows == 1 ? 0 : 1, gt.p, pairs.p, psi.p,
+        psi.p + th, psi.p + 2 * th, reinterpret_cast<double2*>(m->W.p));
+    VRX_HIP(hipGetLastError());
+    if ((rc = cell_pass(m))) return rc;
+    if ((rc = d2h(m, logLik, m->LID, (size_t)(m->M * m->K)))) return rc;
+    if (prob_out) {
+        if (id_rows > 0) {
+            if ((rc = upload_log_rows(m, m->logq_id, ID_prior, id_rows, m->K))) return rc;
+            m->id_mode = id_rows == 1 ? 1 : 2;
+        }
+        if ((rc = softmax_step(m, 1))) return rc;
+        if ((rc = d2h(m, prob_out, m->ID, (size_t)(m->M * m->K)))) return rc;
+    }
+    VRX_HIP(hipStreamSynchronize(s));
+    return VRX_OK;
+}
+
 extern "C" int vrx_problem_donor_reads(vrx_problem* p, int64_t n_col, const double* ID_prob,
                                        double* AD_reads, double* DP_reads) {
     VRX_REQUIRE(p && ID_prob && AD_reads && DP_reads, "vrx_problem_donor_reads: null argument");

@@ -669,6 +669,62 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_gt_update(
 }
 
 // ------------------------------------------------------------------------------------
+// doublet tables  (add_doublet_GT, vireoSNP/utils/vireo_doublet.py:105-136, folded into the
+// W1/W2 tables of the cell pass).  Column c < K is donor c (the T genotype classes, zero
+// mixed classes); column K + j is the j-th donor pair (a < b) over T + T(T-1)/2 classes:
+//   both[t]       = p_t q_t                                   (same genotype)
+//   both[T + m]   = p_{g1} q_{g2} + p_{g2} q_{g1}             (m-th genotype pair g1 < g2)
+// normalised over the classes.  The N x C x (T + T(T-1)/2) tensor the reference
+// materialises (653 MB at N=100k, K=16) never exists: each thread forms its classes in
+// registers and writes W[n][c] = (sum_g both_g (psi1_g - psi2_g), sum_g both_g (psi2_g - psis_g)).
+// psi*: [rows][G] with G = T + T(T-1)/2 classes (rows = N in ASE mode, else 1).  T <= 3.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_doublet_w(
+    int64_t N, int K, int T, int C, int ase, const double* __restrict__ GT,
+    const int2* __restrict__ pair, const double* __restrict__ psi1,
+    const double* __restrict__ psi2, const double* __restrict__ psis, double2* __restrict__ W) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    if (i >= N * C) return;
+    const int64_t n = i / C;
+    const int c = (int)(i - n * C);
+    const int G = T + T * (T - 1) / 2;
+    const int64_t pr = ase ? n : 0;
+    const double* p1 = psi1 + pr * G;
+    const double* p2 = psi2 + pr * G;
+    const double* ps = psis + pr * G;
+    double both[6];
+#pragma unroll
+    for (int g = 0; g < 6; ++g) both[g] = 0.0;
+    if (c < K) {
+        for (int t = 0; t < T; ++t) both[t] = GT[(n * K + c) * T + t];
+    } else {
+        const int2 ab = pair[c - K];
+        const double* p = GT + (n * K + ab.x) * T;
+        const double* q = GT + (n * K + ab.y) * T;
+        double sum = 0.0;
+        for (int t = 0; t < T; ++t) {
+            both[t] = p[t] * q[t];
+            sum += both[t];
+        }
+        int m = T;
+        for (int g1 = 0; g1 < T; ++g1)
+            for (int g2 = g1 + 1; g2 < T; ++g2) {
+                both[m] = p[g1] * q[g2] + p[g2] * q[g1];
+                sum += both[m];
+                ++m;
+            }
+        for (int g = 0; g < G; ++g) both[g] = both[g] / sum;
+    }
+    double w1 = 0.0, w2 = 0.0;
+    for (int g = 0; g < G; ++g) {
+        w1 += both[g] * (p1[g] - p2[g]);
+        w2 += both[g] * (p2[g] - ps[g]);
+    }
+    W[i] = make_double2(w1, w2);
+}
+
+// ------------------------------------------------------------------------------------
 // BinomMixtureVB theta  (bmm_model.py:133-144) fused with the digamma tables of
 // get_E_logLik (:118-130) and the KL_theta partial of get_ELBO (:166-172).
 // Thread per (variant, clone).  update == 0: derive W / KL from the current beta only.

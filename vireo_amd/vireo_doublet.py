@@ -2,8 +2,10 @@
 vireoSNP/utils/vireo_doublet.py:11-136 (``predict_doublet`` and its two table builders).
 
 The K + K(K-1)/2 column cell log-likelihood -- 3*6 transposed sparse products in the
-reference (:53-62) -- is one cell pass on the GPU (``vrx_problem_cell_loglik``); the
-genotype/theta tables of the donor pairs are small host-side combinatorics.
+reference (:53-62) -- is one cell pass on the GPU (``vrx_problem_doublet``); the genotype
+table of the donor pairs (653 MB at N=100k, K=16 in the reference) is formed on the fly in
+the kernel, and the 6 pair thetas are host-side arithmetic on 3 numbers.  ``add_doublet_GT``
+is kept as a public helper (and for n_GT > 3).
 """
 import itertools
 
@@ -50,27 +52,35 @@ def predict_doublet(vobj, AD, DP, update_GT=True, update_ID=True,
     exactly as vireo_doublet.py:11-82, including its side effects on ``vobj``
     (ID_prob <- un-renormalised singlet block, then update_GT_prob)."""
     counts = device_counts(AD, DP)
-    GT_both = add_doublet_GT(vobj.GT_prob)
+    K, T = vobj.GT_prob.shape[1], vobj.GT_prob.shape[2]
+    n_pair = K * (K - 1) // 2
+    C_ = K + n_pair
     beta_mu_both, beta_sum_both = add_doublet_theta(vobj.beta_mu, vobj.beta_sum)
-    n_pair = GT_both.shape[1] - vobj.GT_prob.shape[1]
     if doublet_rate_prior is None:
         doublet_rate_prior = min(0.5, counts.n_cell / 100000)
     ID_prior_both = np.append(
         vobj.ID_prior * (1 - doublet_rate_prior),
         np.ones((vobj.n_cell, n_pair)) / n_pair * doublet_rate_prior, axis=1)
 
-    # T' digamma values per theta row: O(T') host work (vireo_doublet.py:55-57)
+    # T + T(T-1)/2 digamma values per theta row: O(T') host work (vireo_doublet.py:55-57)
     psi1 = f64(digamma(beta_sum_both * beta_mu_both))
     psi2 = f64(digamma(beta_sum_both * (1 - beta_mu_both)))
     psis = f64(digamma(beta_sum_both))
-    C_, G_ = GT_both.shape[1], GT_both.shape[2]
     logLik_ID = np.empty((counts.n_cell, C_))
     ID_prob_both = np.empty((counts.n_cell, C_))
     prior = f64(ID_prior_both)
-    GT_both = f64(GT_both)
-    _lib.check(_lib.lib().vrx_problem_cell_loglik(
-        counts.handle, C_, G_, dptr(GT_both), dptr(psi1), dptr(psi2), dptr(psis),
-        psi1.shape[0], dptr(prior), prior.shape[0], dptr(logLik_ID), dptr(ID_prob_both)))
+    if T <= 3 and K >= 2:
+        # the pair genotype table (add_doublet_GT) is formed inside the kernel, never in memory
+        GT = f64(vobj.GT_prob)
+        _lib.check(_lib.lib().vrx_problem_doublet(
+            counts.handle, K, T, dptr(GT), dptr(psi1), dptr(psi2), dptr(psis), psi1.shape[0],
+            dptr(prior), prior.shape[0], dptr(logLik_ID), dptr(ID_prob_both)))
+    else:   # unusual n_GT: explicit table, same cell pass
+        GT_both = f64(add_doublet_GT(vobj.GT_prob))
+        _lib.check(_lib.lib().vrx_problem_cell_loglik(
+            counts.handle, C_, GT_both.shape[2], dptr(GT_both), dptr(psi1), dptr(psi2),
+            dptr(psis), psi1.shape[0], dptr(prior), prior.shape[0], dptr(logLik_ID),
+            dptr(ID_prob_both)))
 
     logLik_ratio = (logLik_ID[:, vobj.n_donor:].max(1) -
                     logLik_ID[:, :vobj.n_donor].max(1))
