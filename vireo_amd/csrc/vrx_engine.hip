@@ -205,12 +205,13 @@ static int build_orient(Orient& o, int64_t n_rows, int64_t n_contract, const int
     return VRX_OK;
 }
 
-// Tiled entry stream for vrx_spmm_lds (see vrx_kernels.h): VRX_LDS_RW rows per wave handled
+// Tiled entry stream for vrx_spmm_lds (see vrx_kernels.h): RW rows per wave handled
 // 16 at a time (a round), 16 waves per tile, slabs of slab_rows contracted indices; inside a
 // round the words are trip-major and zero-padded to the round's longest row.
 static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const int2* val,
-                       int slab_rows, hipStream_t s) {
-    constexpr int RW = VRX_LDS_RW, G = 16, NR = RW / G, U = VRX_LDS_U;
+                       int RW, int slab_rows, hipStream_t s) {
+    constexpr int G = 16, U = VRX_LDS_U;
+    const int NR = RW / G;
     TiledStream& t = o.tiled;
     t.pad = 4;
     t.rw = RW;
@@ -376,9 +377,10 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
     if (max_count < 2048 &&
         (lds == 1 || (lds != 0 && nnz >= (int64_t)env_int("VIREO_LDS_MIN_NNZ", 4000000)))) {
         // cell pass: slabs of 512 W rows (128 KiB at K = 16); variant pass: 1024 ID rows
-        rc = build_tiled(p->by_cell, colptr, rowidx, cval.data(), 512, p->stream);
+        rc = build_tiled(p->by_cell, colptr, rowidx, cval.data(), VRX_LDS_RW_CELL, 512, p->stream);
         if (rc) return rc;
-        rc = build_tiled(p->by_var, rptr.data(), ridx.data(), rval.data(), 1024, p->stream);
+        rc = build_tiled(p->by_var, rptr.data(), ridx.data(), rval.data(), VRX_LDS_RW_VARIANT, 1024,
+                         p->stream);
         if (rc) return rc;
     }
     *out = p.release();
@@ -754,7 +756,7 @@ static int launch_lds_one(const Orient& o, hipStream_t s, const double* X, int K
     const TiledStream& t = o.tiled;
     const size_t lds = (size_t)t.slab_rows * K * (MODE == 1 ? 16 : 8) + 16 * VRX_RING * 4;
     dim3 grid((unsigned)t.n_tile, (unsigned)t.n_range);
-    auto kern = vrx_spmm_lds<LPE, MODE>;
+    auto kern = vrx_spmm_lds<LPE, MODE, MODE == 1 ? VRX_LDS_RW_CELL : VRX_LDS_RW_VARIANT>;
     VRX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     kern<<<grid, 1024, lds, s>>>(t.ent.p, t.wave_start.p, t.bnd.p, t.n_slab, t.slab_rows,

@@ -283,22 +283,19 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_spmm(
 // Output: one partial array per contracted range (summed in fixed order afterwards).
 constexpr int VRX_RING = 512;   // entries per wave
 constexpr int VRX_CHUNK = 256;  // entries per refill (64 lanes x dwordx4)
-#ifndef VRX_LDS_RW_DEF
-#define VRX_LDS_RW_DEF 48
-#endif
 #ifndef VRX_LDS_U_DEF
 #define VRX_LDS_U_DEF 4
 #endif
-constexpr int VRX_LDS_RW = VRX_LDS_RW_DEF;  // output rows per wave (tile = 16 x this)
+// output rows per wave (tile = 16 x this), per pass: measured best on MI355X at c3
+constexpr int VRX_LDS_RW_VARIANT = 32, VRX_LDS_RW_CELL = 48;
 constexpr int VRX_LDS_U = VRX_LDS_U_DEF;    // entries per trip and group; rows are padded to it
 
-template <int LPE, int MODE>
+template <int LPE, int MODE, int RW>
 __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     const uint32_t* __restrict__ ent, const int64_t* __restrict__ wave_start,
     const int32_t* __restrict__ bnd, int n_slab, int slab_rows, int slabs_per_range,
     int64_t n_contract, int64_t n_rows, const double* __restrict__ X, int K,
     double* __restrict__ out) {
-    constexpr int RW = VRX_LDS_RW;
     constexpr int G = 64 / LPE;            // rows per round
     constexpr int NR = RW / G;             // rounds
     constexpr int XD = MODE == 1 ? 2 : 1;  // doubles per (contracted row, column)
@@ -555,9 +552,62 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_final(int n_part, int T, 
             for (int t = 0; t < 2 * VRX_MAXT; ++t) acc[t] += part[(int64_t)b * 2 * VRX_MAXT + t];
     block_sum_store<2 * VRX_MAXT>(acc, tot);
     __syncthreads();
-    if (threadIdx.x == 0)
-        kl_out[0] = vrx_theta_row(T, update, fix_sum, tot, tot + VRX_MAXT, prior1, prior2, mu, sm,
-                                  psi, psi + T, psi + 2 * T);
+    // The 9 special-function values per genotype class (3 digammas, 6 log-gammas) are the
+    // whole cost of this kernel: spread them over 9*T threads, combine in thread 0 in the
+    // same order as vrx_theta_row / vrx_beta_kl (identical arithmetic, ~9x shorter).
+    __shared__ double sh[VRX_MAXT][2];   // updated (mu, sum)
+    __shared__ double sf[VRX_MAXT][9];   // psi(s1) psi(s2) psi(s12) lg(q1) lg(q2) lg(q12) lg(s1) lg(s2) lg(s12)
+    if (threadIdx.x < T) {
+        const int t = threadIdx.x;
+        double m = mu[t], s = sm[t];
+        if (update) {
+            const double t1 = prior1[t] + tot[t];
+            const double t2 = prior2[t] + tot[VRX_MAXT + t];
+            m = t1 / (t1 + t2);
+            if (!fix_sum) s = t1 + t2;
+            mu[t] = m;
+            sm[t] = s;
+        }
+        sh[t][0] = m;
+        sh[t][1] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9 * T) {
+        const int t = threadIdx.x / 9, j = threadIdx.x % 9;
+        const double m = sh[t][0], s = sh[t][1];
+        const double s1 = m * s, s2 = (1.0 - m) * s, q1 = prior1[t], q2 = prior2[t];
+        double v;
+        switch (j) {
+            case 0: v = vrx_digamma(s1); break;
+            case 1: v = vrx_digamma(s2); break;
+            case 2: v = vrx_digamma(s1 + s2); break;
+            case 3: v = lgamma(q1); break;
+            case 4: v = lgamma(q2); break;
+            case 5: v = lgamma(q1 + q2); break;
+            case 6: v = lgamma(s1); break;
+            case 7: v = lgamma(s2); break;
+            default: v = lgamma(s1 + s2); break;
+        }
+        sf[t][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double kl = 0.0;
+        for (int t = 0; t < T; ++t) {
+            const double m = sh[t][0], s = sh[t][1];
+            const double s1 = m * s, s2 = (1.0 - m) * s, q1 = prior1[t], q2 = prior2[t];
+            const double d1 = sf[t][0], d2 = sf[t][1], ds = sf[t][2];
+            psi[t] = d1;
+            psi[T + t] = d2;
+            psi[2 * T + t] = ds;
+            const double cq = (sf[t][3] + sf[t][4] - sf[t][5]) - (q1 - 1.0) * d1 -
+                              (q2 - 1.0) * d2 + ((q1 + q2) - 2.0) * ds;
+            const double cp = (sf[t][6] + sf[t][7] - sf[t][8]) - (s1 - 1.0) * d1 -
+                              (s2 - 1.0) * d2 + ((s1 + s2) - 2.0) * ds;
+            kl += cq - cp;
+        }
+        kl_out[0] = kl;
+    }
 }
 
 // ASE mode: one theta row per variant (vireo_model.py:82,:177 axis=1).  Thread per variant.
