@@ -210,7 +210,7 @@ static int build_orient(Orient& o, int64_t n_rows, int64_t n_contract, const int
 // round the words are trip-major and zero-padded to the round's longest row.
 static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const int2* val,
                        int RW, int slab_rows, hipStream_t s) {
-    constexpr int G = 16, U = VRX_LDS_U;
+    constexpr int G = 64 / VRX_LDS_LPE, U = VRX_LDS_U;
     const int NR = RW / G;
     TiledStream& t = o.tiled;
     t.pad = 4;
@@ -748,7 +748,7 @@ static void launch_spmm_fmt(const Orient& o, dim3 grid, hipStream_t s, const dou
 template <int MODE>
 static bool lds_eligible(const Orient& o, int K) {
     static const int mask = env_int("VIREO_LDS_PASS", 3);  // bit 0: variant pass, bit 1: cell pass
-    return o.tiled.ready && (mask >> MODE & 1) && K <= 16 && K % 4 == 0;
+    return o.tiled.ready && (mask >> MODE & 1) && K <= 16 && K % (16 / VRX_LDS_LPE) == 0;
 }
 
 template <int LPE, int MODE>
@@ -773,7 +773,7 @@ static int launch_spmm_lds(vrx_model* m, const Orient& o, const double* X, int K
     constexpr int NV = MODE == 0 ? 2 : 1;
     double* dst = t.n_range == 1 ? out : range_partial;
     int rc;
-    rc = launch_lds_one<4, MODE>(o, s, X, K, dst);  // 4-lane groups; K < 16 leaves lanes idle
+    rc = launch_lds_one<VRX_LDS_LPE, MODE>(o, s, X, K, dst);  // K < 16 leaves lanes idle
     if (rc) return rc;
     if (t.n_range > 1 && !defer_sum) {
         const int64_t n = o.n_rows * K * NV;

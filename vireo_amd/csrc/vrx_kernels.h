@@ -287,7 +287,13 @@ constexpr int VRX_CHUNK = 256;  // entries per refill (64 lanes x dwordx4)
 #define VRX_LDS_U_DEF 4
 #endif
 // output rows per wave (tile = 16 x this), per pass: measured best on MI355X at c3
-constexpr int VRX_LDS_RW_VARIANT = 32, VRX_LDS_RW_CELL = 48;
+#ifndef VRX_LDS_LPE_DEF
+#define VRX_LDS_LPE_DEF 4
+#define VRX_LDS_RWV_DEF 32
+#define VRX_LDS_RWC_DEF 48
+#endif
+constexpr int VRX_LDS_RW_VARIANT = VRX_LDS_RWV_DEF, VRX_LDS_RW_CELL = VRX_LDS_RWC_DEF;
+constexpr int VRX_LDS_LPE = VRX_LDS_LPE_DEF;  // lanes per output row (16 / this columns per lane)
 constexpr int VRX_LDS_U = VRX_LDS_U_DEF;    // entries per trip and group; rows are padded to it
 
 template <int LPE, int MODE, int RW>
@@ -299,11 +305,12 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     constexpr int G = 64 / LPE;            // rows per round
     constexpr int NR = RW / G;             // rounds
     constexpr int XD = MODE == 1 ? 2 : 1;  // doubles per (contracted row, column)
-    constexpr int NQ = 2 * XD;             // 16-B reads per lane per entry (4 columns)
+    constexpr int CP = 16 / LPE;           // dense columns per lane (LPE lanes cover K <= 16)
+    constexpr int NQ = CP * XD / 2;        // 16-B reads per lane per entry
     constexpr int PF = 8;                  // 16-B prefetch registers per thread: 128 KiB / 1024
     constexpr int NV = MODE == 0 ? 2 : 1;  // accumulated values per column
     constexpr int U = VRX_LDS_U;           // entries per trip and group
-    static_assert(RW % G == 0 && RW < 64, "rows per wave");
+    static_assert(RW % G == 0 && RW / G < 63, "rows per wave");
     extern __shared__ __attribute__((aligned(16))) char vrx_smem[];
     double* slab = reinterpret_cast<double*>(vrx_smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     const int s_hi = (int)((int64_t)(blockIdx.y + 1) * n_slab / gridDim.y);
     if (s_lo >= s_hi) return;
     const int g = lane / LPE, kl = lane % LPE;
-    const bool kok = kl * 4 < K;  // K is a multiple of 4
+    const bool kok = kl * CP < K;  // K is a multiple of 4; a lane's columns may run past K
     const int64_t wid = (int64_t)tile * 16 + wave;
     const int32_t* bw = bnd + wid * ((int64_t)n_slab * NR + 1);
     const uint32_t* stream = ent + wave_start[wid];
