@@ -76,8 +76,7 @@ struct DevBuf {
 struct TiledStream {
     bool ready = false;
     int rw = 0, slab_rows = 0, n_slab = 0, n_tile = 0;
-    int pad = 4;  // every (slab,row) segment is padded to this many entries (= entries/step)
-    int n_range = 1, slabs_per_range = 0;
+    int n_range = 1;  // contracted ranges = gridDim.y of the LDS-resident pass
     DevBuf<uint32_t> ent;
     DevBuf<int64_t> wave_start;
     DevBuf<int32_t> bnd;

@@ -213,7 +213,6 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
     constexpr int G = 64 / VRX_LDS_LPE, U = VRX_LDS_U;
     const int NR = RW / G;
     TiledStream& t = o.tiled;
-    t.pad = 4;
     t.rw = RW;
     t.slab_rows = slab_rows;
     t.n_slab = (int)((o.n_contract + slab_rows - 1) / slab_rows);
@@ -223,7 +222,6 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
     // the largest n_range with n_tile * n_range <= target (4 rounds of 256 CUs by default)
     const int want = env_int("VIREO_LDS_BLOCKS", 1024);
     t.n_range = std::max(1, std::min(t.n_slab, want / std::max(1, t.n_tile)));
-    t.slabs_per_range = (t.n_slab + t.n_range - 1) / t.n_range;  // (upper bound; kernel splits evenly)
     const int64_t n_wave = (int64_t)t.n_tile * 16;
     const int64_t per_wave = (int64_t)t.n_slab * NR + 1;
     std::vector<uint32_t> ent;
@@ -760,7 +758,7 @@ static int launch_lds_one(const Orient& o, hipStream_t s, const double* X, int K
     VRX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     kern<<<grid, 1024, lds, s>>>(t.ent.p, t.wave_start.p, t.bnd.p, t.n_slab, t.slab_rows,
-                                 t.slabs_per_range, o.n_contract, o.n_rows, X, K, dst);
+                                 o.n_contract, o.n_rows, X, K, dst);
     VRX_HIP(hipGetLastError());
     return VRX_OK;
 }

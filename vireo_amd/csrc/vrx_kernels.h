@@ -4,15 +4,18 @@
 //   13 scipy SpMMs + 2 sparse subtractions + dense softmaxes + an ELBO reduction.
 // Here it is TWO streaming passes over the (ad,dp) matrix plus a few dense kernels:
 //
-//   variant pass  (spmm<KP,0>)  S[n,k]   = ( sum_m ad*ID[m,k] , sum_m dp*ID[m,k] )
-//   cell pass     (spmm<KP,1>)  LID[m,k] =   sum_n ad*W1[n,k] + dp*W2[n,k]
+//   variant pass  S[n,k]   = ( sum_m ad*ID[m,k] , sum_m dp*ID[m,k] )
+//   cell pass     LID[m,k] =   sum_n ad*W1[n,k] + dp*W2[n,k]
 //        with  W1 = sum_t GT[n,k,t](psi1_t - psi2_t),  W2 = sum_t GT[n,k,t](psi2_t - psis_t)
 //        (AD^T(GT psi1) + BD^T(GT psi2) - DP^T(GT psis)  regrouped by ad and dp)
 //
-// Both passes are HBM-bound integer streams (12 B per non-zero) with an fp64 gather of a
-// dense row per non-zero; nothing here is GEMM-shaped enough for MFMA (the K x T
-// contraction is a length-3 dot product).  All arithmetic is fp64; all reductions are
-// fixed-order (no atomics), so results are run-to-run deterministic.
+// Each pass exists twice: vrx_spmm (gathers the dense rows from global memory; any K, any
+// counts; bound by the L1-miss path) and vrx_spmm_lds (streams the dense operand through
+// LDS; large problems, K a multiple of 4 up to 16).  The passes are integer streams (4-12 B
+// per non-zero) with an fp64 row read per non-zero; nothing here is GEMM-shaped enough for
+// MFMA (the K x T contraction is a length-3 dot product, fp64 MFMA runs at the vector rate).
+// All arithmetic is fp64; all reductions are fixed-order (no atomics), so results are
+// run-to-run deterministic.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -299,9 +302,8 @@ constexpr int VRX_LDS_U = VRX_LDS_U_DEF;    // entries per trip and group; rows 
 template <int LPE, int MODE, int RW>
 __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     const uint32_t* __restrict__ ent, const int64_t* __restrict__ wave_start,
-    const int32_t* __restrict__ bnd, int n_slab, int slab_rows, int slabs_per_range,
-    int64_t n_contract, int64_t n_rows, const double* __restrict__ X, int K,
-    double* __restrict__ out) {
+    const int32_t* __restrict__ bnd, int n_slab, int slab_rows, int64_t n_contract,
+    int64_t n_rows, const double* __restrict__ X, int K, double* __restrict__ out) {
     constexpr int G = 64 / LPE;            // rows per round
     constexpr int NR = RW / G;             // rounds
     constexpr int XD = MODE == 1 ? 2 : 1;  // doubles per (contracted row, column)
