@@ -351,6 +351,35 @@ def test_lds_resident_passes_vs_oracle(va, monkeypatch, fmt, blocks):
         close(dev.GT_prob, ref.GT_prob)
 
 
+@pytest.mark.parametrize("top,expect_lds", [(2047, True), (2048, False)])
+def test_lds_count_limit_and_tiny_shapes(va, monkeypatch, top, expect_lds):
+    """the tiled words hold counts < 2048: at the limit the LDS passes are used, one above
+    the problem silently stays on the global-gather kernels; shapes smaller than one tile /
+    one slab (N=70 variants, M=40 cells) and a single contracted range."""
+    from vireo_amd import _lib
+    from vireo_amd.counts import DeviceCounts
+    from vireo_amd.engine import DeviceModel
+    monkeypatch.setenv("VIREO_LDS", "1")
+    rng = np.random.default_rng(5)
+    dp = (rng.random((70, 40)) < 0.3) * rng.integers(1, 60, (70, 40))
+    dp[3, 7] = top
+    ad = rng.binomial(dp, 0.3)
+    AD, DP = csc_matrix(ad), csc_matrix(dp)
+    counts = DeviceCounts(AD, DP)
+    K = 8
+    info = DeviceModel(counts, _lib.KIND_VIREO, K).info()
+    assert info["lds_cell"] == info["lds_variant"] == expect_lds
+    np.random.seed(2)
+    ref = O.vireo_new(40, 70, K)
+    np.random.seed(2)
+    dev = va.Vireo(n_var=70, n_cell=40, n_donor=K)
+    O.vireo_fit(ref, AD, DP, max_iter=6)
+    dev.fit(counts, None, max_iter=6, verbose=False)
+    close(dev.ELBO_, ref.ELBO_)
+    close(dev.ID_prob, ref.ID_prob)
+    close(dev.GT_prob, ref.GT_prob)
+
+
 def test_determinism(va):
     AD, DP = O.synth_donor(3000, 2000, 16, 0.03, seed=5)
     runs = []
