@@ -79,11 +79,13 @@ def main():
     _lib.require_gpu()
 
     comm = vdist.LocalComm()
-    if world > 1:
-        import torch.distributed as tdist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        tdist.init_process_group("gloo")              # out-of-band channel for the RCCL id only
-        comm = vdist.RcclComm(rank, world, local, vdist.torch_store_exchange())
+    # One process per GPU (torch.distributed.run only LAUNCHES the ranks and sets RANK /
+    # WORLD_SIZE / MASTER_*); the ranks talk over RCCL through libvireo_hip.so, and the RCCL
+    # unique id travels over a plain socket -- torch is never imported here: its bundled HIP
+    # runtime and librccl would collide with the library's.  VIREO_BENCH_FORCE_RCCL=1 takes
+    # this path at world 1 too, so a 1-GPU box can exercise it.
+    if world > 1 or os.environ.get("VIREO_BENCH_FORCE_RCCL") == "1":
+        comm = vdist.RcclComm(rank, world, local, vdist.socket_exchange(rank, world))
 
     N, M, K, dens = synth.CONFIGS[args.config]
     T = 3
@@ -210,11 +212,9 @@ def main():
         if cpu:
             out["speedup_vs_cpu_1core"] = out["value"] / cpu["value"]
         print(json.dumps(out))
-    if world > 1:
+    if isinstance(comm, vdist.RcclComm):
+        comm.barrier()
         comm.close()
-        import torch.distributed as tdist
-        tdist.barrier()
-        tdist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -172,3 +172,26 @@ def test_fast_generator_equals_oracle_generator():
         shape, ptr, idx, a, dp = merge_counts(AD, DP)
         assert np.array_equal(ptr, w["colptr"]) and np.array_equal(idx, w["rowidx"])
         assert np.array_equal(a, w["ad"]) and np.array_equal(dp, w["dp"])
+
+
+def test_socket_exchange_world3():
+    """the torch-free rendezvous that hands rank 0's RCCL unique id to the other ranks"""
+    import multiprocessing as mp
+    from vireo_amd import _lib
+    port = _free_port()
+    payload = bytes(range(_lib.UNIQUE_ID_BYTES))
+
+    def worker(rank, q):
+        from vireo_amd.dist import socket_exchange
+        ex = socket_exchange(rank, 3, addr="127.0.0.1", port=port, timeout=60)
+        q.put((rank, ex(payload if rank == 0 else None)))
+
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, q)) for r in (1, 2, 0)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(3))
+    for p in procs:
+        p.join(timeout=30)
+    assert got == {0: payload, 1: payload, 2: payload}

@@ -101,8 +101,55 @@ class GlooComm:
         self._dist.barrier()
 
 
+def socket_exchange(rank, world, addr=None, port=None, timeout=600.0):
+    """unique-id exchange over a plain TCP socket: rank 0 serves the id on
+    (MASTER_ADDR, VIREO_RDZV_PORT or MASTER_PORT + 1), every other rank fetches it.
+    No PyTorch involved -- importing torch next to libvireo_hip.so puts a second HIP runtime
+    (and a second librccl) into the process, and RCCL initialisation then fails."""
+    import socket
+    import time
+    addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+    if port is None:
+        port = int(os.environ.get("VIREO_RDZV_PORT",
+                                  int(os.environ.get("MASTER_PORT", "29500")) + 1))
+
+    def exchange(raw):
+        if world == 1:
+            return raw
+        if rank == 0:
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as srv:
+                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                srv.bind(("", port))
+                srv.listen(world)
+                srv.settimeout(timeout)
+                for _ in range(world - 1):
+                    conn, _peer = srv.accept()
+                    with conn:
+                        conn.sendall(raw)
+            return raw
+        deadline = time.time() + timeout
+        while True:
+            try:
+                with socket.create_connection((addr, port), timeout=10.0) as s:
+                    buf = b""
+                    while len(buf) < _lib.UNIQUE_ID_BYTES:
+                        chunk = s.recv(_lib.UNIQUE_ID_BYTES - len(buf))
+                        if not chunk:
+                            break
+                        buf += chunk
+                if len(buf) == _lib.UNIQUE_ID_BYTES:
+                    return buf
+            except OSError:
+                pass
+            if time.time() > deadline:
+                raise TimeoutError("no RCCL unique id from rank 0 at %s:%d" % (addr, port))
+            time.sleep(0.2)
+    return exchange
+
+
 def torch_store_exchange():
-    """unique-id exchange through an initialised torch.distributed group (any backend)."""
+    """unique-id exchange through an initialised torch.distributed group (any backend).
+    Only for processes that use torch on the CPU alone (see socket_exchange)."""
     import torch.distributed as dist
 
     def exchange(raw):
