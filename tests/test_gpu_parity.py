@@ -380,6 +380,49 @@ def test_lds_count_limit_and_tiny_shapes(va, monkeypatch, top, expect_lds):
     close(dev.GT_prob, ref.GT_prob)
 
 
+@pytest.mark.parametrize("shape", ["row", "full"])
+def test_nonuniform_id_prior_vs_oracle(va, shape):
+    """ID_prior as one broadcast row (set_prior with a 1-D array, vireo_model.py:122-125) and
+    as a full (n_cell, n_donor) table, un-normalised on purpose: scipy's entropy normalises
+    q, np.log(prior) in the softmax does not need to."""
+    AD, DP = gold.c1()
+    M, K = AD.shape[1], 4
+    rng = np.random.default_rng(8)
+    prior = rng.random(K) + 0.2 if shape == "row" else rng.random((M, K)) + 0.2
+    np.random.seed(3)
+    ref = O.vireo_new(M, AD.shape[0], K)
+    O.vireo_prior(ref, ID_prior=prior.copy())
+    np.random.seed(3)
+    dev = va.Vireo(n_var=AD.shape[0], n_cell=M, n_donor=K)
+    dev.set_prior(ID_prior=prior.copy())
+    O.vireo_fit(ref, AD, DP, max_iter=10)
+    dev.fit(AD, DP, max_iter=10, verbose=False)
+    assert len(dev.ELBO_) == len(ref.ELBO_)
+    close(dev.ELBO_, ref.ELBO_)
+    close(dev.ID_prob, ref.ID_prob)
+    close(dev.GT_prob, ref.GT_prob)
+
+
+def test_bmm_fix_beta_sum_and_custom_prior_vs_oracle(va):
+    AD, DP = gold.mito()
+    N, M, K = AD.shape[0], AD.shape[1], 3
+    np.random.seed(4)
+    ref = O.bmm_new(M, N, K, fix_beta_sum=True)
+    ID0 = ref.ID_prob.copy()
+    O.bmm_fit_vb(ref, AD, DP, max_iter=12, min_iter=3)
+    dev = va.BinomMixtureVB(n_var=N, n_cell=M, n_donor=K, fix_beta_sum=True, ID_prob_init=ID0)
+    dev._fit_BV(AD, DP, max_iter=12, min_iter=3, verbose=False)
+    assert len(dev.ELBO_iters) == len(ref.ELBO_iters)
+    close(dev.ELBO_iters, ref.ELBO_iters)
+    close(dev.ID_prob, ref.ID_prob)
+    close(dev.beta_mu, ref.beta_mu)
+    close(dev.beta_sum, ref.beta_sum)      # stays at its initial 30
+    # the public step methods of the clone model
+    L = dev.get_E_logLik(AD, DP)
+    close(L, O.bmm_cell_loglik(ref, AD, DP), rtol=1e-9)
+    close(dev.get_ELBO(AD, DP, logLik_ID=L), O.bmm_elbo(ref, L), rtol=1e-9)
+
+
 def test_determinism(va):
     AD, DP = O.synth_donor(3000, 2000, 16, 0.03, seed=5)
     runs = []
