@@ -3,6 +3,8 @@
 // problem and runs the coordinate-ascent loop of the reference
 // (vireoSNP/utils/vireo_model.py:251-276, vireoSNP/utils/bmm_model.py:178-201).
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cmath>
 #include <cstdarg>
 #include <cstring>
@@ -58,6 +60,34 @@ static constexpr int kSegCap = 4096;     // entries per segment (one wavefront e
 static constexpr int kXcd = 8;           // XCDs per MI355X; workgroup b is observed on XCD b % 8
 static constexpr double kSlabBytes = 1.6e6;  // dense-operand slab per tile (fits a 4 MiB L2)
 
+// Host-side build of a problem (validation, transposition, packing, tiling) is plain loops
+// over the non-zeros; they are spread over host threads (VIREO_HOST_THREADS, default <= 32).
+static int host_threads() {
+    static const int n = [] {
+        const char* v = getenv("VIREO_HOST_THREADS");
+        int t = v && *v ? atoi(v) : (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+        return std::max(1, t);
+    }();
+    return n;
+}
+
+// f(begin, end, tid) over [0, n) cut into contiguous chunks, one per thread
+template <class F>
+static void parallel_chunks(int64_t n, int n_threads, F&& f) {
+    n_threads = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, n));
+    if (n_threads == 1) {
+        f((int64_t)0, n, 0);
+        return;
+    }
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)n_threads);
+    for (int t = 0; t < n_threads; ++t) {
+        const int64_t b = n * t / n_threads, e = n * (t + 1) / n_threads;
+        pool.emplace_back([&f, b, e, t] { f(b, e, t); });
+    }
+    for (auto& th : pool) th.join();
+}
+
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v && *v ? atoi(v) : dflt;
@@ -90,19 +120,21 @@ static int build_orient(Orient& o, int64_t n_rows, int64_t n_contract, const int
     // ---- entries ------------------------------------------------------------------
     const int ew = fmt + 1;
     std::vector<uint32_t> ent((size_t)o.nnz * ew);
-    for (int64_t e = 0; e < o.nnz; ++e) {
-        const uint32_t id = (uint32_t)idx[e], ad = (uint32_t)val[e].x, dp = (uint32_t)val[e].y;
-        if (fmt == VRX_FMT_P32) {
-            ent[(size_t)e] = (id << 12) | (ad << 6) | dp;
-        } else if (fmt == VRX_FMT_P64) {
-            ent[(size_t)e * 2] = id;
-            ent[(size_t)e * 2 + 1] = ad | (dp << 16);
-        } else {
-            ent[(size_t)e * 3] = id;
-            ent[(size_t)e * 3 + 1] = ad;
-            ent[(size_t)e * 3 + 2] = dp;
+    parallel_chunks(o.nnz, host_threads(), [&](int64_t b, int64_t e_end, int) {
+        for (int64_t e = b; e < e_end; ++e) {
+            const uint32_t id = (uint32_t)idx[e], ad = (uint32_t)val[e].x, dp = (uint32_t)val[e].y;
+            if (fmt == VRX_FMT_P32) {
+                ent[(size_t)e] = (id << 12) | (ad << 6) | dp;
+            } else if (fmt == VRX_FMT_P64) {
+                ent[(size_t)e * 2] = id;
+                ent[(size_t)e * 2 + 1] = ad | (dp << 16);
+            } else {
+                ent[(size_t)e * 3] = id;
+                ent[(size_t)e * 3 + 1] = ad;
+                ent[(size_t)e * 3 + 2] = dp;
+            }
         }
-    }
+    });
     // ---- tile boundaries: equal entry counts ------------------------------------------
     std::vector<int64_t> bound((size_t)n_tiles + 1, n_contract);
     bound[0] = 0;
@@ -224,27 +256,26 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
     t.n_range = std::max(1, std::min(t.n_slab, want / std::max(1, t.n_tile)));
     const int64_t n_wave = (int64_t)t.n_tile * 16;
     const int64_t per_wave = (int64_t)t.n_slab * NR + 1;
-    std::vector<uint32_t> ent;
-    ent.reserve((size_t)(o.nnz * 1.9) + 1024);
-    std::vector<int64_t> wave_start((size_t)n_wave);
+    std::vector<int64_t> wave_start((size_t)n_wave), wave_len((size_t)n_wave, 0);
     std::vector<int32_t> bnd((size_t)(n_wave * per_wave));
-    std::vector<int64_t> cursor((size_t)RW), seg_lo((size_t)G), seg_hi((size_t)G);
-    for (int64_t w = 0; w < n_wave; ++w) {
+    std::vector<uint32_t> ent;
+    std::atomic<bool> too_long{false};
+    // One wave's stream: walks its RW rows slab by slab; pass 1 (dst == nullptr) records the
+    // (slab, round) offsets and the length, pass 2 writes the words.  Waves are independent.
+    auto walk = [&](int64_t w, uint32_t* dst) {
         const int64_t r0 = w * RW;
-        while (ent.size() % 4) ent.push_back(0u);  // 16-B aligned start (dwordx4 refills)
-        const int64_t start = (int64_t)ent.size();
-        wave_start[(size_t)w] = start;
+        std::vector<int64_t> cursor((size_t)RW), seg_lo((size_t)G), seg_hi((size_t)G);
         for (int c = 0; c < RW; ++c) cursor[(size_t)c] = r0 + c < o.n_rows ? ptr[r0 + c] : 0;
-        int32_t* b = bnd.data() + w * per_wave;
+        int32_t* bw = bnd.data() + w * per_wave;
+        int64_t rel = 0;
         for (int sl = 0; sl < t.n_slab; ++sl) {
             const int64_t lim = (int64_t)(sl + 1) * slab_rows, base = (int64_t)sl * slab_rows;
             for (int r = 0; r < NR; ++r) {
-                const int64_t rel = (int64_t)ent.size() - start;
                 if (rel >= INT32_MAX - 4096) {
-                    vrx_set_error("tiled stream: wave stream >= 2^31 words");
-                    return VRX_ERR_UNSUPPORTED;
+                    too_long = true;
+                    return;
                 }
-                b[(int64_t)sl * NR + r] = (int32_t)rel;
+                bw[(int64_t)sl * NR + r] = (int32_t)rel;
                 int64_t longest = 0;
                 for (int g = 0; g < G; ++g) {
                     const int64_t row = r0 + (int64_t)r * G + g;
@@ -260,19 +291,38 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
                     longest = std::max(longest, hi - lo);
                 }
                 longest = (longest + U - 1) / U * U;
-                for (int64_t j = 0; j < longest; ++j)
-                    for (int g = 0; g < G; ++g) {
-                        const int64_t e = seg_lo[(size_t)g] + j;
-                        uint32_t word = 0u;  // padding: index 0, ad = dp = 0
-                        if (e < seg_hi[(size_t)g])
-                            word = ((uint32_t)(idx[e] - base) << 22) | ((uint32_t)val[e].x << 11) |
-                                   (uint32_t)val[e].y;
-                        ent.push_back(word);
-                    }
+                if (dst)
+                    for (int64_t j = 0; j < longest; ++j)
+                        for (int g = 0; g < G; ++g) {
+                            const int64_t e = seg_lo[(size_t)g] + j;
+                            uint32_t word = 0u;  // padding: index 0, ad = dp = 0
+                            if (e < seg_hi[(size_t)g])
+                                word = ((uint32_t)(idx[e] - base) << 22) |
+                                       ((uint32_t)val[e].x << 11) | (uint32_t)val[e].y;
+                            dst[rel + j * G + g] = word;
+                        }
+                rel += longest * G;  // (a multiple of 64 words: streams stay 16-B aligned)
             }
         }
-        b[(int64_t)t.n_slab * NR] = (int32_t)((int64_t)ent.size() - start);
+        bw[(int64_t)t.n_slab * NR] = (int32_t)rel;
+        wave_len[(size_t)w] = rel;
+    };
+    parallel_chunks(n_wave, host_threads(), [&](int64_t b0, int64_t e0, int) {
+        for (int64_t w = b0; w < e0; ++w) walk(w, nullptr);
+    });
+    if (too_long) {
+        vrx_set_error("tiled stream: wave stream >= 2^31 words");
+        return VRX_ERR_UNSUPPORTED;
     }
+    int64_t total = 0;
+    for (int64_t w = 0; w < n_wave; ++w) {
+        wave_start[(size_t)w] = total;
+        total += wave_len[(size_t)w];
+    }
+    ent.assign((size_t)total, 0u);
+    parallel_chunks(n_wave, host_threads(), [&](int64_t b0, int64_t e0, int) {
+        for (int64_t w = b0; w < e0; ++w) walk(w, ent.data() + wave_start[(size_t)w]);
+    });
     for (int i = 0; i < 8; ++i) ent.push_back(0u);  // slack for the last dwordx4 refill
     VRX_HIP(t.ent.upload(ent.data(), ent.size(), s));
     VRX_HIP(t.wave_start.upload(wave_start.data(), wave_start.size(), s));
@@ -309,50 +359,87 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
     p->n_cu = prop.multiProcessorCount;
     VRX_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
 
-    // validate + interleave (ad, dp); count per-cell and per-variant entries
+    // validate + interleave (ad, dp); count per-cell and per-variant entries.  Cells are cut
+    // into one contiguous chunk per host thread; every thread keeps its own per-variant
+    // histogram, which also gives it private write cursors for the transposition below
+    // (a parallel counting sort: cells stay increasing inside each variant row).
     std::vector<int2> cval((size_t)nnz);
     std::vector<int64_t> rptr((size_t)n_var + 1, 0);
     p->n_vars.assign((size_t)n_cell, 0);
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), n_cell));
+    std::vector<std::vector<int64_t>> hist((size_t)nt, std::vector<int64_t>((size_t)n_var, 0));
+    std::vector<int32_t> tmax((size_t)nt, 0);
+    std::vector<int64_t> bad_col((size_t)nt, -1), bad_kind((size_t)nt, 0);
+    parallel_chunks(n_cell, nt, [&](int64_t c0, int64_t c1, int tid) {
+        auto& h = hist[(size_t)tid];
+        int32_t mx = 0;
+        for (int64_t c = c0; c < c1; ++c) {
+            if (colptr[c + 1] < colptr[c]) {
+                bad_col[(size_t)tid] = c, bad_kind[(size_t)tid] = 1;
+                return;
+            }
+            int32_t prev = -1, nv = 0;
+            for (int64_t e = colptr[c]; e < colptr[c + 1]; ++e) {
+                const int32_t r = rowidx[e];
+                if (r <= prev || r >= n_var) {
+                    bad_col[(size_t)tid] = c, bad_kind[(size_t)tid] = 2;
+                    return;
+                }
+                if (ad[e] < 0 || dp[e] < 0) {
+                    bad_col[(size_t)tid] = c, bad_kind[(size_t)tid] = 3;
+                    return;
+                }
+                prev = r;
+                cval[(size_t)e] = make_int2(ad[e], dp[e]);
+                mx = std::max(mx, std::max(ad[e], dp[e]));
+                ++h[(size_t)r];
+                nv += dp[e] > 0;
+            }
+            p->n_vars[(size_t)c] = nv;
+        }
+        tmax[(size_t)tid] = mx;
+    });
     int32_t max_count = 0;
-    for (int64_t c = 0; c < n_cell; ++c) {
-        if (colptr[c + 1] < colptr[c]) {
-            vrx_set_error("vrx_problem_create: colptr not monotone at column %lld", (long long)c);
+    for (int t = 0; t < nt; ++t) {
+        max_count = std::max(max_count, tmax[(size_t)t]);
+        if (bad_kind[(size_t)t] == 1) {
+            vrx_set_error("vrx_problem_create: colptr not monotone at column %lld",
+                          (long long)bad_col[(size_t)t]);
             return VRX_ERR_ARG;
         }
-        int32_t prev = -1, nv = 0;
-        for (int64_t e = colptr[c]; e < colptr[c + 1]; ++e) {
-            const int32_t r = rowidx[e];
-            if (r <= prev || r >= n_var) {
-                vrx_set_error("vrx_problem_create: row indices of column %lld not strictly "
-                              "increasing / out of range", (long long)c);
-                return VRX_ERR_ARG;
-            }
-            if (ad[e] < 0 || dp[e] < 0) {
-                vrx_set_error("vrx_problem_create: negative count at entry %lld", (long long)e);
-                return VRX_ERR_ARG;
-            }
-            prev = r;
-            cval[(size_t)e] = make_int2(ad[e], dp[e]);
-            max_count = std::max(max_count, std::max(ad[e], dp[e]));
-            ++rptr[(size_t)r + 1];
-            nv += dp[e] > 0;
+        if (bad_kind[(size_t)t] == 2) {
+            vrx_set_error("vrx_problem_create: row indices of column %lld not strictly "
+                          "increasing / out of range", (long long)bad_col[(size_t)t]);
+            return VRX_ERR_ARG;
         }
-        p->n_vars[(size_t)c] = nv;
+        if (bad_kind[(size_t)t] == 3) {
+            vrx_set_error("vrx_problem_create: negative count in column %lld",
+                          (long long)bad_col[(size_t)t]);
+            return VRX_ERR_ARG;
+        }
     }
-    for (int64_t r = 0; r < n_var; ++r) rptr[(size_t)r + 1] += rptr[(size_t)r];
-
-    // variant-major copy (counting sort keeps cells increasing inside each variant row)
+    // rptr = exclusive scan of the per-variant totals; hist[t][r] becomes thread t's first
+    // write position inside variant row r
+    for (int64_t r = 0; r < n_var; ++r) {
+        int64_t at = rptr[(size_t)r];
+        for (int t = 0; t < nt; ++t) {
+            const int64_t n = hist[(size_t)t][(size_t)r];
+            hist[(size_t)t][(size_t)r] = at;
+            at += n;
+        }
+        rptr[(size_t)r + 1] = at;
+    }
     std::vector<int32_t> ridx((size_t)nnz);
     std::vector<int2> rval((size_t)nnz);
-    {
-        std::vector<int64_t> cur(rptr.begin(), rptr.end() - 1);
-        for (int64_t c = 0; c < n_cell; ++c)
+    parallel_chunks(n_cell, nt, [&](int64_t c0, int64_t c1, int tid) {
+        auto& cur = hist[(size_t)tid];
+        for (int64_t c = c0; c < c1; ++c)
             for (int64_t e = colptr[c]; e < colptr[c + 1]; ++e) {
                 const int64_t q = cur[(size_t)rowidx[e]]++;
                 ridx[(size_t)q] = (int32_t)c;
                 rval[(size_t)q] = cval[(size_t)e];
             }
-    }
+    });
     // narrowest entry format that holds the counts and the contracted index
     auto pick_fmt = [&](int64_t n_contract) {
         int f = VRX_FMT_WIDE;
