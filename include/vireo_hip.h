@@ -180,8 +180,9 @@ int vrx_problem_cell_loglik(vrx_problem* p, int64_t n_col, int64_t n_class,
  * LDS-resident (vrx_spmm_lds) else 0 (vrx_spmm, global gathers); info[2]/[3] = entry format
  * of the variant/cell orientation (0: 4 B, 1: 8 B, 2: 12 B per non-zero); info[4]/[5] =
  * L2 tiles of the variant/cell orientation; info[6]/[7] = contracted ranges of the
- * LDS-resident variant/cell pass. */
-int vrx_model_info(vrx_model* m, int32_t* info8);
+ * LDS-resident variant/cell pass; info[8]/[9] = its stream words (padding included) per 1000
+ * non-zeros; info[10]/[11] = extra row pieces (long rows are cut into interleaved pieces). */
+int vrx_model_info(vrx_model* m, int32_t* info12);
 int vrx_model_profile(vrx_model* m, int32_t enable);
 int vrx_model_profile_read(vrx_model* m, double* ms_total /* VRX_KERN_COUNT */,
                            int64_t* launches /* VRX_KERN_COUNT */);

@@ -80,6 +80,12 @@ struct TiledStream {
     DevBuf<uint32_t> ent;
     DevBuf<int64_t> wave_start;
     DevBuf<int32_t> bnd;
+    DevBuf<int32_t> rowmap;   // tile position -> piece (-1 = padding), pieces sorted by length
+    DevBuf<int32_t> vptr;     // row -> its pieces [vptr[r], vptr[r+1]) (only when split)
+    int64_t n_vrows = 0;      // pieces (== rows unless split)
+    bool split = false;       // some row is cut into several pieces
+    double pad_ratio = 0.0;   // stream words per entry
+    double imbalance = 1.0;   // longest wave stream / mean wave stream
 };
 
 struct Orient {

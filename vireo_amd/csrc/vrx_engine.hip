@@ -240,16 +240,44 @@ static int build_orient(Orient& o, int64_t n_rows, int64_t n_contract, const int
 // Tiled entry stream for vrx_spmm_lds (see vrx_kernels.h): RW rows per wave handled
 // 16 at a time (a round), 16 waves per tile, slabs of slab_rows contracted indices; inside a
 // round the words are trip-major and zero-padded to the round's longest row.
+//
+// Ragged data (heavy-tailed coverage / depth): a round costs its LONGEST row and a workgroup
+// its slowest wave, so (1) a row much longer than the mean is cut into P interleaved PIECES
+// (entry j of a slab segment -> piece (j + slab) % P) that accumulate separately and are
+// summed afterwards in piece order (vrx_sum_pieces), (2) pieces are sorted by length so that
+// a round holds 16 similar ones, (3) the sorted rounds are dealt to the waves in snake order
+// so that every wave (and tile) carries about the same number of entries.
 static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const int2* val,
-                       int RW, int slab_rows, hipStream_t s) {
+                       int RW, int slab_rows, bool guard, hipStream_t s) {
     constexpr int G = 64 / VRX_LDS_LPE, U = VRX_LDS_U;
     const int NR = RW / G;
     TiledStream& t = o.tiled;
     t.rw = RW;
     t.slab_rows = slab_rows;
     t.n_slab = (int)((o.n_contract + slab_rows - 1) / slab_rows);
+    // ---- pieces ------------------------------------------------------------------------
+    const double mean = (double)o.nnz / (double)std::max<int64_t>(o.n_rows, 1);
+    const int64_t cap = std::max<int64_t>(
+        64, (int64_t)(mean * (double)env_int("VIREO_LDS_SPLIT_X10", 20) / 10.0 + 0.5));
+    const bool reorder = env_int("VIREO_LDS_SORT", 1) != 0;
+    std::vector<int32_t> vptr((size_t)o.n_rows + 1, 0);
+    for (int64_t r = 0; r < o.n_rows; ++r) {
+        const int64_t len = ptr[r + 1] - ptr[r];
+        const int64_t P = reorder ? std::max<int64_t>(1, (len + cap - 1) / cap) : 1;
+        if ((int64_t)vptr[(size_t)r] + P >= INT32_MAX) {
+            vrx_set_error("tiled stream: too many row pieces");
+            return VRX_ERR_UNSUPPORTED;
+        }
+        vptr[(size_t)r + 1] = vptr[(size_t)r] + (int32_t)P;
+    }
+    const int64_t n_vrows = vptr[(size_t)o.n_rows];
+    t.n_vrows = n_vrows;
+    t.split = n_vrows != o.n_rows;
+    std::vector<int32_t> vrow_row((size_t)n_vrows);
+    for (int64_t r = 0; r < o.n_rows; ++r)
+        for (int32_t v = vptr[(size_t)r]; v < vptr[(size_t)r + 1]; ++v) vrow_row[(size_t)v] = (int32_t)r;
     const int64_t tile_rows = 16 * (int64_t)RW;
-    t.n_tile = (int)((o.n_rows + tile_rows - 1) / tile_rows);
+    t.n_tile = (int)((n_vrows + tile_rows - 1) / tile_rows);
     // one workgroup per CU at a time (LDS), so the grid should fill whole rounds of CUs:
     // the largest n_range with n_tile * n_range <= target (4 rounds of 256 CUs by default)
     const int want = env_int("VIREO_LDS_BLOCKS", 1024);
@@ -260,12 +288,34 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
     std::vector<int32_t> bnd((size_t)(n_wave * per_wave));
     std::vector<uint32_t> ent;
     std::atomic<bool> too_long{false};
-    // One wave's stream: walks its RW rows slab by slab; pass 1 (dst == nullptr) records the
+    // ---- tile position -> piece (-1 = padding position) ---------------------------------
+    std::vector<int32_t> rowmap((size_t)(n_wave * RW), -1);
+    {
+        std::vector<int32_t> order((size_t)n_vrows);
+        for (int64_t v = 0; v < n_vrows; ++v) order[(size_t)v] = (int32_t)v;
+        if (reorder) {
+            auto piece_len = [&](int32_t v) {
+                const int32_t r = vrow_row[(size_t)v];
+                return (ptr[r + 1] - ptr[r]) / (vptr[(size_t)r + 1] - vptr[(size_t)r]);
+            };
+            std::stable_sort(order.begin(), order.end(),
+                             [&](int32_t a, int32_t b) { return piece_len(a) > piece_len(b); });
+        }
+        const int64_t n_unit = (n_vrows + G - 1) / G;
+        for (int64_t u = 0; u < n_unit; ++u) {
+            const int64_t j = u / n_wave, i = u % n_wave;  // stratum j -> round j of the wave
+            const int64_t w = reorder && (j & 1) ? n_wave - 1 - i : i;
+            for (int g = 0; g < G && u * G + g < n_vrows; ++g)
+                rowmap[(size_t)(w * RW + j * G + g)] = order[(size_t)(u * G + g)];
+        }
+    }
+    // One wave's stream: walks its RW pieces slab by slab; pass 1 (dst == nullptr) records the
     // (slab, round) offsets and the length, pass 2 writes the words.  Waves are independent.
     auto walk = [&](int64_t w, uint32_t* dst) {
-        const int64_t r0 = w * RW;
-        std::vector<int64_t> cursor((size_t)RW), seg_lo((size_t)G), seg_hi((size_t)G);
-        for (int c = 0; c < RW; ++c) cursor[(size_t)c] = r0 + c < o.n_rows ? ptr[r0 + c] : 0;
+        const int32_t* rm = rowmap.data() + w * RW;
+        std::vector<int64_t> cursor((size_t)RW), seg_lo((size_t)G), seg_n((size_t)G),
+            seg_step((size_t)G);
+        for (int c = 0; c < RW; ++c) cursor[(size_t)c] = rm[c] >= 0 ? ptr[vrow_row[(size_t)rm[c]]] : 0;
         int32_t* bw = bnd.data() + w * per_wave;
         int64_t rel = 0;
         for (int sl = 0; sl < t.n_slab; ++sl) {
@@ -278,27 +328,35 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
                 bw[(int64_t)sl * NR + r] = (int32_t)rel;
                 int64_t longest = 0;
                 for (int g = 0; g < G; ++g) {
-                    const int64_t row = r0 + (int64_t)r * G + g;
-                    int64_t lo = 0, hi = 0;
-                    if (row < o.n_rows) {
-                        lo = hi = cursor[(size_t)(r * G + g)];
-                        const int64_t stop = ptr[row + 1];
+                    const int32_t v = rm[r * G + g];
+                    int64_t lo = 0, n = 0, step = 1;
+                    if (v >= 0) {
+                        const int32_t row = vrow_row[(size_t)v];
+                        int64_t hi = cursor[(size_t)(r * G + g)];
+                        const int64_t seg = hi, stop = ptr[row + 1];
                         while (hi < stop && idx[hi] < lim) ++hi;
                         cursor[(size_t)(r * G + g)] = hi;
+                        // this piece's share of the row's slab segment [seg, hi)
+                        step = vptr[(size_t)row + 1] - vptr[(size_t)row];
+                        const int64_t off = ((int64_t)(v - vptr[(size_t)row]) + sl) % step;
+                        lo = seg + off;
+                        n = hi - seg > off ? (hi - seg - off + step - 1) / step : 0;
                     }
                     seg_lo[(size_t)g] = lo;
-                    seg_hi[(size_t)g] = hi;
-                    longest = std::max(longest, hi - lo);
+                    seg_n[(size_t)g] = n;
+                    seg_step[(size_t)g] = step;
+                    longest = std::max(longest, n);
                 }
                 longest = (longest + U - 1) / U * U;
                 if (dst)
                     for (int64_t j = 0; j < longest; ++j)
                         for (int g = 0; g < G; ++g) {
-                            const int64_t e = seg_lo[(size_t)g] + j;
                             uint32_t word = 0u;  // padding: index 0, ad = dp = 0
-                            if (e < seg_hi[(size_t)g])
+                            if (j < seg_n[(size_t)g]) {
+                                const int64_t e = seg_lo[(size_t)g] + j * seg_step[(size_t)g];
                                 word = ((uint32_t)(idx[e] - base) << 22) |
                                        ((uint32_t)val[e].x << 11) | (uint32_t)val[e].y;
+                            }
                             dst[rel + j * G + g] = word;
                         }
                 rel += longest * G;  // (a multiple of 64 words: streams stay 16-B aligned)
@@ -314,10 +372,19 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
         vrx_set_error("tiled stream: wave stream >= 2^31 words");
         return VRX_ERR_UNSUPPORTED;
     }
-    int64_t total = 0;
+    int64_t total = 0, longest_wave = 0;
     for (int64_t w = 0; w < n_wave; ++w) {
         wave_start[(size_t)w] = total;
         total += wave_len[(size_t)w];
+        longest_wave = std::max(longest_wave, wave_len[(size_t)w]);
+    }
+    // Guard: past VIREO_LDS_MAX_PAD stream words per entry (default 3; padding x imbalance of
+    // the slowest wave) the global-gather pass is the faster one, so no stream is kept.
+    t.pad_ratio = o.nnz > 0 ? (double)total / (double)o.nnz : 0.0;
+    t.imbalance = total > 0 ? (double)longest_wave * (double)n_wave / (double)total : 1.0;
+    if (guard && t.pad_ratio * std::max(1.0, t.imbalance / 1.5) > (double)env_int("VIREO_LDS_MAX_PAD", 3)) {
+        t.ready = false;
+        return VRX_OK;
     }
     ent.assign((size_t)total, 0u);
     parallel_chunks(n_wave, host_threads(), [&](int64_t b0, int64_t e0, int) {
@@ -327,6 +394,8 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
     VRX_HIP(t.ent.upload(ent.data(), ent.size(), s));
     VRX_HIP(t.wave_start.upload(wave_start.data(), wave_start.size(), s));
     VRX_HIP(t.bnd.upload(bnd.data(), bnd.size(), s));
+    VRX_HIP(t.rowmap.upload(rowmap.data(), rowmap.size(), s));
+    if (t.split) VRX_HIP(t.vptr.upload(vptr.data(), vptr.size(), s));
     VRX_HIP(hipStreamSynchronize(s));
     t.ready = true;
     return VRX_OK;
@@ -462,10 +531,11 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
     if (max_count < 2048 &&
         (lds == 1 || (lds != 0 && nnz >= (int64_t)env_int("VIREO_LDS_MIN_NNZ", 4000000)))) {
         // cell pass: slabs of 512 W rows (128 KiB at K = 16); variant pass: 1024 ID rows
-        rc = build_tiled(p->by_cell, colptr, rowidx, cval.data(), VRX_LDS_RW_CELL, 512, p->stream);
+        rc = build_tiled(p->by_cell, colptr, rowidx, cval.data(), VRX_LDS_RW_CELL, 512, lds != 1,
+                         p->stream);
         if (rc) return rc;
         rc = build_tiled(p->by_var, rptr.data(), ridx.data(), rval.data(), VRX_LDS_RW_VARIANT, 1024,
-                         p->stream);
+                         lds != 1, p->stream);
         if (rc) return rc;
     }
     *out = p.release();
@@ -642,10 +712,13 @@ extern "C" int vrx_model_create(vrx_problem* p, const vrx_model_cfg* cfg, vrx_mo
     VRX_HIP(m->W.alloc((size_t)m->NK * 2));
     VRX_HIP(m->PV.alloc((size_t)(p->by_var.n_slots * m->K * 2)));
     VRX_HIP(m->PC.alloc((size_t)(p->by_cell.n_slots * m->K)));
-    if (lds_eligible<0>(p->by_var, m->K) && p->by_var.tiled.n_range > 1)
-        VRX_HIP(m->RV.alloc((size_t)(p->by_var.tiled.n_range * m->NK * 2)));
-    if (lds_eligible<1>(p->by_cell, m->K) && p->by_cell.tiled.n_range > 1)
-        VRX_HIP(m->RC.alloc((size_t)(p->by_cell.tiled.n_range * m->M * m->K)));
+    {
+        const TiledStream &tv = p->by_var.tiled, &tc = p->by_cell.tiled;
+        if (lds_eligible<0>(p->by_var, m->K) && (tv.n_range > 1 || tv.split))
+            VRX_HIP(m->RV.alloc((size_t)(tv.n_range * tv.n_vrows * m->K * 2)));
+        if (lds_eligible<1>(p->by_cell, m->K) && (tc.n_range > 1 || tc.split))
+            VRX_HIP(m->RC.alloc((size_t)(tc.n_range * tc.n_vrows * m->K)));
+    }
     // rows without entries are never written by the passes: zero once
     VRX_HIP(hipMemsetAsync(m->S.p, 0, (size_t)m->NK * 2 * sizeof(double), s));
     VRX_HIP(hipMemsetAsync(m->LID.p, 0, (size_t)(m->M * m->K) * sizeof(double), s));
@@ -844,8 +917,8 @@ static int launch_lds_one(const Orient& o, hipStream_t s, const double* X, int K
     auto kern = vrx_spmm_lds<LPE, MODE, MODE == 1 ? VRX_LDS_RW_CELL : VRX_LDS_RW_VARIANT>;
     VRX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    kern<<<grid, 1024, lds, s>>>(t.ent.p, t.wave_start.p, t.bnd.p, t.n_slab, t.slab_rows,
-                                 o.n_contract, o.n_rows, X, K, dst);
+    kern<<<grid, 1024, lds, s>>>(t.ent.p, t.wave_start.p, t.bnd.p, t.rowmap.p, t.n_slab,
+                                 t.slab_rows, o.n_contract, t.n_vrows, X, K, dst);
     VRX_HIP(hipGetLastError());
     return VRX_OK;
 }
@@ -856,11 +929,16 @@ static int launch_spmm_lds(vrx_model* m, const Orient& o, const double* X, int K
     hipStream_t s = m->p->stream;
     const TiledStream& t = o.tiled;
     constexpr int NV = MODE == 0 ? 2 : 1;
-    double* dst = t.n_range == 1 ? out : range_partial;
+    double* dst = t.n_range == 1 && !t.split ? out : range_partial;
     int rc;
     rc = launch_lds_one<VRX_LDS_LPE, MODE>(o, s, X, K, dst);  // K < 16 leaves lanes idle
     if (rc) return rc;
-    if (t.n_range > 1 && !defer_sum) {
+    if (t.split) {  // rows cut into pieces: sum pieces and ranges in one fixed order
+        const int64_t n = o.n_rows * K * NV;
+        vrx_sum_pieces<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
+            o.n_rows, K * NV, t.n_range, t.n_vrows, t.vptr.p, range_partial, out);
+        VRX_HIP(hipGetLastError());
+    } else if (t.n_range > 1 && !defer_sum) {
         const int64_t n = o.n_rows * K * NV;
         vrx_sum_ranges<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
             n, t.n_range, range_partial, out);
@@ -912,7 +990,7 @@ static int launch_spmm(vrx_model* m, const Orient& o, const double* X, int K, do
 static int variant_pass(vrx_model* m, bool defer_sum = false) {
     ProfScope ps(m, VRX_KERN_VARIANT_PASS);
     if (lds_eligible<0>(m->p->by_var, m->K)) {
-        m->s_pending = defer_sum && m->p->by_var.tiled.n_range > 1;
+        m->s_pending = defer_sum && m->p->by_var.tiled.n_range > 1 && !m->p->by_var.tiled.split;
         return launch_spmm_lds<0>(m, m->p->by_var, m->ID.p, m->K, m->S.p, m->RV.p, defer_sum);
     }
     return launch_spmm<0>(m, m->p->by_var, m->ID.p, m->K, m->S.p, m->PV.p);
@@ -922,7 +1000,7 @@ static int variant_pass(vrx_model* m, bool defer_sum = false) {
 static int cell_pass(vrx_model* m, bool defer_sum = false) {
     ProfScope ps(m, VRX_KERN_CELL_PASS);
     if (lds_eligible<1>(m->p->by_cell, m->K)) {
-        m->l_pending = defer_sum && m->p->by_cell.tiled.n_range > 1;
+        m->l_pending = defer_sum && m->p->by_cell.tiled.n_range > 1 && !m->p->by_cell.tiled.split;
         return launch_spmm_lds<1>(m, m->p->by_cell, m->W.p, m->K, m->LID.p, m->RC.p, defer_sum);
     }
     return launch_spmm<1>(m, m->p->by_cell, m->W.p, m->K, m->LID.p, m->PC.p);
@@ -1207,6 +1285,10 @@ extern "C" int vrx_model_info(vrx_model* m, int32_t* info) {
     info[5] = c.n_tiles;
     info[6] = v.tiled.ready ? v.tiled.n_range : 0;
     info[7] = c.tiled.ready ? c.tiled.n_range : 0;
+    info[8] = v.tiled.ready ? (int32_t)(v.tiled.pad_ratio * 1000.0 + 0.5) : 0;
+    info[9] = c.tiled.ready ? (int32_t)(c.tiled.pad_ratio * 1000.0 + 0.5) : 0;
+    info[10] = v.tiled.ready ? (int32_t)(v.tiled.n_vrows - v.n_rows) : 0;
+    info[11] = c.tiled.ready ? (int32_t)(c.tiled.n_vrows - c.n_rows) : 0;
     return VRX_OK;
 }
 

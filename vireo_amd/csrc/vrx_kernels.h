@@ -302,8 +302,9 @@ constexpr int VRX_LDS_U = VRX_LDS_U_DEF;    // entries per trip and group; rows 
 template <int LPE, int MODE, int RW>
 __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     const uint32_t* __restrict__ ent, const int64_t* __restrict__ wave_start,
-    const int32_t* __restrict__ bnd, int n_slab, int slab_rows, int64_t n_contract,
-    int64_t n_rows, const double* __restrict__ X, int K, double* __restrict__ out) {
+    const int32_t* __restrict__ bnd, const int32_t* __restrict__ rowmap, int n_slab,
+    int slab_rows, int64_t n_contract, int64_t n_rows, const double* __restrict__ X, int K,
+    double* __restrict__ out) {
     constexpr int G = 64 / LPE;            // rows per round
     constexpr int NR = RW / G;             // rounds
     constexpr int XD = MODE == 1 ? 2 : 1;  // doubles per (contracted row, column)
@@ -430,8 +431,8 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     if (kok) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            const int64_t row = ((int64_t)tile * 16 + wave) * RW + r * G + g;
-            if (row < n_rows) {
+            const int64_t row = rowmap[((int64_t)tile * 16 + wave) * RW + r * G + g];
+            if (row >= 0) {  // tile position -> row (rows are dealt to rounds by length)
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     const int slice = kl * NQ + (q + g) % NQ;  // 16-B slice of the dense row
@@ -446,6 +447,21 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
             }
         }
     }
+}
+
+// out[row][c] = sum over ranges (outer) and the row's pieces (inner), fixed order
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_pieces(
+    int64_t n_rows, int width, int n_range, int64_t n_vrows, const int32_t* __restrict__ vptr,
+    const double* __restrict__ partial, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    if (i >= n_rows * width) return;
+    const int64_t row = i / width;
+    const int c = (int)(i - row * width);
+    const int v0 = vptr[row], v1 = vptr[row + 1];
+    double s = 0.0;
+    for (int r = 0; r < n_range; ++r)
+        for (int v = v0; v < v1; ++v) s += partial[((int64_t)r * n_vrows + v) * width + c];
+    out[i] = s;
 }
 
 // partial[range][...] summed over the contracted ranges in order

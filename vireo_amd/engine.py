@@ -123,11 +123,13 @@ class DeviceModel:
 
     def info(self):
         """which kernels / formats / tilings this model's passes use (vrx_model_info)"""
-        a = np.zeros(8, dtype=np.int32)
+        a = np.zeros(12, dtype=np.int32)
         _lib.check(_lib.lib().vrx_model_info(self._h, a.ctypes.data_as(C.POINTER(C.c_int32))))
         return dict(lds_variant=bool(a[0]), lds_cell=bool(a[1]), fmt_variant=int(a[2]),
                     fmt_cell=int(a[3]), tiles_variant=int(a[4]), tiles_cell=int(a[5]),
-                    ranges_variant=int(a[6]), ranges_cell=int(a[7]))
+                    ranges_variant=int(a[6]), ranges_cell=int(a[7]),
+                    pad_variant=a[8] / 1000.0, pad_cell=a[9] / 1000.0,
+                    extra_pieces_variant=int(a[10]), extra_pieces_cell=int(a[11]))
 
     # ---- timing -----------------------------------------------------------------------
     def profile(self, enable=True):

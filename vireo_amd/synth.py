@@ -20,13 +20,28 @@ CONFIGS = {
 }
 
 
-def donor_workload(N, M, K, density, seed=0):
+def _skewed_draw(rng, n, size, sigma):
+    """indices in [0, n) with log-normal(sigma) weights: heavy-tailed coverage / depth"""
+    w = rng.lognormal(0.0, sigma, n)
+    cdf = np.cumsum(w)
+    cdf /= cdf[-1]
+    return np.minimum(np.searchsorted(cdf, rng.random(size)), n - 1)
+
+
+def donor_workload(N, M, K, density, seed=0, skew=None):
     """-> dict(shape, colptr int64, rowidx int32, ad int32, dp int32) on DP's pattern
-    (duplicate (row, col) draws summed)."""
+    (duplicate (row, col) draws summed).  skew=(sigma_variant, sigma_cell) replaces the
+    uniform (variant, cell) draws of the 8(d) generator by log-normal weighted ones (real
+    scRNA-seq data: per-variant coverage and per-cell depth are heavy-tailed); it is a
+    robustness workload, not a BASELINE.json configuration."""
     rng = np.random.default_rng(seed)
     nnz_t = int(N * M * density)
-    r = rng.integers(0, N, nnz_t)
-    c = rng.integers(0, M, nnz_t)
+    if skew is None:
+        r = rng.integers(0, N, nnz_t)
+        c = rng.integers(0, M, nnz_t)
+    else:
+        r = _skewed_draw(rng, N, nnz_t, skew[0])
+        c = _skewed_draw(rng, M, nnz_t, skew[1])
     dp = 1 + rng.poisson(1.0, nnz_t)
     GT = rng.integers(0, 3, (N, K))
     z = rng.integers(0, K, M)
