@@ -1,0 +1,39 @@
+"""A/B timing of library variants (scratch/lib_*.so) at c3: per-pass ms.
+usage: ab_bench.py default scratch/libA.so scratch/libB.so ..."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+if len(sys.argv) > 1 and sys.argv[1] == "child":
+    import numpy as np
+    from vireo_amd import _lib, synth
+    from vireo_amd.counts import DeviceCounts
+    from vireo_amd.engine import DeviceModel
+    from vireo_amd.vireo_model import Vireo
+    N, M, K, d = synth.CONFIGS[os.environ.get("AB_CONFIG", "c3")]
+    w = synth.donor_workload(N, M, K, d, seed=0)
+    counts = DeviceCounts.from_merged(w["shape"], w["colptr"], w["rowidx"], w["ad"], w["dp"], device=0)
+    np.random.seed(1)
+    host = Vireo(n_var=N, n_cell=M, n_donor=K)
+    dm = DeviceModel(counts, _lib.KIND_VIREO, K, n_gt=3)
+    dm.set_state(host.ID_prob, host.GT_prob, host.beta_mu, host.beta_sum)
+    dm.set_prior(host.ID_prior, host.GT_prior, host.theta_s1_prior, host.theta_s2_prior)
+    dm.run_iters(3, theta_from_iter=10 ** 9)
+    tr, ms = dm.run_iters(20, theta_from_iter=0)
+    dm.profile(True)
+    dm.run_iters(10, theta_from_iter=0)
+    pm, n = dm.profile_read()
+    print(json.dumps(dict(ms_iter=round(ms / 20, 4), variant=round(pm[0] / max(n[0], 1), 4),
+                          cell=round(pm[1] / max(n[1], 1), 4), dense=round(pm[2] / 10, 4),
+                          elbo=float(tr[-1]))))
+else:
+    for lib in sys.argv[1:]:
+        e = dict(os.environ)
+        if lib != "default":
+            e["VIREO_LIB"] = os.path.join(ROOT, lib)
+        out = subprocess.run([sys.executable, __file__, "child"], env=e, capture_output=True, text=True)
+        print(lib, out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-1500:],
+              flush=True)

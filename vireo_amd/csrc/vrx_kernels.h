@@ -330,10 +330,12 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     const int32_t* bw = bnd + wid * ((int64_t)n_slab * NR + 1);
     const uint32_t* stream = ent + wave_start[wid];
     // byte offset, inside a dense row, of the q-th 16-B slice this lane reads (rotated by g)
-    int qoff[NQ];
+    uint32_t qoff[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) qoff[q] = (kok ? kl : 0) * (NQ * 16) + ((q + g) % NQ) * 16;
     const int row_bytes = K * XD * 8;
+    const uint32_t* ring_g = ring + g;
+    static_assert(VRX_RING % (U * G) == 0, "a trip must not wrap the ring");
 
     double acc[NR][NQ][2];  // [round][slice][half]: cell pass (w1,w2)->1 value; variant: 2 cols x2
     double acc2[NR][NQ][2];
@@ -385,10 +387,11 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     // one entry of this group's segment: word -> 4 column slices -> FMAs
     auto entry = [&](uint32_t w, double (&a)[NQ][2], double (&a2)[NQ][2]) {
         const double ad = (double)((w >> 11) & 2047u), dp = (double)(w & 2047u);
-        const char* rowp = reinterpret_cast<const char*>(slab) + (w >> 22) * row_bytes;
+        const uint32_t idx = w >> 22;  // < 1024 and row_bytes <= 256: 24-bit multiply-add
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const double2 x = *reinterpret_cast<const double2*>(rowp + qoff[q]);
+            const double2 x = *reinterpret_cast<const double2*>(
+                reinterpret_cast<const char*>(slab) + (__umul24(idx, (uint32_t)row_bytes) + qoff[q]));
             if (MODE == 1) {  // x = (w1, w2) of one column
                 a[q][0] = fma(ad, x.x, a[q][0]);
                 a[q][0] = fma(dp, x.y, a[q][0]);
@@ -418,9 +421,12 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
             const int end = __builtin_amdgcn_readlane(bcur, r + 1);
             for (int at = base; at < end; at += U * G) {
                 if (at + U * G > staged_end) stage_chunk();  // wave-uniform, once per 256 words
+                // trips start at multiples of U*G = 64 words and the ring is a multiple of
+                // that, so a trip never wraps: one address, U constant offsets
+                const uint32_t* rp = ring_g + (at & (VRX_RING - 1));
                 uint32_t w[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) w[u] = ring[(at + u * G + g) & (VRX_RING - 1)];
+                for (int u = 0; u < U; ++u) w[u] = rp[u * G];
 #pragma unroll
                 for (int u = 0; u < U; ++u) entry(w[u], acc[r], acc2[r]);
             }
