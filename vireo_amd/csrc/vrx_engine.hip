@@ -325,7 +325,6 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
                     too_long = true;
                     return;
                 }
-                bw[(int64_t)sl * NR + r] = (int32_t)rel;
                 int64_t longest = 0;
                 for (int g = 0; g < G; ++g) {
                     const int32_t v = rm[r * G + g];
@@ -347,6 +346,8 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
                     seg_step[(size_t)g] = step;
                     longest = std::max(longest, n);
                 }
+                // offset | entries in the last trip (0 = full): the kernel skips the padding
+                bw[(int64_t)sl * NR + r] = (int32_t)(rel | (longest % U));
                 longest = (longest + U - 1) / U * U;
                 if (dst)
                     for (int64_t j = 0; j < longest; ++j)

@@ -336,6 +336,7 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     const int row_bytes = K * XD * 8;
     const uint32_t* ring_g = ring + g;
     static_assert(VRX_RING % (U * G) == 0, "a trip must not wrap the ring");
+    static_assert((U & (U - 1)) == 0 && U <= U * G, "tail count lives in the low bits of bnd");
 
     double acc[NR][NQ][2];  // [round][slice][half]: cell pass (w1,w2)->1 value; variant: 2 cols x2
     double acc2[NR][NQ][2];
@@ -368,8 +369,8 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     };
 
     // ---- entry stream: ring of 512 entries refilled 256 at a time, 2 chunks ahead ---------
-    const int stream_lo = __builtin_amdgcn_readfirstlane(bw[(int64_t)s_lo * NR]);
-    const int stream_end = __builtin_amdgcn_readfirstlane(bw[(int64_t)s_hi * NR]);
+    const int stream_lo = __builtin_amdgcn_readfirstlane(bw[(int64_t)s_lo * NR]) & ~(U * G - 1);
+    const int stream_end = __builtin_amdgcn_readfirstlane(bw[(int64_t)s_hi * NR]) & ~(U * G - 1);
     int staged_end = stream_lo;
     auto chunk_load = [&](int from) {  // entries [from + 4*lane, +4); zero beyond the stream
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -417,9 +418,13 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
         for (int r = 0; r < NR; ++r) {
             // the round's entries are stored trip-major: word (base + j*G + g) is the j-th
             // entry of the row owned by group g (zero words where that row is shorter)
-            const int base = __builtin_amdgcn_readlane(bcur, r);
-            const int end = __builtin_amdgcn_readlane(bcur, r + 1);
-            for (int at = base; at < end; at += U * G) {
+            // bnd = stream offset (a multiple of U*G) | entries in the round's last trip
+            // (0 = a full trip): the zero words that pad the last trip are not executed
+            const int braw = __builtin_amdgcn_readlane(bcur, r);
+            const int base = braw & ~(U * G - 1), tail = braw & (U - 1);
+            const int end = __builtin_amdgcn_readlane(bcur, r + 1) & ~(U * G - 1);
+            const int full_end = tail ? end - U * G : end;
+            for (int at = base; at < full_end; at += U * G) {
                 if (at + U * G > staged_end) stage_chunk();  // wave-uniform, once per 256 words
                 // trips start at multiples of U*G = 64 words and the ring is a multiple of
                 // that, so a trip never wraps: one address, U constant offsets
@@ -429,6 +434,16 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
                 for (int u = 0; u < U; ++u) w[u] = rp[u * G];
 #pragma unroll
                 for (int u = 0; u < U; ++u) entry(w[u], acc[r], acc2[r]);
+            }
+            if (tail) {
+                if (full_end + U * G > staged_end) stage_chunk();
+                const uint32_t* rp = ring_g + (full_end & (VRX_RING - 1));
+                uint32_t w[U];
+#pragma unroll
+                for (int u = 0; u < U - 1; ++u) w[u] = rp[u * G];
+#pragma unroll
+                for (int u = 0; u < U - 1; ++u)
+                    if (u < tail) entry(w[u], acc[r], acc2[r]);
             }
         }
     }
