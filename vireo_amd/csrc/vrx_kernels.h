@@ -276,7 +276,8 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_spmm(
 //   * entries are one 32-bit word each (slab-local index:10 | ad:11 | dp:11), stored in
 //     tiled order (tile, wave, slab, round) and TRIP-MAJOR inside a round: word j*G + g is
 //     the j-th entry of group g's row, zero words padding every row to the round's longest
-//     (rounded up to 2).  Every wave thus reads ONE contiguous stream in lock-step with its
+//     (the stream is rounded up to whole trips of U entries per row; the zero words of the
+//     last trip are skipped).  Every wave thus reads ONE contiguous stream in lock-step with its
 //     compute, staged through a 512-word LDS ring in 256-word chunks prefetched two chunks
 //     ahead; bnd[] holds, per wave, the stream offset of every (slab, round).  With ~10
 //     entries per row and slab the padding costs ~1.7 slots per entry, which the 4x lower
