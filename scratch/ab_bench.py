@@ -14,6 +14,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     from vireo_amd.engine import DeviceModel
     from vireo_amd.vireo_model import Vireo
     N, M, K, d = synth.CONFIGS[os.environ.get("AB_CONFIG", "c3")]
+    K = int(os.environ.get("AB_K", K))
     w = synth.donor_workload(N, M, K, d, seed=0)
     counts = DeviceCounts.from_merged(w["shape"], w["colptr"], w["rowidx"], w["ad"], w["dp"], device=0)
     np.random.seed(1)

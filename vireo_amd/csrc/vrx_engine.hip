@@ -902,20 +902,22 @@ static void launch_spmm_fmt(const Orient& o, dim3 grid, hipStream_t s, const dou
 #undef VRX_GO
 }
 
-// LDS-resident pass: K a multiple of 4 up to 16 (4 columns per lane), counts < 2048 (checked
-// when the tiled stream is built)
+// LDS-resident pass: K <= 16 (4 columns per lane, the dense rows zero-padded to a multiple of
+// 4 columns in LDS), counts < 2048 (checked when the tiled stream is built)
 template <int MODE>
 static bool lds_eligible(const Orient& o, int K) {
     static const int mask = env_int("VIREO_LDS_PASS", 3);  // bit 0: variant pass, bit 1: cell pass
-    return o.tiled.ready && (mask >> MODE & 1) && K <= 16 && K % (16 / VRX_LDS_LPE) == 0;
+    static const int kmin = env_int("VIREO_LDS_MIN_K", 3);  // K = 2: the gather kernels win
+    return o.tiled.ready && (mask >> MODE & 1) && K <= 16 && K >= kmin;
 }
 
 template <int LPE, int MODE>
 static int launch_lds_one(const Orient& o, hipStream_t s, const double* X, int K, double* dst) {
     const TiledStream& t = o.tiled;
-    const size_t lds = (size_t)t.slab_rows * K * (MODE == 1 ? 16 : 8) + 16 * VRX_RING * 4;
+    const size_t lds = (size_t)t.slab_rows * ((K + 3) & ~3) * (MODE == 1 ? 16 : 8) + 16 * VRX_RING * 4;
     dim3 grid((unsigned)t.n_tile, (unsigned)t.n_range);
-    auto kern = vrx_spmm_lds<LPE, MODE, MODE == 1 ? VRX_LDS_RW_CELL : VRX_LDS_RW_VARIANT>;
+    constexpr int RW = MODE == 1 ? VRX_LDS_RW_CELL : VRX_LDS_RW_VARIANT;
+    auto kern = K % 4 ? vrx_spmm_lds<LPE, MODE, RW, true> : vrx_spmm_lds<LPE, MODE, RW, false>;
     VRX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     kern<<<grid, 1024, lds, s>>>(t.ent.p, t.wave_start.p, t.bnd.p, t.rowmap.p, t.n_slab,

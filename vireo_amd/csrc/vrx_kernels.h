@@ -259,7 +259,7 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_spmm(
 }
 
 // ------------------------------------------------------------------------------------
-// LDS-resident variant of the sparse passes (large problems, K in {4,8,12,16}, counts < 2048)
+// LDS-resident variant of the sparse passes (large problems, K <= 16, counts < 2048)
 // ------------------------------------------------------------------------------------
 // The global-gather kernel above is bound by the L1-miss path: every non-zero pulls one or
 // two 128-B lines through the vector cache.  Here the dense operand is streamed through
@@ -300,7 +300,8 @@ constexpr int VRX_LDS_RW_VARIANT = VRX_LDS_RWV_DEF, VRX_LDS_RW_CELL = VRX_LDS_RW
 constexpr int VRX_LDS_LPE = VRX_LDS_LPE_DEF;  // lanes per output row (16 / this columns per lane)
 constexpr int VRX_LDS_U = VRX_LDS_U_DEF;    // entries per trip and group; rows are padded to it
 
-template <int LPE, int MODE, int RW>
+// PADK: K is not a multiple of 4 (the slab is staged element-wise into zero-padded rows)
+template <int LPE, int MODE, int RW, bool PADK>
 __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     const uint32_t* __restrict__ ent, const int64_t* __restrict__ wave_start,
     const int32_t* __restrict__ bnd, const int32_t* __restrict__ rowmap, int n_slab,
@@ -318,7 +319,8 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     extern __shared__ __attribute__((aligned(16))) char vrx_smem[];
     double* slab = reinterpret_cast<double*>(vrx_smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int slab_doubles = slab_rows * K * XD;
+    const int KP = (K + 3) & ~3;  // LDS rows are padded to a multiple of 4 columns (zeros)
+    const int slab_doubles = slab_rows * KP * XD;
     uint32_t* ring = reinterpret_cast<uint32_t*>(slab + slab_doubles) + wave * VRX_RING;
     const int tile = blockIdx.x;
     // contracted range of this workgroup: slabs split as evenly as possible over gridDim.y
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     const int s_hi = (int)((int64_t)(blockIdx.y + 1) * n_slab / gridDim.y);
     if (s_lo >= s_hi) return;
     const int g = lane / LPE, kl = lane % LPE;
-    const bool kok = kl * CP < K;  // K is a multiple of 4; a lane's columns may run past K
+    const bool kok = kl * CP < K;  // a lane's 4 columns may start (or run) past K
     const int64_t wid = (int64_t)tile * 16 + wave;
     const int32_t* bw = bnd + wid * ((int64_t)n_slab * NR + 1);
     const uint32_t* stream = ent + wave_start[wid];
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     uint32_t qoff[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) qoff[q] = (kok ? kl : 0) * (NQ * 16) + ((q + g) % NQ) * 16;
-    const int row_bytes = K * XD * 8;
+    const int row_bytes = KP * XD * 8;
     const uint32_t* ring_g = ring + g;
     static_assert(VRX_RING % (U * G) == 0, "a trip must not wrap the ring");
     static_assert((U & (U - 1)) == 0 && U <= U * G, "tail count lives in the low bits of bnd");
@@ -347,25 +349,58 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
         for (int q = 0; q < NQ; ++q) acc[r][q][0] = acc[r][q][1] = acc2[r][q][0] = acc2[r][q][1] = 0.0;
 
     // ---- slab prefetch (global -> registers), one slab ahead ---------------------------
+    // PADK: K columns become KP columns per LDS row (zero filled).  Thread t stages the 16-B
+    // unit j0 = t % upr of rows r0 + i*rstep (t below the largest multiple T of upr), so the
+    // unit's column never changes and nothing is divided inside the loop.
     double2 pf[PF];
+    const int upr = KP * XD / 2;  // 16-B units per LDS row
+    const int padT = 1024 / upr * upr, j0 = threadIdx.x % upr, r0 = threadIdx.x / upr;
+    const int rstep = padT / upr;
+    const bool pad_act = (int)threadIdx.x < padT;
     auto slab_fetch = [&](int s) {
         const int64_t row0 = (int64_t)s * slab_rows;
         const int64_t rows = min((int64_t)slab_rows, n_contract - row0);
-        const int n16 = (int)(rows * K * XD / 2);
-        const double2* src = reinterpret_cast<const double2*>(X + row0 * K * XD);
+        if (!PADK) {  // rows are contiguous 16-B units: flat copy
+            const int n16 = (int)(rows * K * XD / 2);
+            const double2* src = reinterpret_cast<const double2*>(X + row0 * K * XD);
 #pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            const int at = threadIdx.x + i * 1024;
-            pf[i] = at < n16 ? src[at] : make_double2(0.0, 0.0);
+            for (int i = 0; i < PF; ++i) {
+                const int at = threadIdx.x + i * 1024;
+                pf[i] = at < n16 ? src[at] : make_double2(0.0, 0.0);
+            }
+        } else {
+            const double* src = X + row0 * K * XD;
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const int row = r0 + i * rstep;
+                double2 v = make_double2(0.0, 0.0);
+                if (pad_act && row < rows) {
+                    if (MODE == 1) {  // unit j0 = (w1, w2) of column j0
+                        if (j0 < K) v = reinterpret_cast<const double2*>(src)[row * K + j0];
+                    } else {  // unit j0 = columns 2*j0, 2*j0 + 1
+                        if (2 * j0 < K) v.x = src[row * K + 2 * j0];
+                        if (2 * j0 + 1 < K) v.y = src[row * K + 2 * j0 + 1];
+                    }
+                }
+                pf[i] = v;
+            }
         }
     };
     auto slab_store = [&]() {
         double2* dst = reinterpret_cast<double2*>(slab);
-        const int n16 = slab_doubles / 2;
+        if (!PADK) {
+            const int n16 = slab_doubles / 2;
 #pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            const int at = threadIdx.x + i * 1024;
-            if (at < n16) dst[at] = pf[i];
+            for (int i = 0; i < PF; ++i) {
+                const int at = threadIdx.x + i * 1024;
+                if (at < n16) dst[at] = pf[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const int row = r0 + i * rstep;
+                if (pad_act && row < slab_rows) dst[row * upr + j0] = pf[i];
+            }
         }
     };
 
@@ -459,11 +494,13 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
                 for (int q = 0; q < NQ; ++q) {
                     const int slice = kl * NQ + (q + g) % NQ;  // 16-B slice of the dense row
                     if (MODE == 1) {
-                        dst[row * K + slice] = acc[r][q][0];
+                        if (!PADK || slice < K) dst[row * K + slice] = acc[r][q][0];
                     } else {  // columns 2*slice, 2*slice+1; S[row][k] = (s1, ss)
                         double2* o = reinterpret_cast<double2*>(dst) + row * K + 2 * slice;
-                        o[0] = make_double2(acc[r][q][0], acc2[r][q][0]);
-                        o[1] = make_double2(acc[r][q][1], acc2[r][q][1]);
+                        if (!PADK || 2 * slice < K)
+                            o[0] = make_double2(acc[r][q][0], acc2[r][q][0]);
+                        if (!PADK || 2 * slice + 1 < K)
+                            o[1] = make_double2(acc[r][q][1], acc2[r][q][1]);
                     }
                 }
             }
