@@ -330,8 +330,9 @@ def test_entry_formats_and_tiling_vs_oracle(va, monkeypatch, fmt, tiles_c, tiles
 @pytest.mark.parametrize("fmt,blocks,sort", [(0, 2048, 1), (1, 1, 1), (2, 40, 1), (0, 40, 0)])
 def test_lds_resident_passes_vs_oracle(va, monkeypatch, fmt, blocks, sort):
     """the LDS-resident (two-dimensionally tiled) passes, forced on a small ragged problem:
-    one or many contracted ranges, K = 16 / 12 / 8 / 4 (4, 3, 2 and 1 active lanes per row)
-    and K = 9 / 6 / 3 / 15 (dense rows zero-padded to 12 / 8 / 4 / 16 columns in LDS).  The long
+    one or many contracted ranges, K = 16 / 12 (4 / 3 lanes per entry), K = 8 / 4 (2 / 4 entries of
+    a row at once on 2 / 1 lanes each) and K = 9 / 6 / 3 / 15 / 2 (dense rows zero-padded to
+    12 / 8 / 4 / 16 / 4 columns in LDS).  The long
     variant / cell of the ragged case are cut into interleaved pieces (sort=1) or kept whole
     in natural row order (sort=0)."""
     from vireo_amd import _lib
@@ -346,7 +347,7 @@ def test_lds_resident_passes_vs_oracle(va, monkeypatch, fmt, blocks, sort):
     info = DeviceModel(counts, _lib.KIND_VIREO, 16).info()
     assert info["lds_cell"] and info["lds_variant"]
     assert (info["extra_pieces_cell"] > 0) == (info["extra_pieces_variant"] > 0) == bool(sort)
-    for K in (16, 12, 8, 4, 9, 6, 3, 15):
+    for K in (16, 12, 8, 4, 9, 6, 3, 15, 2):
         np.random.seed(11)
         ref = O.vireo_new(AD.shape[1], AD.shape[0], K)
         np.random.seed(11)

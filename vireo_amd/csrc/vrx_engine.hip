@@ -907,8 +907,22 @@ static void launch_spmm_fmt(const Orient& o, dim3 grid, hipStream_t s, const dou
 template <int MODE>
 static bool lds_eligible(const Orient& o, int K) {
     static const int mask = env_int("VIREO_LDS_PASS", 3);  // bit 0: variant pass, bit 1: cell pass
-    static const int kmin = env_int("VIREO_LDS_MIN_K", 3);  // K = 2: the gather kernels win
+    static const int kmin = env_int("VIREO_LDS_MIN_K", 2);
     return o.tiled.ready && (mask >> MODE & 1) && K <= 16 && K >= kmin;
+}
+
+// kernel instance for K: zero-padded rows when K % 4, 2 / 4 entries at once when K <= 8 / 4
+template <int LPE, int MODE>
+static auto lds_kernel(int K) {
+    constexpr int RW = MODE == 1 ? VRX_LDS_RW_CELL : VRX_LDS_RW_VARIANT;
+    static const int split_on = env_int("VIREO_LDS_SPLIT_K", 1);
+    const int split = !split_on ? 1 : K <= 4 ? 4 : K <= 8 ? 2 : 1;
+    const bool pad = K % 4 != 0;
+    if (split == 4)
+        return pad ? vrx_spmm_lds<LPE, MODE, RW, true, 4> : vrx_spmm_lds<LPE, MODE, RW, false, 4>;
+    if (split == 2)
+        return pad ? vrx_spmm_lds<LPE, MODE, RW, true, 2> : vrx_spmm_lds<LPE, MODE, RW, false, 2>;
+    return pad ? vrx_spmm_lds<LPE, MODE, RW, true, 1> : vrx_spmm_lds<LPE, MODE, RW, false, 1>;
 }
 
 template <int LPE, int MODE>
@@ -916,8 +930,7 @@ static int launch_lds_one(const Orient& o, hipStream_t s, const double* X, int K
     const TiledStream& t = o.tiled;
     const size_t lds = (size_t)t.slab_rows * ((K + 3) & ~3) * (MODE == 1 ? 16 : 8) + 16 * VRX_RING * 4;
     dim3 grid((unsigned)t.n_tile, (unsigned)t.n_range);
-    constexpr int RW = MODE == 1 ? VRX_LDS_RW_CELL : VRX_LDS_RW_VARIANT;
-    auto kern = K % 4 ? vrx_spmm_lds<LPE, MODE, RW, true> : vrx_spmm_lds<LPE, MODE, RW, false>;
+    auto kern = lds_kernel<LPE, MODE>(K);
     VRX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     kern<<<grid, 1024, lds, s>>>(t.ent.p, t.wave_start.p, t.bnd.p, t.rowmap.p, t.n_slab,

@@ -300,8 +300,11 @@ constexpr int VRX_LDS_RW_VARIANT = VRX_LDS_RWV_DEF, VRX_LDS_RW_CELL = VRX_LDS_RW
 constexpr int VRX_LDS_LPE = VRX_LDS_LPE_DEF;  // lanes per output row (16 / this columns per lane)
 constexpr int VRX_LDS_U = VRX_LDS_U_DEF;    // entries per trip and group; rows are padded to it
 
-// PADK: K is not a multiple of 4 (the slab is staged element-wise into zero-padded rows)
-template <int LPE, int MODE, int RW, bool PADK>
+// PADK: K is not a multiple of 4 (the slab is staged element-wise into zero-padded rows).
+// SPLIT: with K <= 8 (<= 4) a row needs only 2 (1) of the group's 4 lanes, so the group's lanes
+// take SPLIT = 2 (4) consecutive entries of the row at once, each into its own partial sums;
+// the partial sums are added across the lanes once, after the last slab (fixed order).
+template <int LPE, int MODE, int RW, bool PADK, int SPLIT>
 __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     const uint32_t* __restrict__ ent, const int64_t* __restrict__ wave_start,
     const int32_t* __restrict__ bnd, const int32_t* __restrict__ rowmap, int n_slab,
@@ -327,7 +330,10 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     const int s_lo = (int)((int64_t)blockIdx.y * n_slab / gridDim.y);
     const int s_hi = (int)((int64_t)(blockIdx.y + 1) * n_slab / gridDim.y);
     if (s_lo >= s_hi) return;
-    const int g = lane / LPE, kl = lane % LPE;
+    constexpr int LPR = LPE / SPLIT;  // lanes per entry: they cover LPR*CP >= K columns
+    constexpr int US = U / SPLIT;     // entries per trip and lane
+    static_assert(LPE % SPLIT == 0 && U % SPLIT == 0, "split");
+    const int g = lane / LPE, sub = (lane % LPE) / LPR, kl = lane % LPR;
     const bool kok = kl * CP < K;  // a lane's 4 columns may start (or run) past K
     const int64_t wid = (int64_t)tile * 16 + wave;
     const int32_t* bw = bnd + wid * ((int64_t)n_slab * NR + 1);
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
 #pragma unroll
     for (int q = 0; q < NQ; ++q) qoff[q] = (kok ? kl : 0) * (NQ * 16) + ((q + g) % NQ) * 16;
     const int row_bytes = KP * XD * 8;
-    const uint32_t* ring_g = ring + g;
+    const uint32_t* ring_g = ring + g + sub * G;  // entries sub, sub + SPLIT, ... of a trip
     static_assert(VRX_RING % (U * G) == 0, "a trip must not wrap the ring");
     static_assert((U & (U - 1)) == 0 && U <= U * G, "tail count lives in the low bits of bnd");
 
@@ -463,29 +469,42 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
             for (int at = base; at < full_end; at += U * G) {
                 if (at + U * G > staged_end) stage_chunk();  // wave-uniform, once per 256 words
                 // trips start at multiples of U*G = 64 words and the ring is a multiple of
-                // that, so a trip never wraps: one address, U constant offsets
+                // that, so a trip never wraps: one address, constant offsets
                 const uint32_t* rp = ring_g + (at & (VRX_RING - 1));
-                uint32_t w[U];
+                uint32_t w[US];
 #pragma unroll
-                for (int u = 0; u < U; ++u) w[u] = rp[u * G];
+                for (int u = 0; u < US; ++u) w[u] = rp[u * SPLIT * G];
 #pragma unroll
-                for (int u = 0; u < U; ++u) entry(w[u], acc[r], acc2[r]);
+                for (int u = 0; u < US; ++u) entry(w[u], acc[r], acc2[r]);
             }
-            if (tail) {
+            if (tail) {  // (entries past the tail are zero words: harmless where SPLIT > 1)
                 if (full_end + U * G > staged_end) stage_chunk();
                 const uint32_t* rp = ring_g + (full_end & (VRX_RING - 1));
-                uint32_t w[U];
+                uint32_t w[US];
 #pragma unroll
-                for (int u = 0; u < U - 1; ++u) w[u] = rp[u * G];
+                for (int u = 0; u < US; ++u) w[u] = rp[u * SPLIT * G];
 #pragma unroll
-                for (int u = 0; u < U - 1; ++u)
-                    if (u < tail) entry(w[u], acc[r], acc2[r]);
+                for (int u = 0; u < US; ++u)
+                    if (u * SPLIT < tail) entry(w[u], acc[r], acc2[r]);
             }
         }
     }
     // ---- every group holds the complete sums of its rows: store them ------------------------
+    if (SPLIT > 1) {  // partial sums of the SPLIT entry streams: butterfly over the lanes
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int m = LPR; m < LPE; m <<= 1) {
+                        acc[r][q][h] += __shfl_xor(acc[r][q][h], m, 64);
+                        if (MODE == 0) acc2[r][q][h] += __shfl_xor(acc2[r][q][h], m, 64);
+                    }
+    }
     double* dst = out + (int64_t)blockIdx.y * n_rows * K * NV;
-    if (kok) {
+    if (kok && sub == 0) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int64_t row = rowmap[((int64_t)tile * 16 + wave) * RW + r * G + g];
