@@ -527,17 +527,23 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
                       tiles_v, pick_fmt(n_cell), p->stream);
     if (rc) return rc;
     // LDS-resident passes (vrx_spmm_lds) pay off on large problems (two-dimensional tiling,
-    // one 160 KiB workgroup per CU); VIREO_LDS=0/1 forces them off/on.
+    // one 160 KiB workgroup per CU); VIREO_LDS=0/1 forces them off/on.  Measured crossovers
+    // against the gather kernels (K = 8 and 16): the cell pass wins from ~4 M non-zeros; the
+    // variant pass (whose per-range partials also cost the theta kernel a wider read) only
+    // ties at 8-16 M and wins clearly at 100 M.
     const int lds = env_int("VIREO_LDS", -1);
-    if (max_count < 2048 &&
-        (lds == 1 || (lds != 0 && nnz >= (int64_t)env_int("VIREO_LDS_MIN_NNZ", 4000000)))) {
+    if (max_count < 2048 && lds != 0) {
         // cell pass: slabs of 512 W rows (128 KiB at K = 16); variant pass: 1024 ID rows
-        rc = build_tiled(p->by_cell, colptr, rowidx, cval.data(), VRX_LDS_RW_CELL, 512, lds != 1,
-                         p->stream);
-        if (rc) return rc;
-        rc = build_tiled(p->by_var, rptr.data(), ridx.data(), rval.data(), VRX_LDS_RW_VARIANT, 1024,
-                         lds != 1, p->stream);
-        if (rc) return rc;
+        if (lds == 1 || nnz >= (int64_t)env_int("VIREO_LDS_MIN_NNZ", 4000000)) {
+            rc = build_tiled(p->by_cell, colptr, rowidx, cval.data(), VRX_LDS_RW_CELL, 512,
+                             lds != 1, p->stream);
+            if (rc) return rc;
+        }
+        if (lds == 1 || nnz >= (int64_t)env_int("VIREO_LDS_MIN_NNZ_VAR", 32000000)) {
+            rc = build_tiled(p->by_var, rptr.data(), ridx.data(), rval.data(), VRX_LDS_RW_VARIANT,
+                             1024, lds != 1, p->stream);
+            if (rc) return rc;
+        }
     }
     *out = p.release();
     return VRX_OK;

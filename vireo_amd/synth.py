@@ -14,6 +14,12 @@ CONFIGS = {
     "c3": (100000, 50000, 16, 0.02),
     "mid": (50000, 20000, 16, 0.02),
     "small": (2000, 1000, 4, 0.02),
+    # crossover probes for the LDS-resident passes (nnz ~ 1 M, 2 M, 4.5 M, 8 M, 16 M)
+    "x1m": (14000, 7000, 8, 0.01),
+    "x2m": (20000, 10000, 8, 0.01),
+    "x4m": (30000, 15000, 8, 0.01),
+    "x8m": (40000, 20000, 8, 0.01),
+    "x16m": (56000, 28000, 8, 0.01),
     # locality probes (same nnz and nnz/row as c3, dense operand of ONE pass fits an XCD's L2)
     "l2c": (6250, 50000, 16, 0.32),     # W  = 1.6 MB
     "l2v": (100000, 6250, 16, 0.16),    # ID = 0.8 MB
