@@ -675,23 +675,24 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_final(int n_part, int T, 
         sh[t][1] = s;
     }
     __syncthreads();
-    if (threadIdx.x < 9 * T) {
-        const int t = threadIdx.x / 9, j = threadIdx.x % 9;
-        const double m = sh[t][0], s = sh[t][1];
-        const double s1 = m * s, s2 = (1.0 - m) * s, q1 = prior1[t], q2 = prior2[t];
-        double v;
-        switch (j) {
-            case 0: v = vrx_digamma(s1); break;
-            case 1: v = vrx_digamma(s2); break;
-            case 2: v = vrx_digamma(s1 + s2); break;
-            case 3: v = lgamma(q1); break;
-            case 4: v = lgamma(q2); break;
-            case 5: v = lgamma(q1 + q2); break;
-            case 6: v = lgamma(s1); break;
-            case 7: v = lgamma(s2); break;
-            default: v = lgamma(s1 + s2); break;
+    // wave 0 evaluates the 3*T digammas, wave 1 the 6*T log-gammas: every lane of a wave runs
+    // the SAME function (a switch over 9 functions inside one wave would run them one after
+    // the other), and the two waves run side by side
+    {
+        const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+        const int per = wv == 0 ? 3 : 6;
+        if (wv < 2 && ln < per * T) {
+            const int t = ln / per, j = ln % per;
+            const double m = sh[t][0], s = sh[t][1];
+            const double s1 = m * s, s2 = (1.0 - m) * s, q1 = prior1[t], q2 = prior2[t];
+            if (wv == 0) {
+                const double x = j == 0 ? s1 : j == 1 ? s2 : s1 + s2;
+                sf[t][j] = vrx_digamma(x);
+            } else {
+                const double x = j == 0 ? q1 : j == 1 ? q2 : j == 2 ? q1 + q2 : j == 3 ? s1 : j == 4 ? s2 : s1 + s2;
+                sf[t][3 + j] = lgamma(x);
+            }
         }
-        sf[t][j] = v;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
