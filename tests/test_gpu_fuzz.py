@@ -1,0 +1,89 @@
+"""Randomised shape / K / path sweep of the HIP hot path against the oracle (MI355X).
+
+Every case draws its own (N, M, density, count range, K, flags) from a seeded generator,
+runs a few iterations of Vireo (and every fourth case BinomMixtureVB) on the device and
+in the oracle from the same initial state, and compares iteration count, ELBO trace and
+posteriors to 1e-5 relative.  The LDS-resident passes are forced on for half of the cases
+(`VIREO_LDS=1`), so all their instantiations (K % 4 != 0 padding, 2 / 4 entries at once
+for K <= 8 / 4, row pieces, single / many contracted ranges) see odd shapes: row and slab
+counts that are not multiples of the tile sizes, empty rows, one very long row.
+"""
+import os
+
+import numpy as np
+import pytest
+from scipy.sparse import csc_matrix
+
+from oracle import vireo_oracle as O
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-5, 1e-300
+
+
+@pytest.fixture(scope="module")
+def va():
+    import vireo_amd
+    from vireo_amd import _lib
+    _lib.require_gpu()
+    return vireo_amd
+
+
+def close(a, b):
+    np.testing.assert_allclose(np.asarray(a), np.asarray(b), rtol=RTOL, atol=ATOL)
+
+
+def draw_case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.integers(40, 2600))
+    M = int(rng.integers(30, 2200))
+    dens = float(rng.choice([0.004, 0.02, 0.08, 0.3]))
+    top = int(rng.choice([3, 40, 300, 2047, 5000]))
+    K = int(rng.integers(1, 21))
+    mask = rng.random((N, M)) < dens
+    dp = mask * rng.integers(1, top + 1, (N, M))
+    if rng.random() < 0.5:                       # one long variant and one long cell
+        dp[rng.integers(N), :] = rng.integers(1, top + 1, M)
+        dp[:, rng.integers(M)] = rng.integers(1, top + 1, N)
+    if rng.random() < 0.5:                       # empty variants / cells
+        dp[rng.integers(N, size=3), :] = 0
+        dp[:, rng.integers(M, size=3)] = 0
+    ad = rng.binomial(dp, rng.choice([0.02, 0.5, 0.97], (N, 1)))
+    return csc_matrix(ad), csc_matrix(dp), K, rng
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_case_vs_oracle(va, monkeypatch, seed):
+    from vireo_amd.counts import DeviceCounts
+    AD, DP, K, rng = draw_case(seed)
+    N, M = AD.shape
+    monkeypatch.setenv("VIREO_LDS", "1" if seed % 2 else "0")
+    monkeypatch.setenv("VIREO_LDS_BLOCKS", str(int(rng.choice([1, 16, 1024]))))
+    counts = DeviceCounts(AD, DP)
+    if seed % 4 == 3:                            # clone mode (bmm_model.py)
+        K = max(K, 2)
+        np.random.seed(seed)
+        init = np.random.rand(M, K)
+        ref = O.bmm_new(M, N, K, ID_prob_init=init.copy())
+        dev = va.BinomMixtureVB(n_cell=M, n_var=N, n_donor=K, ID_prob_init=init.copy())
+        O.bmm_fit_vb(ref, AD, DP, min_iter=2, max_iter=4)
+        dev._fit_BV(AD, DP, min_iter=2, max_iter=4, verbose=False)
+        assert len(dev.ELBO_iters) == len(ref.ELBO_iters)
+        close(dev.ELBO_iters, ref.ELBO_iters)
+        close(dev.ID_prob, ref.ID_prob)
+        close(dev.beta_mu, ref.beta_mu)
+        close(dev.beta_sum, ref.beta_sum)
+        return
+    flags = dict(ASE_mode=bool(rng.random() < 0.2), fix_beta_sum=bool(rng.random() < 0.2),
+                 learn_theta=bool(rng.random() < 0.85))
+    np.random.seed(seed)
+    ref = O.vireo_new(M, N, K, **flags)
+    np.random.seed(seed)
+    dev = va.Vireo(n_cell=M, n_var=N, n_donor=K, **flags)
+    O.vireo_fit(ref, AD, DP, min_iter=2, max_iter=5, delay_fit_theta=1)
+    dev.fit(counts, None, min_iter=2, max_iter=5, delay_fit_theta=1, verbose=False)
+    assert len(dev.ELBO_) == len(ref.ELBO_)
+    close(dev.ELBO_, ref.ELBO_)
+    close(dev.ID_prob, ref.ID_prob)
+    close(dev.GT_prob, ref.GT_prob)
+    close(dev.beta_mu, ref.beta_mu)
+    close(dev.beta_sum, ref.beta_sum)
