@@ -1,6 +1,6 @@
 """mid-size (N=50k x M=20k) parity of the LDS-resident passes for odd K against the oracle."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 os.environ["VIREO_LDS"] = "1"
