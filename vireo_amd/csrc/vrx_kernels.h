@@ -278,15 +278,16 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_spmm(
 //     the j-th entry of group g's row, zero words padding every row to the round's longest
 //     (the stream is rounded up to whole trips of U entries per row; the zero words of the
 //     last trip are skipped).  Every wave thus reads ONE contiguous stream in lock-step with its
-//     compute, staged through a 512-word LDS ring in 256-word chunks prefetched two chunks
-//     ahead; bnd[] holds, per wave, the stream offset of every (slab, round).  With ~10
+//     compute, landing in a 512-word LDS ring in 256-word chunks by LDS-DMA
+//     (global_load_lds_dwordx4), one chunk ahead of the walk; bnd[] holds, per wave, the
+//     stream offset of every (slab, round).  With ~10
 //     entries per row and slab the padding costs ~1.7 slots per entry, which the 4x lower
 //     per-slot instruction count more than repays;
 //   * the 4 columns of a lane are visited in a group-dependent rotation so that the
 //     16 lanes serviced together by ds_read_b128 hit 16 different 16-B bank slots.
 // Output: one partial array per contracted range (summed in fixed order afterwards).
 constexpr int VRX_RING = 512;   // entries per wave
-constexpr int VRX_CHUNK = 256;  // entries per refill (64 lanes x dwordx4)
+constexpr int VRX_CHUNK = 256;  // entries per refill (64 lanes x 16 B of one LDS-DMA load)
 #ifndef VRX_LDS_U_DEF
 #define VRX_LDS_U_DEF 4
 #endif
@@ -320,11 +321,13 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     constexpr int U = VRX_LDS_U;           // entries per trip and group
     static_assert(RW % G == 0 && RW / G < 63, "rows per wave");
     extern __shared__ __attribute__((aligned(16))) char vrx_smem[];
-    double* slab = reinterpret_cast<double*>(vrx_smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int KP = (K + 3) & ~3;  // LDS rows are padded to a multiple of 4 columns (zeros)
     const int slab_doubles = slab_rows * KP * XD;
-    uint32_t* ring = reinterpret_cast<uint32_t*>(slab + slab_doubles) + wave * VRX_RING;
+    // LDS = [16 entry rings][slab]: the rings first, so that the LDS-DMA destinations stay
+    // below 64 KiB
+    double* slab = reinterpret_cast<double*>(vrx_smem + 16 * VRX_RING * 4);
+    uint32_t* ring = reinterpret_cast<uint32_t*>(vrx_smem) + wave * VRX_RING;
     const int tile = blockIdx.x;
     // contracted range of this workgroup: slabs split as evenly as possible over gridDim.y
     const int s_lo = (int)((int64_t)blockIdx.y * n_slab / gridDim.y);
@@ -410,22 +413,40 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
         }
     };
 
-    // ---- entry stream: ring of 512 entries refilled 256 at a time, 2 chunks ahead ---------
+    // ---- entry stream: global -> LDS directly (LDS-DMA: no staging registers, no ds_write).
+    // A chunk is 256 words (one global_load_lds_dwordx4 per wave) on the absolute 256-word grid
+    // of the wave's stream; the ring holds two.  A chunk is issued as soon as the slot it goes
+    // to has been vacated, and awaited (vmcnt(0)) when the walk reaches it one chunk later.
+    // The compiler does not see these loads: its own vmcnt waits only become stricter.
     const int stream_lo = __builtin_amdgcn_readfirstlane(bw[(int64_t)s_lo * NR]) & ~(U * G - 1);
     const int stream_end = __builtin_amdgcn_readfirstlane(bw[(int64_t)s_hi * NR]) & ~(U * G - 1);
-    int staged_end = stream_lo;
-    auto chunk_load = [&](int from) {  // entries [from + 4*lane, +4); zero beyond the stream
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (from + 4 * lane < stream_end)  // (the stream is padded to a multiple of 4 words)
-            v = *reinterpret_cast<const uint4*>(stream + from + 4 * lane);
-        return v;
+    const int base0 = stream_lo & ~(VRX_CHUNK - 1);
+    const int clamp_last = max(stream_end - 4, 0);  // lanes past the range re-read its last 16 B
+    const uint32_t ring_lds = (uint32_t)(wave * VRX_RING * 4);  // (dynamic LDS starts at 0)
+    int landed_end = base0, issued_end = base0;
+    auto dma_issue = [&](int pos) {
+        const uint32_t* gsrc = stream + min(pos + 4 * lane, clamp_last);
+        const uint32_t dst =
+            __builtin_amdgcn_readfirstlane(ring_lds + (uint32_t)((pos & (VRX_RING - 1)) * 4));
+        unsigned keep;  // M0 = LDS destination of lane 0; written and restored in one statement
+        asm volatile(
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(gsrc), "s"(dst)
+            : "memory");
+        issued_end = pos + VRX_CHUNK;
     };
-    uint4 pre0 = chunk_load(stream_lo), pre1 = chunk_load(stream_lo + VRX_CHUNK);
-    auto stage_chunk = [&]() {
-        *reinterpret_cast<uint4*>(ring + ((staged_end + 4 * lane) & (VRX_RING - 1))) = pre0;
-        staged_end += VRX_CHUNK;
-        pre0 = pre1;
-        pre1 = chunk_load(staged_end + VRX_CHUNK);
+    dma_issue(base0);
+    if (base0 + VRX_CHUNK < stream_end) dma_issue(base0 + VRX_CHUNK);
+    auto ring_need = [&](int at) {  // at: a trip position (multiple of U*G words), wave-uniform
+        if (at + U * G > landed_end) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            landed_end = issued_end;
+        }
+        if ((at & (VRX_CHUNK - 1)) == 0 && at > base0 && at + VRX_CHUNK < stream_end &&
+            at + VRX_CHUNK >= issued_end)
+            dma_issue(at + VRX_CHUNK);  // into the slot of the chunk just finished
     };
     // one entry of this group's segment: word -> 4 column slices -> FMAs
     auto entry = [&](uint32_t w, double (&a)[NQ][2], double (&a2)[NQ][2]) {
@@ -467,7 +488,7 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
             const int end = __builtin_amdgcn_readlane(bcur, r + 1) & ~(U * G - 1);
             const int full_end = tail ? end - U * G : end;
             for (int at = base; at < full_end; at += U * G) {
-                if (at + U * G > staged_end) stage_chunk();  // wave-uniform, once per 256 words
+                ring_need(at);
                 // trips start at multiples of U*G = 64 words and the ring is a multiple of
                 // that, so a trip never wraps: one address, constant offsets
                 const uint32_t* rp = ring_g + (at & (VRX_RING - 1));
@@ -478,7 +499,7 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
                 for (int u = 0; u < US; ++u) entry(w[u], acc[r], acc2[r]);
             }
             if (tail) {  // (entries past the tail are zero words: harmless where SPLIT > 1)
-                if (full_end + U * G > staged_end) stage_chunk();
+                ring_need(full_end);
                 const uint32_t* rp = ring_g + (full_end & (VRX_RING - 1));
                 uint32_t w[US];
 #pragma unroll
