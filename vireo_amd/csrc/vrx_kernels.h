@@ -437,7 +437,7 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
             : "memory");
         issued_end = pos + VRX_CHUNK;
     };
-    dma_issue(base0);
+    if (base0 < stream_end) dma_issue(base0);
     if (base0 + VRX_CHUNK < stream_end) dma_issue(base0 + VRX_CHUNK);
     auto ring_need = [&](int at) {  // at: a trip position (multiple of U*G words), wave-uniform
         if (at + U * G > landed_end) {
@@ -510,6 +510,9 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
             }
         }
     }
+    // (every issued chunk has been awaited by the walk; this only guards the invariant that no
+    //  LDS-DMA write is in flight when the workgroup's LDS is released)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ---- every group holds the complete sums of its rows: store them ------------------------
     if (SPLIT > 1) {  // partial sums of the SPLIT entry streams: butterfly over the lanes
 #pragma unroll
