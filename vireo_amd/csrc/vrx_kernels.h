@@ -439,14 +439,19 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     };
     if (base0 < stream_end) dma_issue(base0);
     if (base0 + VRX_CHUNK < stream_end) dma_issue(base0 + VRX_CHUNK);
-    auto ring_need = [&](int at) {  // at: a trip position (multiple of U*G words), wave-uniform
-        if (at + U * G > landed_end) {
+    // Ring work happens only at the first trip and at chunk boundaries: `ring_evt` is the next
+    // such trip position, so a trip pays one scalar compare (at: multiple of U*G, wave-uniform).
+    int ring_evt = stream_lo;
+    auto ring_need = [&](int at) {
+        if (at < ring_evt) return;
+        if (at >= landed_end) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             landed_end = issued_end;
         }
         if ((at & (VRX_CHUNK - 1)) == 0 && at > base0 && at + VRX_CHUNK < stream_end &&
             at + VRX_CHUNK >= issued_end)
             dma_issue(at + VRX_CHUNK);  // into the slot of the chunk just finished
+        ring_evt = (at & ~(VRX_CHUNK - 1)) + VRX_CHUNK;
     };
     // one entry of this group's segment: word -> 4 column slices -> FMAs
     auto entry = [&](uint32_t w, double (&a)[NQ][2], double (&a2)[NQ][2]) {
