@@ -46,7 +46,9 @@ extern "C" int vrx_device_info(int device, char* name, int name_len, int* n_cu,
     hipDeviceProp_t prop;
     VRX_HIP(hipGetDeviceProperties(&prop, device));
     if (name && name_len > 0) {
-        snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+        // (some boxes report an empty marketing name: say what the arch is then)
+        snprintf(name, name_len, "%s (%s)", prop.name[0] ? prop.name : "AMD GPU",
+                 prop.gcnArchName);
     }
     if (n_cu) *n_cu = prop.multiProcessorCount;
     if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
