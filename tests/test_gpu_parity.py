@@ -147,6 +147,26 @@ def test_wrap(va, name, kw, capsys):
         assert np.array_equal(np.argmax(rv["doublet_prob"], 1), np.argmax(g["doublet_prob"], 1))
 
 
+def test_wrap_on_lds_resident_passes(va, monkeypatch, capsys):
+    """the notebook-style wrap (restarts, final fit, doublets) with the LDS-resident passes
+    forced on: K = 4 fits, and the doublet log-likelihoods as one K' = 4 + 6 = 10 column
+    operand; against the reference's golden output (the problem cache is cleared so that
+    the problem is built with the LDS streams)."""
+    from vireo_amd.counts import clear_cache
+    monkeypatch.setenv("VIREO_LDS", "1")
+    clear_cache()
+    g = gold.load("c1_wrap_seed2_init4")
+    AD, DP = gold.c1()
+    rv = va.vireo_wrap(AD.copy(), DP.copy(), n_donor=4, n_init=4, random_seed=2)
+    clear_cache()
+    capsys.readouterr()
+    close(rv["LB_list"], g["LB_list"])
+    close(rv["LB_doublet"], g["LB_doublet"])
+    for k in ("ID_prob", "GT_prob", "doublet_prob"):
+        close(rv[k], g[k])
+    assert np.array_equal(np.argmax(rv["doublet_prob"], 1), np.argmax(g["doublet_prob"], 1))
+
+
 # ---------------------------------------------------------------- golden: clone mode
 def test_bmm_mito_known_answer(va):
     g = gold.load("mito_bmm_k3_seed1")
@@ -332,7 +352,7 @@ def test_lds_resident_passes_vs_oracle(va, monkeypatch, fmt, blocks, sort):
     """the LDS-resident (two-dimensionally tiled) passes, forced on a small ragged problem:
     one or many contracted ranges, K = 16 / 12 (4 / 3 lanes per entry), K = 8 / 4 (2 / 4 entries of
     a row at once on 2 / 1 lanes each) and K = 9 / 6 / 3 / 15 / 2 (dense rows zero-padded to
-    12 / 8 / 4 / 16 / 4 columns in LDS).  The long
+    12 / 8 / 4 / 16 / 4 columns in LDS) and K = 20 / 33 (column blocks of 16).  The long
     variant / cell of the ragged case are cut into interleaved pieces (sort=1) or kept whole
     in natural row order (sort=0)."""
     from vireo_amd import _lib
@@ -347,7 +367,7 @@ def test_lds_resident_passes_vs_oracle(va, monkeypatch, fmt, blocks, sort):
     info = DeviceModel(counts, _lib.KIND_VIREO, 16).info()
     assert info["lds_cell"] and info["lds_variant"]
     assert (info["extra_pieces_cell"] > 0) == (info["extra_pieces_variant"] > 0) == bool(sort)
-    for K in (16, 12, 8, 4, 9, 6, 3, 15, 2):
+    for K in (16, 12, 8, 4, 9, 6, 3, 15, 2, 20, 33):
         np.random.seed(11)
         ref = O.vireo_new(AD.shape[1], AD.shape[0], K)
         np.random.seed(11)

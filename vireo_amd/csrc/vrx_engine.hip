@@ -916,16 +916,17 @@ template <int MODE>
 static bool lds_eligible(const Orient& o, int K) {
     static const int mask = env_int("VIREO_LDS_PASS", 3);  // bit 0: variant pass, bit 1: cell pass
     static const int kmin = env_int("VIREO_LDS_MIN_K", 2);
-    return o.tiled.ready && (mask >> MODE & 1) && K <= 16 && K >= kmin;
+    static const int kmax = env_int("VIREO_LDS_MAX_K", 1 << 20);  // > 16: column blocks of 16
+    return o.tiled.ready && (mask >> MODE & 1) && K <= kmax && K >= kmin;
 }
 
 // kernel instance for K: zero-padded rows when K % 4, 2 / 4 entries at once when K <= 8 / 4
 template <int LPE, int MODE>
-static auto lds_kernel(int K) {
+static auto lds_kernel(int K, bool strided) {
     constexpr int RW = MODE == 1 ? VRX_LDS_RW_CELL : VRX_LDS_RW_VARIANT;
     static const int split_on = env_int("VIREO_LDS_SPLIT_K", 1);
     const int split = !split_on ? 1 : K <= 4 ? 4 : K <= 8 ? 2 : 1;
-    const bool pad = K % 4 != 0;
+    const bool pad = K % 4 != 0 || strided;  // (the element-wise slab copy handles row strides)
     if (split == 4)
         return pad ? vrx_spmm_lds<LPE, MODE, RW, true, 4> : vrx_spmm_lds<LPE, MODE, RW, false, 4>;
     if (split == 2)
@@ -936,14 +937,21 @@ static auto lds_kernel(int K) {
 template <int LPE, int MODE>
 static int launch_lds_one(const Orient& o, hipStream_t s, const double* X, int K, double* dst) {
     const TiledStream& t = o.tiled;
-    const size_t lds = (size_t)t.slab_rows * ((K + 3) & ~3) * (MODE == 1 ? 16 : 8) + 16 * VRX_RING * 4;
+    constexpr int XD = MODE == 1 ? 2 : 1, NV = MODE == 0 ? 2 : 1;
     dim3 grid((unsigned)t.n_tile, (unsigned)t.n_range);
-    auto kern = lds_kernel<LPE, MODE>(K);
-    VRX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    kern<<<grid, 1024, lds, s>>>(t.ent.p, t.wave_start.p, t.bnd.p, t.rowmap.p, t.n_slab,
-                                 t.slab_rows, o.n_contract, t.n_vrows, X, K, dst);
-    VRX_HIP(hipGetLastError());
+    // operands wider than 16 columns go through in blocks of 16 (the stream is re-read per
+    // block, like the column chunks of the gather kernels)
+    for (int c0 = 0; c0 < K; c0 += 16) {
+        const int kb = std::min(16, K - c0);
+        const size_t lds = (size_t)t.slab_rows * ((kb + 3) & ~3) * (MODE == 1 ? 16 : 8) + 16 * VRX_RING * 4;
+        auto kern = lds_kernel<LPE, MODE>(kb, K > 16);
+        VRX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        kern<<<grid, 1024, lds, s>>>(t.ent.p, t.wave_start.p, t.bnd.p, t.rowmap.p, t.n_slab,
+                                     t.slab_rows, o.n_contract, t.n_vrows, X + (size_t)c0 * XD, kb, K,
+                                     dst + (size_t)c0 * NV);
+        VRX_HIP(hipGetLastError());
+    }
     return VRX_OK;
 }
 

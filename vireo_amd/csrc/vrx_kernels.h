@@ -259,7 +259,8 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_spmm(
 }
 
 // ------------------------------------------------------------------------------------
-// LDS-resident variant of the sparse passes (large problems, K <= 16, counts < 2048)
+// LDS-resident variant of the sparse passes (large problems, counts < 2048; K <= 16 columns
+// per launch, wider operands in column blocks)
 // ------------------------------------------------------------------------------------
 // The global-gather kernel above is bound by the L1-miss path: every non-zero pulls one or
 // two 128-B lines through the vector cache.  Here the dense operand is streamed through
@@ -310,7 +311,9 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     const uint32_t* __restrict__ ent, const int64_t* __restrict__ wave_start,
     const int32_t* __restrict__ bnd, const int32_t* __restrict__ rowmap, int n_slab,
     int slab_rows, int64_t n_contract, int64_t n_rows, const double* __restrict__ X, int K,
-    double* __restrict__ out) {
+    int ld, double* __restrict__ out) {
+    // K <= 16 columns of this launch; ld = columns per row of X and out (ld > K: one block of a
+    // wider operand, always with PADK = true: the flat slab copy needs contiguous rows)
     constexpr int G = 64 / LPE;            // rows per round
     constexpr int NR = RW / G;             // rounds
     constexpr int XD = MODE == 1 ? 2 : 1;  // doubles per (contracted row, column)
@@ -378,17 +381,17 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
                 pf[i] = at < n16 ? src[at] : make_double2(0.0, 0.0);
             }
         } else {
-            const double* src = X + row0 * K * XD;
+            const double* src = X + row0 * ld * XD;
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
                 const int row = r0 + i * rstep;
                 double2 v = make_double2(0.0, 0.0);
                 if (pad_act && row < rows) {
                     if (MODE == 1) {  // unit j0 = (w1, w2) of column j0
-                        if (j0 < K) v = reinterpret_cast<const double2*>(src)[row * K + j0];
+                        if (j0 < K) v = reinterpret_cast<const double2*>(src)[row * ld + j0];
                     } else {  // unit j0 = columns 2*j0, 2*j0 + 1
-                        if (2 * j0 < K) v.x = src[row * K + 2 * j0];
-                        if (2 * j0 + 1 < K) v.y = src[row * K + 2 * j0 + 1];
+                        if (2 * j0 < K) v.x = src[row * ld + 2 * j0];
+                        if (2 * j0 + 1 < K) v.y = src[row * ld + 2 * j0 + 1];
                     }
                 }
                 pf[i] = v;
@@ -532,7 +535,7 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
                         if (MODE == 0) acc2[r][q][h] += __shfl_xor(acc2[r][q][h], m, 64);
                     }
     }
-    double* dst = out + (int64_t)blockIdx.y * n_rows * K * NV;
+    double* dst = out + (int64_t)blockIdx.y * n_rows * ld * NV;
     if (kok && sub == 0) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
@@ -542,9 +545,9 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
                 for (int q = 0; q < NQ; ++q) {
                     const int slice = kl * NQ + (q + g) % NQ;  // 16-B slice of the dense row
                     if (MODE == 1) {
-                        if (!PADK || slice < K) dst[row * K + slice] = acc[r][q][0];
+                        if (!PADK || slice < K) dst[row * ld + slice] = acc[r][q][0];
                     } else {  // columns 2*slice, 2*slice+1; S[row][k] = (s1, ss)
-                        double2* o = reinterpret_cast<double2*>(dst) + row * K + 2 * slice;
+                        double2* o = reinterpret_cast<double2*>(dst) + row * ld + 2 * slice;
                         if (!PADK || 2 * slice < K)
                             o[0] = make_double2(acc[r][q][0], acc2[r][q][0]);
                         if (!PADK || 2 * slice + 1 < K)
