@@ -967,8 +967,12 @@ static int launch_spmm_lds(vrx_model* m, const Orient& o, const double* X, int K
     if (rc) return rc;
     if (t.split) {  // rows cut into pieces: sum pieces and ranges in one fixed order
         const int64_t n = o.n_rows * K * NV;
-        vrx_sum_pieces<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
-            o.n_rows, K * NV, t.n_range, t.n_vrows, t.vptr.p, range_partial, out);
+        if ((int64_t)t.n_range * t.n_vrows >= 64 * o.n_rows)  // >= 64 terms per row on average
+            vrx_sum_pieces_wave<<<(unsigned)((n * 64 + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
+                o.n_rows, K * NV, t.n_range, t.n_vrows, t.vptr.p, range_partial, out);
+        else
+            vrx_sum_pieces<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
+                o.n_rows, K * NV, t.n_range, t.n_vrows, t.vptr.p, range_partial, out);
         VRX_HIP(hipGetLastError());
     } else if (t.n_range > 1 && !defer_sum) {
         const int64_t n = o.n_rows * K * NV;

@@ -568,10 +568,42 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_pieces(
     const int64_t row = i / width;
     const int c = (int)(i - row * width);
     const int v0 = vptr[row], v1 = vptr[row + 1];
+    // the terms are numbered t = r * (v1 - v0) + (v - v0) and added in that order; 16 loads are
+    // in flight at a time (a plain loop pays one memory round trip per term)
+    const int np = v1 - v0, nt = n_range * np;
     double s = 0.0;
-    for (int r = 0; r < n_range; ++r)
-        for (int v = v0; v < v1; ++v) s += partial[((int64_t)r * n_vrows + v) * width + c];
+    for (int t0 = 0; t0 < nt; t0 += 16) {
+        double x[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int t = t0 + j, r = t / np, v = v0 + (t - r * np);
+            x[j] = t < nt ? partial[((int64_t)r * n_vrows + v) * width + c] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += x[j];
+    }
     out[i] = s;
+}
+
+// the same sum when a row has many terms (few long rows cut into many pieces, many ranges):
+// one wavefront per output, lane l adds terms l, l + 64, ... in order, then the fixed
+// butterfly of wave_sum
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_pieces_wave(
+    int64_t n_rows, int width, int n_range, int64_t n_vrows, const int32_t* __restrict__ vptr,
+    const double* __restrict__ partial, double* __restrict__ out) {
+    const int64_t i = ((int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (i >= n_rows * width) return;
+    const int64_t row = i / width;
+    const int c = (int)(i - row * width);
+    const int v0 = vptr[row], np = vptr[row + 1] - v0, nt = n_range * np;
+    double s = 0.0;
+    for (int t = lane; t < nt; t += 64) {
+        const int r = t / np, v = v0 + (t - r * np);
+        s += partial[((int64_t)r * n_vrows + v) * width + c];
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[i] = s;
 }
 
 // partial[range][...] summed over the contracted ranges in order
@@ -581,7 +613,13 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_ranges(int64_t n, int n_ran
     const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
     if (i >= n) return;
     double s = 0.0;
-    for (int r = 0; r < n_range; ++r) s += partial[(int64_t)r * n + i];
+    for (int r0 = 0; r0 < n_range; r0 += 16) {  // 16 loads in flight, added in range order
+        double x[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) x[j] = r0 + j < n_range ? partial[(int64_t)(r0 + j) * n + i] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += x[j];
+    }
     out[i] = s;
 }
 
