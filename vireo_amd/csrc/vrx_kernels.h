@@ -270,7 +270,7 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_spmm(
 //   * the contracted dimension is cut into slabs of `slab_rows` dense rows (<= 128 KiB);
 //     the workgroup walks the slabs of its range in order, staging each slab into LDS with
 //     coalesced loads issued one slab ahead (register prefetch);
-//   * inside a wave, LPE = K/4 lanes form a group that owns ONE output row at a time
+//   * inside a wave, LPE = 4 lanes form a group that owns ONE output row at a time
 //     (G = 64/LPE rows per round, RW/G rounds) and each lane owns 4 columns of it, so the
 //     per-entry overhead (unpack, convert, address) is paid by 4 lanes instead of 16 and a
 //     row's sums never leave its lanes: no cross-lane traffic at all;
@@ -281,9 +281,9 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_spmm(
 //     last trip are skipped).  Every wave thus reads ONE contiguous stream in lock-step with its
 //     compute, landing in a 512-word LDS ring in 256-word chunks by LDS-DMA
 //     (global_load_lds_dwordx4), one chunk ahead of the walk; bnd[] holds, per wave, the
-//     stream offset of every (slab, round).  With ~10
-//     entries per row and slab the padding costs ~1.7 slots per entry, which the 4x lower
-//     per-slot instruction count more than repays;
+//     stream offset of every (slab, round) and, in its low bits, the entries of the round's
+//     last trip.  With ~10 entries per row and slab the padding costs ~1.6 slots per entry,
+//     which the 4x lower per-slot instruction count more than repays;
 //   * the 4 columns of a lane are visited in a group-dependent rotation so that the
 //     16 lanes serviced together by ds_read_b128 hit 16 different 16-B bank slots.
 // Output: one partial array per contracted range (summed in fixed order afterwards).
