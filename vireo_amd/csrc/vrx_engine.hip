@@ -537,7 +537,26 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
     if (max_count < 2048 && lds != 0) {
         // cell pass: slabs of 512 W rows (128 KiB at K = 16); variant pass: 1024 ID rows
         if (lds == 1 || nnz >= (int64_t)env_int("VIREO_LDS_MIN_NNZ", 4000000)) {
-            rc = build_tiled(p->by_cell, colptr, rowidx, cval.data(), VRX_LDS_RW_CELL, 512,
+            // One workgroup per CU at a time: a launch of W workgroups takes ceil(W / 256)
+            // rounds.  With many slabs W is ~1000 whatever the tile height; with one or two
+            // slabs (few variants: clone mode) W = tiles x slabs, and the shorter tile wins
+            // when it fills the last round better (200 k cells: 261 tiles of 768 rows = 2
+            // rounds at 51 %, 391 tiles of 512 rows = 2 rounds at 76 %).
+            const int n_slab_c = (int)((n_var + 511) / 512);
+            auto cost = [&](int rw) {  // rounds x rows per wave x slabs per workgroup
+                const int64_t tiles = (n_cell + 16 * (int64_t)rw - 1) / (16 * (int64_t)rw);
+                const int64_t ranges = std::max<int64_t>(
+                    1, std::min<int64_t>(n_slab_c, env_int("VIREO_LDS_BLOCKS", 1024) / std::max<int64_t>(tiles, 1)));
+                const int64_t w = tiles * ranges;
+                return (double)((w + 255) / 256) * rw * (double)n_slab_c / (double)ranges;
+            };
+            const int forced = env_int("VIREO_LDS_RW_CELL", 0);
+            const int rw_cell =
+                forced == VRX_LDS_RW_CELL_SHORT ||
+                        (forced == 0 && n_slab_c <= 2 && cost(VRX_LDS_RW_CELL_SHORT) < cost(VRX_LDS_RW_CELL))
+                    ? VRX_LDS_RW_CELL_SHORT
+                    : VRX_LDS_RW_CELL;
+            rc = build_tiled(p->by_cell, colptr, rowidx, cval.data(), rw_cell, 512,
                              lds != 1, p->stream);
             if (rc) return rc;
         }
@@ -921,9 +940,8 @@ static bool lds_eligible(const Orient& o, int K) {
 }
 
 // kernel instance for K: zero-padded rows when K % 4, 2 / 4 entries at once when K <= 8 / 4
-template <int LPE, int MODE>
-static auto lds_kernel(int K, bool strided) {
-    constexpr int RW = MODE == 1 ? VRX_LDS_RW_CELL : VRX_LDS_RW_VARIANT;
+template <int LPE, int MODE, int RW>
+static auto lds_kernel_rw(int K, bool strided) {
     static const int split_on = env_int("VIREO_LDS_SPLIT_K", 1);
     const int split = !split_on ? 1 : K <= 4 ? 4 : K <= 8 ? 2 : 1;
     const bool pad = K % 4 != 0 || strided;  // (the element-wise slab copy handles row strides)
@@ -932,6 +950,14 @@ static auto lds_kernel(int K, bool strided) {
     if (split == 2)
         return pad ? vrx_spmm_lds<LPE, MODE, RW, true, 2> : vrx_spmm_lds<LPE, MODE, RW, false, 2>;
     return pad ? vrx_spmm_lds<LPE, MODE, RW, true, 1> : vrx_spmm_lds<LPE, MODE, RW, false, 1>;
+}
+
+// rows per wave: the pass default, or (cell pass) the shorter tile of short_tile_pays()
+template <int LPE, int MODE>
+static auto lds_kernel(int K, bool strided, int rw) {
+    if (MODE == 1 && rw == VRX_LDS_RW_CELL_SHORT)
+        return lds_kernel_rw<LPE, MODE, MODE == 1 ? VRX_LDS_RW_CELL_SHORT : VRX_LDS_RW_VARIANT>(K, strided);
+    return lds_kernel_rw<LPE, MODE, MODE == 1 ? VRX_LDS_RW_CELL : VRX_LDS_RW_VARIANT>(K, strided);
 }
 
 template <int LPE, int MODE>
@@ -944,7 +970,7 @@ static int launch_lds_one(const Orient& o, hipStream_t s, const double* X, int K
     for (int c0 = 0; c0 < K; c0 += 16) {
         const int kb = std::min(16, K - c0);
         const size_t lds = (size_t)t.slab_rows * ((kb + 3) & ~3) * (MODE == 1 ? 16 : 8) + 16 * VRX_RING * 4;
-        auto kern = lds_kernel<LPE, MODE>(kb, K > 16);
+        auto kern = lds_kernel<LPE, MODE>(kb, K > 16, t.rw);
         VRX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         kern<<<grid, 1024, lds, s>>>(t.ent.p, t.wave_start.p, t.bnd.p, t.rowmap.p, t.n_slab,
