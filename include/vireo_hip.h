@@ -88,6 +88,16 @@ void vrx_model_destroy(vrx_model* m);
  * that array as it is on the device.  GT_prob is ignored for VRX_KIND_BMM. */
 int vrx_model_set_state(vrx_model* m, const double* ID_prob, const double* GT_prob,
                         const double* beta_mu, const double* beta_sum);
+/* Initial state straight from the random draws (Vireo.set_initial, vireo_model.py:98-104:
+ * ID_prob = normalize(rand(M, K)), GT_prob = normalize(rand(N, K, T))): uploads the RAW draws
+ * and normalises them on the device over the last axis, bit-identically to NumPy's
+ * X / X.sum(-1) (pairwise summation order restated in vrx_normalize_rows).  NULL arguments are
+ * left untouched.  <= 128 columns. */
+int vrx_model_set_state_raw(vrx_model* m, const double* ID_raw, const double* GT_raw,
+                            const double* beta_mu, const double* beta_sum);
+/* restore == 0: save (ID_prob, GT_prob, beta_mu, beta_sum) in a device-side slot;
+ * restore != 0: bring them back.  The best restart so far (vireo_wrap.py:90-91) stays in HBM. */
+int vrx_model_snapshot(vrx_model* m, int32_t restore);
 int vrx_model_get_state(vrx_model* m, double* ID_prob, double* GT_prob, double* beta_mu,
                         double* beta_sum);
 
@@ -181,8 +191,10 @@ int vrx_problem_cell_loglik(vrx_problem* p, int64_t n_col, int64_t n_class,
  * of the variant/cell orientation (0: 4 B, 1: 8 B, 2: 12 B per non-zero); info[4]/[5] =
  * L2 tiles of the variant/cell orientation; info[6]/[7] = contracted ranges of the
  * LDS-resident variant/cell pass; info[8]/[9] = its stream words (padding included) per 1000
- * non-zeros; info[10]/[11] = extra row pieces (long rows are cut into interleaved pieces). */
-int vrx_model_info(vrx_model* m, int32_t* info12);
+ * non-zeros; info[10]/[11] = extra row pieces (long rows are cut into interleaved pieces);
+ * info[12] = form of the LDS-resident cell stream (0: (ad, dp) pairs, 1: single-valued AD / BD
+ * entries); info[13..15] reserved (0). */
+int vrx_model_info(vrx_model* m, int32_t* info16);
 int vrx_model_profile(vrx_model* m, int32_t enable);
 int vrx_model_profile_read(vrx_model* m, double* ms_total /* VRX_KERN_COUNT */,
                            int64_t* launches /* VRX_KERN_COUNT */);
@@ -204,6 +216,14 @@ int vrx_comm_allgather_f64(vrx_comm* c, const double* local, int64_t n_local, do
 int vrx_comm_barrier(vrx_comm* c);
 /* broadcast a host buffer of doubles from `root` (winner's state to rank 0 / everyone) */
 int vrx_comm_bcast_f64(vrx_comm* c, double* buf, int64_t n, int root);
+
+/* ---- restart initialisation ------------------------------------------------------------
+ * Every restart's initial ID_prob / GT_prob comes from NumPy's legacy global stream
+ * (np.random.rand in vireo_model.py:98,103, one Vireo per restart in vireo_wrap.py:66-71).
+ * Continue that stream in C: write the next n doubles of RandomState.random_sample() to
+ * `out`, or (out == NULL) skip them, advancing the MT19937 state of np.random.get_state()
+ * (key[624], pos) in place.  Host only; no GPU needed. */
+int vrx_mt19937_random_sample(uint32_t* key624, int32_t* pos, double* out, int64_t n);
 
 #ifdef __cplusplus
 }

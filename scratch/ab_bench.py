@@ -1,5 +1,5 @@
-"""A/B timing of library variants (scratch/lib_*.so) at c3: per-pass ms.
-usage: ab_bench.py default scratch/libA.so scratch/libB.so ..."""
+"""A/B timing of library variants (scratch/lib_*.so) and / or environment knobs at c3: per-pass ms.
+usage: ab_bench.py default scratch/libA.so default@VIREO_CELL_FORM=0,VIREO_LDS_PARITY=0 ..."""
 import json
 import os
 import subprocess
@@ -15,7 +15,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     from vireo_amd.vireo_model import Vireo
     N, M, K, d = synth.CONFIGS[os.environ.get("AB_CONFIG", "c3")]
     K = int(os.environ.get("AB_K", K))
-    w = synth.donor_workload(N, M, K, d, seed=0)
+    cache = "/tmp/ab_%s.npz" % os.environ.get("AB_CONFIG", "c3")
+    if os.path.exists(cache):
+        w = dict(np.load(cache))
+        w["shape"] = tuple(int(x) for x in w["shape"])
+    else:
+        w = synth.donor_workload(N, M, K, d, seed=0)
+        np.savez(cache, **{k: w[k] for k in ("shape", "colptr", "rowidx", "ad", "dp")})
     counts = DeviceCounts.from_merged(w["shape"], w["colptr"], w["rowidx"], w["ad"], w["dp"], device=0)
     np.random.seed(1)
     host = Vireo(n_var=N, n_cell=M, n_donor=K)
@@ -27,14 +33,20 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     dm.profile(True)
     dm.run_iters(10, theta_from_iter=0)
     pm, n = dm.profile_read()
+    info = dm.info()
     print(json.dumps(dict(ms_iter=round(ms / 20, 4), variant=round(pm[0] / max(n[0], 1), 4),
                           cell=round(pm[1] / max(n[1], 1), 4), dense=round(pm[2] / 10, 4),
-                          elbo=float(tr[-1]))))
+                          elbo=float(tr[-1]), pad_v=info["pad_variant"], pad_c=info["pad_cell"],
+                          form=info["cell_form"])))
 else:
-    for lib in sys.argv[1:]:
+    for arg in sys.argv[1:]:
+        lib, _, knobs = arg.partition("@")
         e = dict(os.environ)
+        for kv in filter(None, knobs.split(",")):
+            k, _, v = kv.partition("=")
+            e[k] = v
         if lib != "default":
             e["VIREO_LIB"] = os.path.join(ROOT, lib)
         out = subprocess.run([sys.executable, __file__, "child"], env=e, capture_output=True, text=True)
-        print(lib, out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-1500:],
+        print(arg, out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-1500:],
               flush=True)

@@ -380,11 +380,15 @@ def test_lds_resident_passes_vs_oracle(va, monkeypatch, fmt, blocks, sort):
         close(dev.GT_prob, ref.GT_prob)
 
 
-@pytest.mark.parametrize("top,expect_lds", [(2047, True), (2048, False)])
+@pytest.mark.parametrize("top,expect_lds", [(2047, True), (2048, False), (16383, False),
+                                            (16384, False), (90000, False)])
 def test_lds_count_limit_and_tiny_shapes(va, monkeypatch, top, expect_lds):
-    """the tiled words hold counts < 2048: at the limit the LDS passes are used, one above
-    the problem silently stays on the global-gather kernels; shapes smaller than one tile /
-    one slab (N=70 variants, M=40 cells) and a single contracted range."""
+    """the (ad, dp) pair words of the variant stream hold counts < 2048: at the limit the LDS
+    variant pass is used, one above that pass silently stays on the global-gather kernel; the
+    single-valued AD / BD words of the cell stream hold 15 signed bits and cut larger counts
+    into several entries, so the LDS cell pass takes any count (16383 / 16384: the chunk
+    boundary; 90000: data/mitoDNA-like depth).  Shapes smaller than one tile / one slab
+    (N=70 variants, M=40 cells) and a single contracted range."""
     from vireo_amd import _lib
     from vireo_amd.counts import DeviceCounts
     from vireo_amd.engine import DeviceModel
@@ -397,7 +401,8 @@ def test_lds_count_limit_and_tiny_shapes(va, monkeypatch, top, expect_lds):
     counts = DeviceCounts(AD, DP)
     K = 8
     info = DeviceModel(counts, _lib.KIND_VIREO, K).info()
-    assert info["lds_cell"] == info["lds_variant"] == expect_lds
+    assert info["lds_variant"] == expect_lds
+    assert info["lds_cell"] and info["cell_form"] == 1
     np.random.seed(2)
     ref = O.vireo_new(40, 70, K)
     np.random.seed(2)

@@ -48,6 +48,8 @@ SIGNATURES = {
     "vrx_model_destroy": (None, [_P]),
     "vrx_model_set_state": (C.c_int, [_P, _D, _D, _D, _D]),
     "vrx_model_get_state": (C.c_int, [_P, _D, _D, _D, _D]),
+    "vrx_model_set_state_raw": (C.c_int, [_P, _D, _D, _D, _D]),
+    "vrx_model_snapshot": (C.c_int, [_P, C.c_int32]),
     "vrx_model_set_prior": (C.c_int, [_P, _D, C.c_int64, _D, C.c_int64, _D, _D, C.c_int64]),
     "vrx_model_fit": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_double, C.c_int32, _D, _I32, _I32]),
     "vrx_model_step": (C.c_int, [_P, C.c_int32, _D]),
@@ -69,6 +71,7 @@ SIGNATURES = {
     "vrx_comm_allgather_f64": (C.c_int, [_P, _D, C.c_int64, _D]),
     "vrx_comm_barrier": (C.c_int, [_P]),
     "vrx_comm_bcast_f64": (C.c_int, [_P, _D, C.c_int64, C.c_int]),
+    "vrx_mt19937_random_sample": (C.c_int, [C.POINTER(C.c_uint32), _I32, _D, C.c_int64]),
 }
 
 _lib = None

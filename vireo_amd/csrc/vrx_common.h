@@ -75,6 +75,7 @@ struct DevBuf {
 // offset of every (slab, row) segment start (+ one end marker).
 struct TiledStream {
     bool ready = false;
+    int form = 0;  // 0: (ad, dp) pairs; 1: single-valued AD / BD entries (cell pass, FORM 1)
     int rw = 0, slab_rows = 0, n_slab = 0, n_tile = 0;
     int n_range = 1;  // contracted ranges = gridDim.y of the LDS-resident pass
     DevBuf<uint32_t> ent;

@@ -249,11 +249,19 @@ static int build_orient(Orient& o, int64_t n_rows, int64_t n_contract, const int
 // summed afterwards in piece order (vrx_sum_pieces), (2) pieces are sorted by length so that
 // a round holds 16 similar ones, (3) the sorted rounds are dealt to the waves in snake order
 // so that every wave (and tile) carries about the same number of entries.
+//
+// form 1 (cell pass): every (ad, dp) entry becomes single-valued entries of AD and of
+// BD = DP - AD (none for a zero, several for a value outside 15 signed bits), see FORM 1 in
+// vrx_kernels.h.  Word = value:15 | (2 * slab-local index + half) * 128.  Lane groups g with
+// g % 8 < 4 walk a segment's AD entries first, the others its BD entries first: the two groups
+// that share a slice rotation inside a ds_read_b128 service group then read different halves
+// (different banks) except where their AD / BD counts differ.
 static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const int2* val,
-                       int RW, int slab_rows, bool guard, hipStream_t s) {
+                       int RW, int slab_rows, bool guard, int form, hipStream_t s) {
     constexpr int G = 64 / VRX_LDS_LPE, U = VRX_LDS_U;
     const int NR = RW / G;
     TiledStream& t = o.tiled;
+    t.form = form;
     t.rw = RW;
     t.slab_rows = slab_rows;
     t.n_slab = (int)((o.n_contract + slab_rows - 1) / slab_rows);
@@ -313,10 +321,18 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
     }
     // One wave's stream: walks its RW pieces slab by slab; pass 1 (dst == nullptr) records the
     // (slab, round) offsets and the length, pass 2 writes the words.  Waves are independent.
+    const bool parity_order = env_int("VIREO_LDS_PARITY", 1) != 0;
+    auto push_value = [](std::vector<uint32_t>& out, int64_t v, uint32_t off) {
+        while (v != 0) {  // chunks of 15 signed bits (counts past 16383 are rare: clone mode)
+            const int64_t c = std::max<int64_t>(-16384, std::min<int64_t>(16383, v));
+            out.push_back(((uint32_t)(int32_t)c << 17) | off);
+            v -= c;
+        }
+    };
     auto walk = [&](int64_t w, uint32_t* dst) {
         const int32_t* rm = rowmap.data() + w * RW;
-        std::vector<int64_t> cursor((size_t)RW), seg_lo((size_t)G), seg_n((size_t)G),
-            seg_step((size_t)G);
+        std::vector<int64_t> cursor((size_t)RW);
+        std::vector<uint32_t> segw[G], second;
         for (int c = 0; c < RW; ++c) cursor[(size_t)c] = rm[c] >= 0 ? ptr[vrow_row[(size_t)rm[c]]] : 0;
         int32_t* bw = bnd.data() + w * per_wave;
         int64_t rel = 0;
@@ -330,7 +346,8 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
                 int64_t longest = 0;
                 for (int g = 0; g < G; ++g) {
                     const int32_t v = rm[r * G + g];
-                    int64_t lo = 0, n = 0, step = 1;
+                    std::vector<uint32_t>& sw = segw[g];
+                    sw.clear();
                     if (v >= 0) {
                         const int32_t row = vrow_row[(size_t)v];
                         int64_t hi = cursor[(size_t)(r * G + g)];
@@ -338,30 +355,33 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
                         while (hi < stop && idx[hi] < lim) ++hi;
                         cursor[(size_t)(r * G + g)] = hi;
                         // this piece's share of the row's slab segment [seg, hi)
-                        step = vptr[(size_t)row + 1] - vptr[(size_t)row];
+                        const int64_t step = vptr[(size_t)row + 1] - vptr[(size_t)row];
                         const int64_t off = ((int64_t)(v - vptr[(size_t)row]) + sl) % step;
-                        lo = seg + off;
-                        n = hi - seg > off ? (hi - seg - off + step - 1) / step : 0;
+                        if (form == 0) {
+                            for (int64_t e = seg + off; e < hi; e += step)
+                                sw.push_back(((uint32_t)(idx[e] - base) << 22) |
+                                             ((uint32_t)val[e].x << 11) | (uint32_t)val[e].y);
+                        } else {
+                            const bool bd_first = parity_order && (g % 8) >= 4;
+                            second.clear();
+                            for (int64_t e = seg + off; e < hi; e += step) {
+                                const uint32_t at = (uint32_t)(idx[e] - base) * 256u;
+                                const int64_t ad = val[e].x, bd = (int64_t)val[e].y - val[e].x;
+                                push_value(bd_first ? second : sw, ad, at);
+                                push_value(bd_first ? sw : second, bd, at + 128u);
+                            }
+                            sw.insert(sw.end(), second.begin(), second.end());
+                        }
                     }
-                    seg_lo[(size_t)g] = lo;
-                    seg_n[(size_t)g] = n;
-                    seg_step[(size_t)g] = step;
-                    longest = std::max(longest, n);
+                    longest = std::max<int64_t>(longest, (int64_t)sw.size());
                 }
                 // offset | entries in the last trip (0 = full): the kernel skips the padding
                 bw[(int64_t)sl * NR + r] = (int32_t)(rel | (longest % U));
                 longest = (longest + U - 1) / U * U;
                 if (dst)
                     for (int64_t j = 0; j < longest; ++j)
-                        for (int g = 0; g < G; ++g) {
-                            uint32_t word = 0u;  // padding: index 0, ad = dp = 0
-                            if (j < seg_n[(size_t)g]) {
-                                const int64_t e = seg_lo[(size_t)g] + j * seg_step[(size_t)g];
-                                word = ((uint32_t)(idx[e] - base) << 22) |
-                                       ((uint32_t)val[e].x << 11) | (uint32_t)val[e].y;
-                            }
-                            dst[rel + j * G + g] = word;
-                        }
+                        for (int g = 0; g < G; ++g)  // padding: a zero word (value 0, offset 0)
+                            dst[rel + j * G + g] = j < (int64_t)segw[g].size() ? segw[g][(size_t)j] : 0u;
                 rel += longest * G;  // (a multiple of 64 words: streams stay 16-B aligned)
             }
         }
@@ -534,7 +554,8 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
     // variant pass (whose per-range partials also cost the theta kernel a wider read) only
     // ties at 8-16 M and wins clearly at 100 M.
     const int lds = env_int("VIREO_LDS", -1);
-    if (max_count < 2048 && lds != 0) {
+    const int cell_form = env_int("VIREO_CELL_FORM", 1);  // 1: AD/BD stream (any counts)
+    if ((max_count < 2048 || cell_form == 1) && lds != 0) {
         // cell pass: slabs of 512 W rows (128 KiB at K = 16); variant pass: 1024 ID rows
         if (lds == 1 || nnz >= (int64_t)env_int("VIREO_LDS_MIN_NNZ", 4000000)) {
             // One workgroup per CU at a time: a launch of W workgroups takes ceil(W / 256)
@@ -556,13 +577,16 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
                         (forced == 0 && n_slab_c <= 2 && cost(VRX_LDS_RW_CELL_SHORT) < cost(VRX_LDS_RW_CELL))
                     ? VRX_LDS_RW_CELL_SHORT
                     : VRX_LDS_RW_CELL;
-            rc = build_tiled(p->by_cell, colptr, rowidx, cval.data(), rw_cell, 512,
-                             lds != 1, p->stream);
-            if (rc) return rc;
+            if (cell_form == 1 || max_count < 2048) {
+                rc = build_tiled(p->by_cell, colptr, rowidx, cval.data(), rw_cell, 512,
+                                 lds != 1, cell_form == 1 ? 1 : 0, p->stream);
+                if (rc) return rc;
+            }
         }
-        if (lds == 1 || nnz >= (int64_t)env_int("VIREO_LDS_MIN_NNZ_VAR", 32000000)) {
+        if (max_count < 2048 &&
+            (lds == 1 || nnz >= (int64_t)env_int("VIREO_LDS_MIN_NNZ_VAR", 32000000))) {
             rc = build_tiled(p->by_var, rptr.data(), ridx.data(), rval.data(), VRX_LDS_RW_VARIANT,
-                             1024, lds != 1, p->stream);
+                             1024, lds != 1, 0, p->stream);
             if (rc) return rc;
         }
     }
@@ -641,7 +665,10 @@ struct vrx_model {
     int nb_theta = 0, nb_nk = 0, nb_cell = 0, nb_throws = 0, n_th_part = 1;
     DevBuf<double> part_theta, part_gt, part_cell, part_th;
     DevBuf<double> d_elbo, d_parts;
+    DevBuf<double> snapID, snapGT, snapTh;  // vrx_model_snapshot
+    bool snap_valid = false;
     double* h_pin = nullptr;  // pinned staging for scalar read-backs
+    int wform = 0;            // layout of W: 0 (W1, W2) pairs, 1 planar (Wa | Wb) rows (FORM 1)
     bool w_valid = false;     // W matches (GT, psi) on the device
     bool s_pending = false;   // S still sits in RV as per-range partials (sum fused downstream)
     bool l_pending = false;   // logLik_ID still sits in RC as per-range partials
@@ -747,6 +774,7 @@ extern "C" int vrx_model_create(vrx_problem* p, const vrx_model_cfg* cfg, vrx_mo
         if (lds_eligible<1>(p->by_cell, m->K) && (tc.n_range > 1 || tc.split))
             VRX_HIP(m->RC.alloc((size_t)(tc.n_range * tc.n_vrows * m->K)));
     }
+    m->wform = lds_eligible<1>(p->by_cell, m->K) && p->by_cell.tiled.form == 1 ? 1 : 0;
     // rows without entries are never written by the passes: zero once
     VRX_HIP(hipMemsetAsync(m->S.p, 0, (size_t)m->NK * 2 * sizeof(double), s));
     VRX_HIP(hipMemsetAsync(m->LID.p, 0, (size_t)(m->M * m->K) * sizeof(double), s));
@@ -810,6 +838,65 @@ extern "C" int vrx_model_set_state(vrx_model* m, const double* ID_prob, const do
     if ((rc = h2d(m, m->sm, beta_sum, (size_t)(m->th_rows * m->th_cols)))) return rc;
     VRX_HIP(hipStreamSynchronize(m->p->stream));
     m->w_valid = false;
+    return VRX_OK;
+}
+
+extern "C" int vrx_model_set_state_raw(vrx_model* m, const double* ID_raw, const double* GT_raw,
+                                       const double* beta_mu, const double* beta_sum) {
+    VRX_REQUIRE(m, "vrx_model_set_state_raw: null model");
+    if (m->K > 128 || m->T > 128) {
+        vrx_set_error("vrx_model_set_state_raw: more than 128 columns (normalise on the host)");
+        return VRX_ERR_UNSUPPORTED;
+    }
+    VRX_HIP(hipSetDevice(m->p->device));
+    hipStream_t s = m->p->stream;
+    int rc;
+    if ((rc = h2d(m, m->ID, ID_raw, (size_t)(m->M * m->K)))) return rc;
+    if (ID_raw) {
+        vrx_normalize_rows<<<(unsigned)((m->M + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
+            m->M, m->K, m->ID.p);
+        VRX_HIP(hipGetLastError());
+    }
+    if (m->cfg.kind == VRX_KIND_VIREO && GT_raw) {
+        if ((rc = h2d(m, m->GT, GT_raw, (size_t)m->NK * m->T))) return rc;
+        vrx_normalize_rows<<<(unsigned)((m->NK + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
+            m->NK, m->T, m->GT.p);
+        VRX_HIP(hipGetLastError());
+    }
+    if ((rc = h2d(m, m->mu, beta_mu, (size_t)(m->th_rows * m->th_cols)))) return rc;
+    if ((rc = h2d(m, m->sm, beta_sum, (size_t)(m->th_rows * m->th_cols)))) return rc;
+    VRX_HIP(hipStreamSynchronize(s));
+    m->w_valid = false;
+    return VRX_OK;
+}
+
+// device-side copy of the variational state: the best restart so far is kept in HBM, no
+// round trip through the host (vireo_wrap keeps `model_all[argmax]`, vireo_wrap.py:90-91)
+extern "C" int vrx_model_snapshot(vrx_model* m, int32_t restore) {
+    VRX_REQUIRE(m, "vrx_model_snapshot: null model");
+    VRX_HIP(hipSetDevice(m->p->device));
+    hipStream_t s = m->p->stream;
+    const size_t th = (size_t)(m->th_rows * m->th_cols);
+    if (restore) {
+        VRX_REQUIRE(m->snap_valid, "vrx_model_snapshot: nothing saved");
+    } else if (!m->snapID.p) {
+        VRX_HIP(m->snapID.alloc((size_t)(m->M * m->K)));
+        if (m->cfg.kind == VRX_KIND_VIREO) VRX_HIP(m->snapGT.alloc((size_t)m->NK * m->T));
+        VRX_HIP(m->snapTh.alloc(2 * th));
+    }
+    auto cp = [&](double* live, double* saved, size_t n) {
+        return restore ? hipMemcpyAsync(live, saved, n * sizeof(double), hipMemcpyDeviceToDevice, s)
+                       : hipMemcpyAsync(saved, live, n * sizeof(double), hipMemcpyDeviceToDevice, s);
+    };
+    VRX_HIP(cp(m->ID.p, m->snapID.p, (size_t)(m->M * m->K)));
+    if (m->cfg.kind == VRX_KIND_VIREO) VRX_HIP(cp(m->GT.p, m->snapGT.p, (size_t)m->NK * m->T));
+    VRX_HIP(cp(m->mu.p, m->snapTh.p, th));
+    VRX_HIP(cp(m->sm.p, m->snapTh.p + th, th));
+    VRX_HIP(hipStreamSynchronize(s));
+    if (restore)
+        m->w_valid = false;
+    else
+        m->snap_valid = true;
     return VRX_OK;
 }
 
@@ -952,9 +1039,21 @@ static auto lds_kernel_rw(int K, bool strided) {
     return pad ? vrx_spmm_lds<LPE, MODE, RW, true, 1> : vrx_spmm_lds<LPE, MODE, RW, false, 1>;
 }
 
+// the AD/BD form of the cell pass (FORM 1): one instance for K = 16, one that stages
+// element-wise and masks its stores for every other K / column block
+template <int RW>
+static auto lds_kernel_form1(bool pad) {
+    return pad ? vrx_spmm_lds<4, 1, RW, true, 1, 1> : vrx_spmm_lds<4, 1, RW, false, 1, 1>;
+}
+
 // rows per wave: the pass default, or (cell pass) the shorter tile of short_tile_pays()
 template <int LPE, int MODE>
-static auto lds_kernel(int K, bool strided, int rw) {
+static auto lds_kernel(int K, bool strided, int rw, int form) {
+    if (MODE == 1 && form == 1) {
+        const bool pad = K != 16 || strided;
+        return rw == VRX_LDS_RW_CELL_SHORT ? lds_kernel_form1<VRX_LDS_RW_CELL_SHORT>(pad)
+                                           : lds_kernel_form1<VRX_LDS_RW_CELL>(pad);
+    }
     if (MODE == 1 && rw == VRX_LDS_RW_CELL_SHORT)
         return lds_kernel_rw<LPE, MODE, MODE == 1 ? VRX_LDS_RW_CELL_SHORT : VRX_LDS_RW_VARIANT>(K, strided);
     return lds_kernel_rw<LPE, MODE, MODE == 1 ? VRX_LDS_RW_CELL : VRX_LDS_RW_VARIANT>(K, strided);
@@ -969,13 +1068,15 @@ static int launch_lds_one(const Orient& o, hipStream_t s, const double* X, int K
     // block, like the column chunks of the gather kernels)
     for (int c0 = 0; c0 < K; c0 += 16) {
         const int kb = std::min(16, K - c0);
-        const size_t lds = (size_t)t.slab_rows * ((kb + 3) & ~3) * (MODE == 1 ? 16 : 8) + 16 * VRX_RING * 4;
-        auto kern = lds_kernel<LPE, MODE>(kb, K > 16, t.rw);
+        const bool f1 = MODE == 1 && t.form == 1;  // planar operand, 256-B LDS rows
+        const size_t lds = (size_t)t.slab_rows * (f1 ? 256 : ((kb + 3) & ~3) * (MODE == 1 ? 16 : 8)) +
+                           16 * VRX_RING * 4;
+        auto kern = lds_kernel<LPE, MODE>(kb, K > 16, t.rw, t.form);
         VRX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         kern<<<grid, 1024, lds, s>>>(t.ent.p, t.wave_start.p, t.bnd.p, t.rowmap.p, t.n_slab,
-                                     t.slab_rows, o.n_contract, t.n_vrows, X + (size_t)c0 * XD, kb, K,
-                                     dst + (size_t)c0 * NV);
+                                     t.slab_rows, o.n_contract, t.n_vrows,
+                                     X + (size_t)c0 * (f1 ? 1 : XD), kb, K, dst + (size_t)c0 * NV);
         VRX_HIP(hipGetLastError());
     }
     return VRX_OK;
@@ -1101,8 +1202,8 @@ static int theta_step(vrx_model* m, int update) {
     if (c.kind == VRX_KIND_BMM) {
         vrx_bmm_theta<<<m->nb_nk, VRX_BLOCK, 0, s>>>(
             m->NK, update, c.fix_beta_sum, reinterpret_cast<const double2*>(m->S.p), m->prior1.p,
-            m->prior2.p, m->prior_rows == 1 ? 0 : 1, m->mu.p, m->sm.p,
-            reinterpret_cast<double2*>(m->W.p), m->part_th.p);
+            m->prior2.p, m->prior_rows == 1 ? 0 : 1, m->mu.p, m->sm.p, m->W.p, m->K, m->wform,
+            m->part_th.p);
         m->w_valid = true;
     } else if (c.ase_mode) {
         vrx_theta_ase<<<m->nb_throws, VRX_BLOCK, 0, s>>>(
@@ -1137,8 +1238,8 @@ static int gt_step(vrx_model* m, int learn) {
     }
     vrx_gt_update<<<m->nb_nk, VRX_BLOCK, 0, m->p->stream>>>(
         m->NK, m->K, m->T, learn, m->cfg.ase_mode, m->N, reinterpret_cast<const double2*>(m->S.p),
-        m->psi.p, m->logq_gt.p, m->gt_mode, -std::log((double)m->T), m->GT.p,
-        reinterpret_cast<double2*>(m->W.p), m->part_gt.p);
+        m->psi.p, m->logq_gt.p, m->gt_mode, -std::log((double)m->T), m->GT.p, m->W.p, m->wform,
+        m->part_gt.p);
     VRX_HIP(hipGetLastError());
     m->w_valid = true;
     return VRX_OK;
@@ -1351,6 +1452,8 @@ extern "C" int vrx_model_info(vrx_model* m, int32_t* info) {
     info[9] = c.tiled.ready ? (int32_t)(c.tiled.pad_ratio * 1000.0 + 0.5) : 0;
     info[10] = v.tiled.ready ? (int32_t)(v.tiled.n_vrows - v.n_rows) : 0;
     info[11] = c.tiled.ready ? (int32_t)(c.tiled.n_vrows - c.n_rows) : 0;
+    info[12] = c.tiled.ready ? c.tiled.form : 0;
+    info[13] = info[14] = info[15] = 0;
     return VRX_OK;
 }
 
@@ -1423,7 +1526,7 @@ extern "C" int vrx_problem_doublet(vrx_problem* p, int64_t n_donor, int64_t n_gt
     const int64_t n = p->n_var * C;
     vrx_doublet_w<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
         p->n_var, (int)n_donor, (int)n_gt, (int)C, psi_rows == 1 ? 0 : 1, gt.p, pairs.p, psi.p,
-        psi.p + th, psi.p + 2 * th, reinterpret_cast<double2*>(m->W.p));
+        psi.p + th, psi.p + 2 * th, m->W.p, m->wform);
     VRX_HIP(hipGetLastError());
     if ((rc = cell_pass(m))) return rc;
     if ((rc = d2h(m, logLik, m->LID, (size_t)(m->M * m->K)))) return rc;

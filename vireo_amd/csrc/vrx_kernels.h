@@ -307,7 +307,18 @@ constexpr int VRX_LDS_U = VRX_LDS_U_DEF;    // entries per trip and group; rows 
 // SPLIT: with K <= 8 (<= 4) a row needs only 2 (1) of the group's 4 lanes, so the group's lanes
 // take SPLIT = 2 (4) consecutive entries of the row at once, each into its own partial sums;
 // the partial sums are added across the lanes once, after the last slab (fixed order).
-template <int LPE, int MODE, int RW, bool PADK, int SPLIT>
+//
+// FORM 1 (cell pass, K = 16): the (ad, dp) pair of an entry is split into SINGLE-VALUED entries
+// of the two matrices the reference multiplies with (AD and BD = DP - AD,
+// vireo_model.py:190-196): LID = AD^T Wa + BD^T Wb with Wa = W1 + W2, Wb = W2.  On sequencing
+// data most entries have ad = 0 or ad = dp, so the split stream is only ~1.14x longer while
+// every entry reads 128 B of LDS instead of 256 B and costs 4 FMAs per lane instead of 8.
+// The dense operand is PLANAR: row n = [Wa[n][0..16) | Wb[n][0..16)] (256 B), an entry names
+// one half.  Word = value:15 (signed) | half-row byte offset:17 (a multiple of 128), so the
+// LDS address of a slice is one v_and_or_b32.  The two lane groups of a ds_read_b128 service
+// group that share a slice rotation read different halves whenever one walks AD entries and the
+// other BD entries, which the stream builder arranges (AD-first / BD-first segments).
+template <int LPE, int MODE, int RW, bool PADK, int SPLIT, int FORM = 0>
 __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     const uint32_t* __restrict__ ent, const int64_t* __restrict__ wave_start,
     const int32_t* __restrict__ bnd, const int32_t* __restrict__ rowmap, int n_slab,
@@ -319,14 +330,16 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     constexpr int NR = RW / G;             // rounds
     constexpr int XD = MODE == 1 ? 2 : 1;  // doubles per (contracted row, column)
     constexpr int CP = 16 / LPE;           // dense columns per lane (LPE lanes cover K <= 16)
-    constexpr int NQ = CP * XD / 2;        // 16-B reads per lane per entry
+    constexpr int NQ = FORM == 1 ? CP / 2 : CP * XD / 2;  // 16-B reads per lane per entry
     constexpr int PF = 8;                  // 16-B prefetch registers per thread: 128 KiB / 1024
     constexpr int NV = MODE == 0 ? 2 : 1;  // accumulated values per column
     constexpr int U = VRX_LDS_U;           // entries per trip and group
     static_assert(RW % G == 0 && RW / G < 63, "rows per wave");
+    static_assert(FORM == 0 || (MODE == 1 && LPE == 4 && SPLIT == 1), "AD/BD form");
     extern __shared__ __attribute__((aligned(16))) char vrx_smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int KP = (K + 3) & ~3;  // LDS rows are padded to a multiple of 4 columns (zeros)
+    // LDS rows are padded to a multiple of 4 columns (zeros); FORM 1: two halves of 16 columns
+    const int KP = FORM == 1 ? 16 : (K + 3) & ~3;
     const int slab_doubles = slab_rows * KP * XD;
     // LDS = [16 entry rings][slab]: the rings first, so that the LDS-DMA destinations stay
     // below 64 KiB
@@ -382,13 +395,18 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
                 pf[i] = at < n16 ? src[at] : make_double2(0.0, 0.0);
             }
         } else {
-            const double* src = X + row0 * ld * XD;
+            const double* src = X + row0 * ld * XD;  // (FORM 1: planar rows of 2 * ld doubles)
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
                 const int row = r0 + i * rstep;
                 double2 v = make_double2(0.0, 0.0);
                 if (pad_act && row < rows) {
-                    if (MODE == 1) {  // unit j0 = (w1, w2) of column j0
+                    if (FORM == 1) {  // unit j0 = columns 2*(j0 & 7), +1 of half j0 >> 3
+                        const int cc = 2 * (j0 & 7);
+                        const double* sr = src + (int64_t)row * 2 * ld + (j0 >> 3) * ld + cc;
+                        if (cc < K) v.x = sr[0];
+                        if (cc + 1 < K) v.y = sr[1];
+                    } else if (MODE == 1) {  // unit j0 = (w1, w2) of column j0
                         if (j0 < K) v = reinterpret_cast<const double2*>(src)[row * ld + j0];
                     } else {  // unit j0 = columns 2*j0, 2*j0 + 1
                         if (2 * j0 < K) v.x = src[row * ld + 2 * j0];
@@ -459,6 +477,17 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     };
     // one entry of this group's segment: word -> 4 column slices -> FMAs
     auto entry = [&](uint32_t w, double (&a)[NQ][2], double (&a2)[NQ][2]) {
+        if (FORM == 1) {  // one value, two adjacent columns per 16-B slice of a 128-B half row
+            const double v = (double)((int32_t)w >> 17);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const double2 x = *reinterpret_cast<const double2*>(
+                    reinterpret_cast<const char*>(slab) + ((w & 0x1ff80u) | qoff[q]));
+                a[q][0] = fma(v, x.x, a[q][0]);
+                a[q][1] = fma(v, x.y, a[q][1]);
+            }
+            return;
+        }
         const double ad = (double)((w >> 11) & 2047u), dp = (double)(w & 2047u);
         const uint32_t idx = w >> 22;  // < 1024 and row_bytes <= 256: 24-bit multiply-add
 #pragma unroll
@@ -545,7 +574,15 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     const int slice = kl * NQ + (q + g) % NQ;  // 16-B slice of the dense row
-                    if (MODE == 1) {
+                    if (FORM == 1) {  // columns 2*slice, 2*slice + 1 of logLik_ID
+                        double* o = dst + row * ld + 2 * slice;
+                        if (!PADK)
+                            *reinterpret_cast<double2*>(o) = make_double2(acc[r][q][0], acc[r][q][1]);
+                        else {
+                            if (2 * slice < K) o[0] = acc[r][q][0];
+                            if (2 * slice + 1 < K) o[1] = acc[r][q][1];
+                        }
+                    } else if (MODE == 1) {
                         if (!PADK || slice < K) dst[row * ld + slice] = acc[r][q][0];
                     } else {  // columns 2*slice, 2*slice+1; S[row][k] = (s1, ss)
                         double2* o = reinterpret_cast<double2*>(dst) + row * ld + 2 * slice;
@@ -820,6 +857,19 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_ase(int64_t N, int K, int
     block_sum_store<1>(kl, kl_part + blockIdx.x);
 }
 
+// One entry of the cell pass's dense operand.  wform 0: W[n][k] = (W1, W2) interleaved, used
+// with (ad, dp) pairs; wform 1: planar rows [Wa[n][0..K) | Wb[n][0..K)] with Wa = W1 + W2 (the
+// factor of AD) and Wb = W2 (the factor of BD = DP - AD), used by the AD/BD stream (FORM 1).
+__device__ __forceinline__ void vrx_store_w(double* W, int wform, int64_t n, int k, int K,
+                                            double w1, double w2, double wa) {
+    if (wform) {
+        W[n * 2 * K + k] = wa;
+        W[n * 2 * K + K + k] = w2;
+    } else {
+        reinterpret_cast<double2*>(W)[n * K + k] = make_double2(w1, w2);
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // genotype posterior  (Vireo.update_GT_prob, vireo_model.py:204-219) fused with the
 // W1/W2 tables of the cell pass and the KL(GT || prior) partial of get_ELBO (:238).
@@ -829,7 +879,7 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_ase(int64_t N, int K, int
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_gt_update(
     int64_t NK, int K, int T, int learn, int ase, int64_t N, const double2* __restrict__ S,
     const double* __restrict__ psi, const double* __restrict__ logq, int gt_mode, double logq_uni,
-    double* __restrict__ GT, double2* __restrict__ W, double* __restrict__ kl_part) {
+    double* __restrict__ GT, double* __restrict__ W, int wform, double* __restrict__ kl_part) {
 #pragma clang fp contract(off)
     const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
     double kl[1] = {0.0};
@@ -881,14 +931,15 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_gt_update(
                     if (g[t] > 0.0) kl[0] += g[t] * (log(g[t]) - lq[t]);
                 }
         }
-        double w1 = 0.0, w2 = 0.0;
+        double w1 = 0.0, w2 = 0.0, wa = 0.0;
 #pragma unroll
         for (int t = 0; t < VRX_MAXT; ++t)
             if (t < T) {
                 w1 += g[t] * (p1[t] - p2[t]);
                 w2 += g[t] * (p2[t] - ps[t]);
+                wa += g[t] * (p1[t] - ps[t]);
             }
-        W[i] = make_double2(w1, w2);
+        vrx_store_w(W, wform, n, k, K, w1, w2, wa);
     }
     block_sum_store<1>(kl, kl_part + blockIdx.x);
 }
@@ -907,7 +958,8 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_gt_update(
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_doublet_w(
     int64_t N, int K, int T, int C, int ase, const double* __restrict__ GT,
     const int2* __restrict__ pair, const double* __restrict__ psi1,
-    const double* __restrict__ psi2, const double* __restrict__ psis, double2* __restrict__ W) {
+    const double* __restrict__ psi2, const double* __restrict__ psis, double* __restrict__ W,
+    int wform) {
 #pragma clang fp contract(off)
     const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
     if (i >= N * C) return;
@@ -941,12 +993,13 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_doublet_w(
             }
         for (int g = 0; g < G; ++g) both[g] = both[g] / sum;
     }
-    double w1 = 0.0, w2 = 0.0;
+    double w1 = 0.0, w2 = 0.0, wa = 0.0;
     for (int g = 0; g < G; ++g) {
         w1 += both[g] * (p1[g] - p2[g]);
         w2 += both[g] * (p2[g] - ps[g]);
+        wa += both[g] * (p1[g] - ps[g]);
     }
-    W[i] = make_double2(w1, w2);
+    vrx_store_w(W, wform, n, c, C, w1, w2, wa);
 }
 
 // ------------------------------------------------------------------------------------
@@ -959,7 +1012,7 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_bmm_theta(int64_t NK, int updat
                                                            const double* __restrict__ prior1,
                                                            const double* __restrict__ prior2,
                                                            int prior_full, double* mu, double* sm,
-                                                           double2* __restrict__ W,
+                                                           double* __restrict__ W, int K, int wform,
                                                            double* __restrict__ kl_part) {
 #pragma clang fp contract(off)
     const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
@@ -978,7 +1031,7 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_bmm_theta(int64_t NK, int updat
         }
         const double s1 = m * s, s2 = (1.0 - m) * s;
         const double d1 = vrx_digamma(s1), d2 = vrx_digamma(s2), ds = vrx_digamma(s1 + s2);
-        W[i] = make_double2(d1 - d2, d2 - ds);
+        vrx_store_w(W, wform, i / K, (int)(i % K), K, d1 - d2, d2 - ds, d1 - ds);
         kl[0] = vrx_beta_kl(s1, s2, q1, q2, d1, d2, ds);
     }
     block_sum_store<1>(kl, kl_part + blockIdx.x);
@@ -1109,6 +1162,37 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_log_rows(int64_t rows, int C,
     double s = 0.0;
     for (int c = 0; c < C; ++c) s += p[r * C + c];
     for (int c = 0; c < C; ++c) logq[r * C + c] = log(p[r * C + c] / s);
+}
+
+// ------------------------------------------------------------------------------------
+// normalize(X) = X / X.sum(axis=-1, keepdims=True)  (vireo_base.py:44-55) of a freshly drawn
+// initial state, on the device.  The row sum follows NumPy's pairwise summation (the add-reduce
+// inner loop over a contiguous axis: a plain loop below 8 terms, eight running sums combined as
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus a sequential tail up to 128 terms), so the result
+// is bit-identical to the host's.  Thread per row; C <= 128.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_normalize_rows(int64_t rows, int C,
+                                                                double* __restrict__ X) {
+#pragma clang fp contract(off)
+    const int64_t r = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    if (r >= rows) return;
+    double* a = X + r * C;
+    double s;
+    if (C < 8) {
+        s = 0.0;
+        for (int i = 0; i < C; ++i) s += a[i];
+    } else {
+        double q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[j] = a[j];
+        int i = 8;
+        for (; i < C - (C % 8); i += 8)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q[j] += a[i + j];
+        s = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+        for (; i < C; ++i) s += a[i];
+    }
+    for (int i = 0; i < C; ++i) a[i] = a[i] / s;
 }
 
 // ------------------------------------------------------------------------------------

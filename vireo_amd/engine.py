@@ -66,6 +66,24 @@ class DeviceModel:
         _lib.check(_lib.lib().vrx_model_set_state(self._h, dptr(ID_prob), dptr(GT_prob),
                                                   dptr(beta_mu), dptr(beta_sum)))
 
+    def set_state_raw(self, ID_raw=None, GT_raw=None, beta_mu=None, beta_sum=None):
+        """upload un-normalised draws; normalised over the last axis on the device exactly
+        like ``normalize`` does on the host (vrx_model_set_state_raw)"""
+        ID_raw = self._check(ID_raw, (self.M, self.K), "ID_raw")
+        GT_raw = (self._check(GT_raw, (self.N, self.K, self.T), "GT_raw")
+                  if self.kind == _lib.KIND_VIREO else None)
+        beta_mu = self._check(beta_mu, self.theta_shape, "beta_mu")
+        beta_sum = self._check(beta_sum, self.theta_shape, "beta_sum")
+        _lib.check(_lib.lib().vrx_model_set_state_raw(self._h, dptr(ID_raw), dptr(GT_raw),
+                                                      dptr(beta_mu), dptr(beta_sum)))
+
+    def snapshot(self):
+        """keep the current state in a device-side slot"""
+        _lib.check(_lib.lib().vrx_model_snapshot(self._h, 0))
+
+    def restore(self):
+        _lib.check(_lib.lib().vrx_model_snapshot(self._h, 1))
+
     def get_state(self, want_GT=True):
         ID = np.empty((self.M, self.K))
         GT = np.empty((self.N, self.K, self.T)) if (want_GT and self.kind == _lib.KIND_VIREO) else None
@@ -123,13 +141,14 @@ class DeviceModel:
 
     def info(self):
         """which kernels / formats / tilings this model's passes use (vrx_model_info)"""
-        a = np.zeros(12, dtype=np.int32)
+        a = np.zeros(16, dtype=np.int32)
         _lib.check(_lib.lib().vrx_model_info(self._h, a.ctypes.data_as(C.POINTER(C.c_int32))))
         return dict(lds_variant=bool(a[0]), lds_cell=bool(a[1]), fmt_variant=int(a[2]),
                     fmt_cell=int(a[3]), tiles_variant=int(a[4]), tiles_cell=int(a[5]),
                     ranges_variant=int(a[6]), ranges_cell=int(a[7]),
                     pad_variant=a[8] / 1000.0, pad_cell=a[9] / 1000.0,
-                    extra_pieces_variant=int(a[10]), extra_pieces_cell=int(a[11]))
+                    extra_pieces_variant=int(a[10]), extra_pieces_cell=int(a[11]),
+                    cell_form=int(a[12]))
 
     # ---- timing -----------------------------------------------------------------------
     def profile(self, enable=True):

@@ -121,11 +121,15 @@ class Vireo():
         shape = (rows, self.n_GT)
         dm.set_state(self.ID_prob, self.GT_prob, np.broadcast_to(self.beta_mu, shape),
                      np.broadcast_to(self.beta_sum, shape))
-        GT_prior = self.GT_prior
-        if GT_prior.shape[0] != 1 and GT_prior.shape != self.GT_prob.shape:
-            GT_prior = np.broadcast_to(GT_prior, self.GT_prob.shape)
-        dm.set_prior(self.ID_prior, GT_prior, self.theta_s1_prior, self.theta_s2_prior)
+        self._set_device_prior(dm)
         return dm, counts
+
+    def _set_device_prior(self, dm):
+        GT_prior = self.GT_prior
+        full = (self.n_var, self.n_donor, self.n_GT)
+        if GT_prior.shape[0] != 1 and GT_prior.shape != full:
+            GT_prior = np.broadcast_to(GT_prior, full)
+        dm.set_prior(self.ID_prior, GT_prior, self.theta_s1_prior, self.theta_s2_prior)
 
     def _pull(self, dm, want_GT=True):
         ID, GT, mu, sm = dm.get_state(want_GT=want_GT)
