@@ -1,8 +1,9 @@
 """Worker of tests/test_host_cpu.py::test_sharded_wrap_gloo_world2 (one process per rank).
 
-The GPU fit is replaced by the CPU oracle (test infrastructure) so that the complete
-sharded control flow of vireo_amd.vireo_wrap -- RNG consumption on every rank, restart
-ownership, ELBO all-gather, winner broadcast -- runs on CPU with gloo."""
+The device restarts are replaced by the CPU oracle (test infrastructure) so that the complete
+sharded control flow of vireo_amd.vireo_wrap -- the C continuation of the NumPy random
+stream (drawn for owned restarts, skipped for the others), restart ownership, ELBO
+all-gather, winner broadcast -- runs on CPU with gloo."""
 import os
 import pickle
 import sys
@@ -20,44 +21,63 @@ def main(rank, world, port, out_path):
                             world_size=world)
     from oracle import vireo_oracle as O
     from tests import gold
+    from tests.gloo_comm import GlooComm
     import vireo_amd
     W = sys.modules["vireo_amd.vireo_wrap"]   # the package attribute is the function
-    from vireo_amd import Vireo
-    from vireo_amd.dist import GlooComm
 
     AD, DP = gold.c1()
     fake_counts = types.SimpleNamespace(shape=AD.shape, n_var=AD.shape[0], n_cell=AD.shape[1])
     fitted = []
+    STATE = ("ID_prob", "GT_prob", "beta_mu", "beta_sum", "ELBO_")
 
-    def to_oracle(self):
-        st = O.vireo_new(self.n_cell, self.n_var, self.n_donor, n_GT=self.n_GT,
-                         learn_GT=self.learn_GT, learn_theta=self.learn_theta,
-                         ASE_mode=self.ASE_mode, fix_beta_sum=self.fix_beta_sum,
-                         ID_prob_init=np.ones((self.n_cell, self.n_donor)),
-                         GT_prob_init=np.ones((self.n_var, self.n_donor, self.n_GT)))
-        for k in ("ID_prob", "GT_prob", "beta_mu", "beta_sum", "ID_prior", "GT_prior",
-                  "theta_s1_prior", "theta_s2_prior", "ELBO_"):
-            setattr(st, k, getattr(self, k))
+    def to_oracle(m):
+        st = O.vireo_new(m.n_cell, m.n_var, m.n_donor, n_GT=m.n_GT,
+                         learn_GT=m.learn_GT, learn_theta=m.learn_theta,
+                         ASE_mode=m.ASE_mode, fix_beta_sum=m.fix_beta_sum,
+                         ID_prob_init=np.ones((m.n_cell, m.n_donor)),
+                         GT_prob_init=np.ones((m.n_var, m.n_donor, m.n_GT)))
+        for k in STATE + ("ID_prior", "GT_prior", "theta_s1_prior", "theta_s2_prior"):
+            setattr(st, k, getattr(m, k))
         return st
 
-    def from_oracle(self, st):
-        for k in ("ID_prob", "GT_prob", "beta_mu", "beta_sum", "ELBO_"):
-            setattr(self, k, getattr(st, k))
+    class OracleRestarts:
+        """vireo_amd.restarts.DeviceRestarts with the device model replaced by the CPU oracle"""
 
-    def fake_fit(self, counts, _dp, max_iter=200, min_iter=5, epsilon_conv=1e-2,
-                 delay_fit_theta=0, verbose=True, **_):
-        st = to_oracle(self)
-        O.vireo_fit(st, AD, DP, max_iter, min_iter, epsilon_conv, delay_fit_theta)
-        from_oracle(self, st)
-        fitted.append(len(self.ELBO_))
+        def __init__(self, counts, template):
+            self.t, self.best = template, None
+
+        def run(self, im, ID_raw, GT_raw, ID_fixed, GT_fixed, max_iter, delay_fit_theta):
+            st = to_oracle(self.t)
+            st.ID_prob = O.unit_sum(ID_raw) if ID_raw is not None else ID_fixed
+            st.GT_prob = O.unit_sum(GT_raw) if GT_raw is not None else GT_fixed
+            st.ELBO_ = np.zeros(0)
+            O.vireo_fit(st, AD, DP, max_iter, 5, 1e-2, delay_fit_theta)
+            fitted.append(im)
+            if self.best is None or st.ELBO_[-1] > self.best[0]:
+                self.best = (st.ELBO_[-1], im, st)
+            return st.ELBO_[-1]
+
+        def winner(self, im, refine):
+            assert self.best[1] == im
+            st = self.best[2]
+            if refine:
+                O.vireo_fit(st, AD, DP, 200, 5, 1e-2, 0)
+                fitted.append(-1)
+            for k in STATE:
+                setattr(self.t, k, getattr(st, k))
+            return self.t
+
+        def close(self):
+            pass
 
     def fake_doublet(vobj, counts, _dp):
         st = to_oracle(vobj)
         r = O.vireo_doublet(st, AD, DP)
-        from_oracle(vobj, st)
+        for k in STATE:
+            setattr(vobj, k, getattr(st, k))
         return r
 
-    Vireo.fit = fake_fit
+    W.DeviceRestarts = OracleRestarts
     W.predict_doublet = fake_doublet
     W.device_counts = lambda a, b=None: fake_counts
     import io

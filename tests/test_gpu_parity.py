@@ -467,3 +467,86 @@ def test_determinism(va):
         runs.append((m.ELBO_.copy(), m.ID_prob.copy(), m.GT_prob.copy()))
     for a, b in zip(runs[0], runs[1]):
         assert np.array_equal(a, b)          # fixed-order reductions: bitwise reproducible
+
+
+# ---------------------------------------------------------------- restart plumbing
+@pytest.mark.parametrize("K,T", [(4, 3), (16, 3), (7, 2), (9, 5), (20, 3), (100, 3)])
+def test_device_normalise_is_numpys(va, K, T):
+    """vrx_model_set_state_raw: raw draws normalised on the device over the last axis are
+    bit-identical to normalize() on the host (NumPy's pairwise row sum, vireo_base.py:44-55)"""
+    from vireo_amd import _lib
+    from vireo_amd.counts import DeviceCounts
+    from vireo_amd.engine import DeviceModel
+    AD, DP = O.synth_donor(300, 200, 3, 0.05, seed=3)
+    dm = DeviceModel(DeviceCounts(AD, DP), _lib.KIND_VIREO, K, n_gt=T)
+    rng = np.random.default_rng(K * 10 + T)
+    ID, GT = rng.random((200, K)), rng.random((300, K, T))
+    mu, sm = np.linspace(0.01, 0.99, T)[None, :], np.full((1, T), 50.0)
+    dm.set_state_raw(ID, GT, mu, sm)
+    gID, gGT, gmu, gsm = dm.get_state()
+    assert np.array_equal(gID, va.normalize(ID))
+    assert np.array_equal(gGT, va.normalize(GT))
+    assert np.array_equal(gmu, mu) and np.array_equal(gsm, sm)
+
+
+def test_snapshot_restore_and_restart_runner(va):
+    """the best restart stays in HBM: DeviceRestarts over 4 restarts == 4 independent Vireo
+    fits from the same draws, bit for bit, winner included"""
+    from vireo_amd.restarts import DeviceRestarts, LegacyStream
+    from vireo_amd.vireo_wrap import _template
+    AD, DP = gold.c1()
+    counts = va.device_counts(AD, DP)
+    N, M, K = AD.shape[0], AD.shape[1], 4
+    np.random.seed(2)
+    singles = []
+    for _ in range(4):
+        m = va.Vireo(n_var=N, n_cell=M, n_donor=K)
+        m.fit(counts, None, min_iter=5, max_iter=20, delay_fit_theta=3, verbose=False)
+        singles.append(m)
+    np.random.seed(2)
+    st, run = LegacyStream(), DeviceRestarts(counts, _template(counts, K, True, None, {}))
+    elbos = [run.run(i, st.rand(M, K), st.rand(N, K, 3), None, None, 20, 3) for i in range(4)]
+    assert elbos == [m.ELBO_[-1] for m in singles]
+    best = int(np.argmax(elbos))
+    win = run.winner(best, refine=False)
+    for name in ("ID_prob", "GT_prob", "beta_mu", "beta_sum", "ELBO_"):
+        assert np.array_equal(getattr(win, name), getattr(singles[best], name)), name
+    g = gold.load("c1_wrap_seed2_init4")
+    close(np.array(elbos), g["LB_list"], rtol=1e-9)
+
+
+def test_count_cache_notices_inplace_edits(va):
+    """the (AD, DP) -> device cache is keyed on object identity AND buffer contents"""
+    from vireo_amd import counts as C
+    C.clear_cache()
+    AD, DP = O.synth_donor(400, 300, 3, 0.05, seed=1)
+    a = va.device_counts(AD, DP)
+    assert va.device_counts(AD, DP) is a
+    j = np.flatnonzero(np.diff(DP.indptr) >= 2)[0]           # a column with two entries:
+    lo = DP.indptr[j]                                         # swap their values (same sum)
+    DP.data[lo], DP.data[lo + 1] = DP.data[lo + 1] + 1, DP.data[lo] - 1
+    AD.data[:] = np.minimum(AD.data, 0)
+    b = va.device_counts(AD, DP)
+    assert b is not a
+    AD2, DP2 = AD.copy(), DP.copy()
+    assert va.device_counts(AD2, DP2) is not b               # equal content, other objects
+    C.clear_cache()
+
+
+def test_bmm_prior_that_differs_per_clone(va):
+    """a (1, n_donor) Beta prior broadcasts over the variants (bmm_model.py:92-98)"""
+    AD, DP = gold.mito()
+    N, M, K = AD.shape[0], AD.shape[1], 3
+    mu = np.array([[0.2, 0.5, 0.7]])
+    sm = np.array([[2.0, 4.0, 3.0]])
+    np.random.seed(4)
+    ref = O.bmm_new(M, N, K)
+    ID0 = ref.ID_prob.copy()
+    ref.theta_s1_prior, ref.theta_s2_prior = mu * sm, (1 - mu) * sm
+    O.bmm_fit_vb(ref, AD, DP, max_iter=8, min_iter=3)
+    dev = va.BinomMixtureVB(n_var=N, n_cell=M, n_donor=K, ID_prob_init=ID0)
+    dev.set_prior(beta_mu_prior=mu, beta_sum_prior=sm)
+    dev._fit_BV(AD, DP, max_iter=8, min_iter=3, verbose=False)
+    close(dev.ELBO_iters, ref.ELBO_iters)
+    close(dev.beta_mu, ref.beta_mu)
+    close(dev.ID_prob, ref.ID_prob)

@@ -195,3 +195,81 @@ def test_socket_exchange_world3():
     for p in procs:
         p.join(timeout=30)
     assert got == {0: payload, 1: payload, 2: payload}
+
+
+def test_legacy_stream_continues_numpy_bit_for_bit():
+    """vrx_mt19937_random_sample (host C): the doubles np.random.rand would give, at every
+    alignment of the 624-word state, mixed with skips and with real np.random calls."""
+    from vireo_amd.restarts import LegacyStream
+    st = LegacyStream()
+    for seed in (0, 2, 987654321):
+        shapes = [(5,), (1,), (311, 1), (2, 156), (313,), (4, 5, 3), (7919,), (0,), (3,)]
+        np.random.seed(seed)
+        want = [np.random.rand(*sh) for sh in shapes]
+        tail = np.random.rand(4)
+        np.random.seed(seed)
+        got = [st.rand(*sh) for sh in shapes]
+        assert all(np.array_equal(a, b) for a, b in zip(want, got))
+        assert np.array_equal(np.random.rand(4), tail)        # numpy continues where C stopped
+        np.random.seed(seed)
+        for i, sh in enumerate(shapes):                       # skipping == drawing and dropping
+            if i % 2:
+                st.skip(int(np.prod(sh)))
+            else:
+                assert np.array_equal(st.rand(*sh), want[i])
+        assert np.array_equal(st.rand(4), tail)
+
+
+def test_models_pickle_without_device_handles():
+    """reference models are plain NumPy objects that travel through multiprocessing.Pool
+    (vireo_wrap.py:74-83); the device-problem handle a fitted model remembers must not break that"""
+    import vireo_amd
+    np.random.seed(0)
+    m = vireo_amd.Vireo(n_cell=20, n_var=30, n_donor=3)
+    m._last_counts = ctypes.c_void_p(1234)        # what a fit leaves behind (unpicklable)
+    back = pickle.loads(pickle.dumps(m))
+    assert not hasattr(back, "_last_counts")
+    assert np.array_equal(back.ID_prob, m.ID_prob) and np.array_equal(back.GT_prob, m.GT_prob)
+
+
+def test_package_surface_matches_the_reference():
+    """names a user of `import vireoSNP` finds at the top level (vireoSNP/__init__.py:3-15;
+    VireoBulk / plot are out of scope) and the console script"""
+    import vireo_amd
+    for name in ("__version__", "vcf", "base", "model", "load_VCF", "match_SNPs", "read_cellSNP",
+                 "read_vartrix", "normalize", "loglik_amplify", "get_binom_coeff", "match",
+                 "optimal_match", "vireo_wrap", "Vireo", "BinomMixtureVB"):
+        assert hasattr(vireo_amd, name), name
+    text = open(os.path.join(ROOT, "pyproject.toml")).read()
+    assert 'vireo = "vireo_amd.vireo:main"' in text
+    AD, DP = gold.c1()
+    c = vireo_amd.get_binom_coeff(AD, DP)
+    assert c.dtype == np.float32 and c.shape == (1, int((DP > 0).sum()))
+    g = gold.load("binom_const")
+    assert np.float32(np.sum(c)) == np.float32(g["c1"])     # summed like vireo_model.py:313
+    t1 = np.array([[0.3, 29.7], [3, 3], [29.7, 0.3]])
+    t2 = np.array([[364, 24197], [5886, 7475], [6075, 397.]])
+    assert vireo_amd.beta_entropy(t2, t1) > 0 and vireo_amd.beta_entropy(t1, t1) == 0
+
+
+def test_socket_rendezvous_ignores_strangers():
+    """the unique-id exchange serves each rank once and survives a stray connection"""
+    import threading
+    import time
+    from vireo_amd.dist import socket_exchange
+    port, res = _free_port(), {}
+
+    def run(r):
+        res[r] = socket_exchange(r, 3, addr="127.0.0.1", port=port, timeout=30)(
+            bytes(range(128)) if r == 0 else None)
+    threads = [threading.Thread(target=run, args=(0,))]
+    threads[0].start()
+    time.sleep(0.3)
+    with socket.create_connection(("127.0.0.1", port)) as s:
+        s.sendall(b"port probe")
+    for r in (1, 2):
+        threads.append(threading.Thread(target=run, args=(r,)))
+        threads[-1].start()
+    for t in threads:
+        t.join()
+    assert res == {r: bytes(range(128)) for r in range(3)}

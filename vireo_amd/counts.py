@@ -130,18 +130,39 @@ class DeviceCounts:
 
 
 # (AD, DP) -> DeviceCounts.  vireo_wrap calls fit() n_init+1 times on the same matrices
-# (vireo_wrap.py:84-94); upload once.  Keyed on object identity + buffer addresses + a
-# content checksum so that in-place edits are noticed.
-_cache = {}
+# (vireo_wrap.py:84-94); upload once.  A cached entry is reused only for the SAME objects
+# (held by weak reference: an entry dies with its matrices, so a recycled id() or buffer
+# address can never hit it) whose buffers still hash to what was uploaded (in-place edits of
+# data, indices or indptr are noticed).
+_cache = []          # [(ref(AD), ref(DP) or None, device, digest, DeviceCounts)]
 _CACHE_MAX = 2
 
 
-def _fingerprint(X):
-    if issparse(X):
-        return (id(X), X.shape, X.nnz, X.data.ctypes.data if X.nnz else 0,
-                float(X.data.sum()) if X.nnz else 0.0, X.format)
-    X = np.asarray(X)
-    return (id(X), X.shape, X.ctypes.data, float(X.sum()))
+def _hasher():
+    try:
+        import xxhash
+        return xxhash.xxh3_64()
+    except ImportError:         # pragma: no cover
+        import hashlib
+        return hashlib.blake2b(digest_size=8)
+
+
+def _digest(*mats):
+    """position-sensitive content hash of the matrices' buffers (and shapes / formats)"""
+    h = _hasher()
+    for X in mats:
+        if X is None:
+            h.update(b"none")
+        elif issparse(X):
+            h.update(("%s%s" % (X.format, X.shape)).encode())
+            for part in (X.data, X.indices, X.indptr) if X.format in ("csc", "csr") else \
+                    (X.tocsc().data,):
+                h.update(np.ascontiguousarray(part).view(np.uint8))
+        else:
+            A = np.ascontiguousarray(X)
+            h.update(("dense%s%s" % (A.shape, A.dtype)).encode())
+            h.update(A.view(np.uint8).reshape(-1))
+    return h.hexdigest()
 
 
 def default_device():
@@ -157,16 +178,23 @@ def device_counts(AD, DP=None, device=None):
         return AD
     if device is None:
         device = default_device()
-    key = (_fingerprint(AD), _fingerprint(DP), device)
-    hit = _cache.get(key)
-    if hit is not None:
-        return hit
+    _cache[:] = [e for e in _cache if e[0]() is not None and (e[1] is None or e[1]() is not None)]
+    digest = None
+    for ra, rd, dev, dig, dc in _cache:
+        if ra() is AD and (rd() if rd is not None else None) is DP and dev == device:
+            digest = digest or _digest(AD, DP)
+            if dig == digest:
+                return dc
     dc = DeviceCounts(AD, DP, device=device)
-    while len(_cache) >= _CACHE_MAX:      # evicted handles die with their last reference
-        _cache.pop(next(iter(_cache)))
-    _cache[key] = dc
+    try:
+        entry = (weakref.ref(AD), weakref.ref(DP) if DP is not None else None, device,
+                 digest or _digest(AD, DP), dc)
+    except TypeError:            # not weak-referenceable (a list, ...): do not cache
+        return dc
+    del _cache[:max(0, len(_cache) - _CACHE_MAX + 1)]   # evicted handles die with their last reference
+    _cache.append(entry)
     return dc
 
 
 def clear_cache():
-    _cache.clear()
+    del _cache[:]

@@ -252,12 +252,9 @@ static int build_orient(Orient& o, int64_t n_rows, int64_t n_contract, const int
 //
 // form 1 (cell pass): every (ad, dp) entry becomes single-valued entries of AD and of
 // BD = DP - AD (none for a zero, several for a value outside 15 signed bits), see FORM 1 in
-// vrx_kernels.h.  Word = value:15 | (2 * slab-local index + half) * 128.  Lane groups g with
-// g % 8 < 4 walk a segment's AD entries first, the others its BD entries first: the two groups
-// that share a slice rotation inside a ds_read_b128 service group then read different halves
-// (different banks) except where their AD / BD counts differ.
+// vrx_kernels.h.  Word = value:15 | (2 * slab-local index + half) * 128.
 static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const int2* val,
-                       int RW, int slab_rows, bool guard, int form, hipStream_t s) {
+                       int RW, int slab_rows, bool guard, int form, int mode, hipStream_t s) {
     constexpr int G = 64 / VRX_LDS_LPE, U = VRX_LDS_U;
     const int NR = RW / G;
     TiledStream& t = o.tiled;
@@ -322,6 +319,9 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
     // One wave's stream: walks its RW pieces slab by slab; pass 1 (dst == nullptr) records the
     // (slab, round) offsets and the length, pass 2 writes the words.  Waves are independent.
     const bool parity_order = env_int("VIREO_LDS_PARITY", 1) != 0;
+    // the entry bit that selects the LDS bank half of a 128-B dense row: half (form 1), parity
+    // of the slab-local index (variant pass); none for the 256-B rows of the (ad, dp) cell pass
+    const int bit_shift = form == 1 ? 7 : (mode == 0 ? 22 : -1);
     auto push_value = [](std::vector<uint32_t>& out, int64_t v, uint32_t off) {
         while (v != 0) {  // chunks of 15 signed bits (counts past 16383 are rare: clone mode)
             const int64_t c = std::max<int64_t>(-16384, std::min<int64_t>(16383, v));
@@ -362,18 +362,58 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
                                 sw.push_back(((uint32_t)(idx[e] - base) << 22) |
                                              ((uint32_t)val[e].x << 11) | (uint32_t)val[e].y);
                         } else {
-                            const bool bd_first = parity_order && (g % 8) >= 4;
-                            second.clear();
                             for (int64_t e = seg + off; e < hi; e += step) {
                                 const uint32_t at = (uint32_t)(idx[e] - base) * 256u;
                                 const int64_t ad = val[e].x, bd = (int64_t)val[e].y - val[e].x;
-                                push_value(bd_first ? second : sw, ad, at);
-                                push_value(bd_first ? sw : second, bd, at + 128u);
+                                push_value(sw, ad, at);
+                                push_value(sw, bd, at + 128u);
                             }
-                            sw.insert(sw.end(), second.begin(), second.end());
                         }
                     }
                     longest = std::max<int64_t>(longest, (int64_t)sw.size());
+                }
+                // Bank conflicts.  The dense rows are 128 B (ID_prob rows; the AD / BD half
+                // rows), so the LDS bank of a slice depends on one address bit of the entry
+                // (index parity / half).  ds_read_b128 serves lane groups {0,3,5,6}, {1,2,4,7}
+                // (+8) together, and the two groups with the same slice rotation (g & 1) collide
+                // whenever that bit agrees.  The order of a segment's entries is free, and the
+                // zero words that pad a segment to the round's length can point at either
+                // parity: group P walks its bit-0 entries (then bit-0 padding) up to a split
+                // position z and its bit-1 entries after it, its partner Q the other way round.
+                // z exists whenever the pair's bit-0 entries and its bit-1 entries each fit
+                // into the round, i.e. almost always.
+                if (parity_order && bit_shift >= 0) {
+                    for (int g = 0; g < G; ++g) {
+                        // the group that shares g's rotation inside g's service group holds
+                        // lanes ^ 24 (ds_read_b128: {0-3,12-15,20-27}, {4-11,16-19,28-31}, +32)
+                        const int q = g ^ (24 / VRX_LDS_LPE);
+                        if (q < g) continue;
+                        std::vector<uint32_t> part[2][2];  // [P / Q][bit]
+                        for (int m = 0; m < 2; ++m)
+                            for (uint32_t wd : segw[m ? q : g]) part[m][(wd >> bit_shift) & 1u].push_back(wd);
+                        const int64_t p0 = (int64_t)part[0][0].size(), p1 = (int64_t)part[0][1].size();
+                        const int64_t q0 = (int64_t)part[1][0].size(), q1 = (int64_t)part[1][1].size();
+                        const int64_t zlo = std::max(p0, q1), zhi = std::min(longest - p1, longest - q0);
+                        if (zlo > zhi) {  // does not fit: opposite orders, as far as that goes
+                            segw[g] = part[0][0];
+                            segw[g].insert(segw[g].end(), part[0][1].begin(), part[0][1].end());
+                            segw[q] = part[1][1];
+                            segw[q].insert(segw[q].end(), part[1][0].begin(), part[1][0].end());
+                            continue;
+                        }
+                        const int64_t z = (zlo + zhi) / 2;
+                        const uint32_t pad1 = 1u << bit_shift;
+                        auto lay = [&](std::vector<uint32_t>& out, const std::vector<uint32_t>& first,
+                                       uint32_t pad_first, const std::vector<uint32_t>& rest,
+                                       uint32_t pad_rest) {
+                            out = first;
+                            out.resize((size_t)z, pad_first);
+                            out.insert(out.end(), rest.begin(), rest.end());
+                            out.resize((size_t)longest, pad_rest);
+                        };
+                        lay(segw[g], part[0][0], 0u, part[0][1], pad1);
+                        lay(segw[q], part[1][1], pad1, part[1][0], 0u);
+                    }
                 }
                 // offset | entries in the last trip (0 = full): the kernel skips the padding
                 bw[(int64_t)sl * NR + r] = (int32_t)(rel | (longest % U));
@@ -578,15 +618,17 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
                     ? VRX_LDS_RW_CELL_SHORT
                     : VRX_LDS_RW_CELL;
             if (cell_form == 1 || max_count < 2048) {
-                rc = build_tiled(p->by_cell, colptr, rowidx, cval.data(), rw_cell, 512,
-                                 lds != 1, cell_form == 1 ? 1 : 0, p->stream);
+                rc = build_tiled(p->by_cell, colptr, rowidx, cval.data(), rw_cell,
+                                 std::min(512, std::max(16, env_int("VIREO_LDS_SLAB_CELL", 512))),
+                                 lds != 1, cell_form == 1 ? 1 : 0, 1, p->stream);
                 if (rc) return rc;
             }
         }
         if (max_count < 2048 &&
             (lds == 1 || nnz >= (int64_t)env_int("VIREO_LDS_MIN_NNZ_VAR", 32000000))) {
             rc = build_tiled(p->by_var, rptr.data(), ridx.data(), rval.data(), VRX_LDS_RW_VARIANT,
-                             1024, lds != 1, 0, p->stream);
+                             std::min(1024, std::max(16, env_int("VIREO_LDS_SLAB_VAR", 1024))),
+                             lds != 1, 0, 0, p->stream);
             if (rc) return rc;
         }
     }
@@ -1030,12 +1072,14 @@ static bool lds_eligible(const Orient& o, int K) {
 template <int LPE, int MODE, int RW>
 static auto lds_kernel_rw(int K, bool strided) {
     static const int split_on = env_int("VIREO_LDS_SPLIT_K", 1);
-    const int split = !split_on ? 1 : K <= 4 ? 4 : K <= 8 ? 2 : 1;
+    const int split = std::min(LPE, !split_on ? 1 : K <= 4 ? 4 : K <= 8 ? 2 : 1);
     const bool pad = K % 4 != 0 || strided;  // (the element-wise slab copy handles row strides)
-    if (split == 4)
-        return pad ? vrx_spmm_lds<LPE, MODE, RW, true, 4> : vrx_spmm_lds<LPE, MODE, RW, false, 4>;
-    if (split == 2)
-        return pad ? vrx_spmm_lds<LPE, MODE, RW, true, 2> : vrx_spmm_lds<LPE, MODE, RW, false, 2>;
+    if constexpr (LPE >= 4)
+        if (split == 4)
+            return pad ? vrx_spmm_lds<LPE, MODE, RW, true, 4> : vrx_spmm_lds<LPE, MODE, RW, false, 4>;
+    if constexpr (LPE >= 2)
+        if (split == 2)
+            return pad ? vrx_spmm_lds<LPE, MODE, RW, true, 2> : vrx_spmm_lds<LPE, MODE, RW, false, 2>;
     return pad ? vrx_spmm_lds<LPE, MODE, RW, true, 1> : vrx_spmm_lds<LPE, MODE, RW, false, 1>;
 }
 
@@ -1043,7 +1087,7 @@ static auto lds_kernel_rw(int K, bool strided) {
 // element-wise and masks its stores for every other K / column block
 template <int RW>
 static auto lds_kernel_form1(bool pad) {
-    return pad ? vrx_spmm_lds<4, 1, RW, true, 1, 1> : vrx_spmm_lds<4, 1, RW, false, 1, 1>;
+    return pad ? vrx_spmm_lds<VRX_LDS_LPE, 1, RW, true, 1, 1> : vrx_spmm_lds<VRX_LDS_LPE, 1, RW, false, 1, 1>;
 }
 
 // rows per wave: the pass default, or (cell pass) the shorter tile of short_tile_pays()

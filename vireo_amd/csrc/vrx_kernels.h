@@ -292,6 +292,21 @@ constexpr int VRX_CHUNK = 256;  // entries per refill (64 lanes x 16 B of one LD
 #ifndef VRX_LDS_U_DEF
 #define VRX_LDS_U_DEF 4
 #endif
+#ifndef VRX_F1_SCHED
+#define VRX_F1_SCHED 0
+#endif
+#ifndef VRX_LDS_L2PF
+#define VRX_LDS_L2PF 0
+#endif
+#ifndef VRX_L2PF_AHEAD
+#define VRX_L2PF_AHEAD 2
+#endif
+#ifndef VRX_LDS_PRIO
+#define VRX_LDS_PRIO 0
+#endif
+#ifndef VRX_F1_ANDOR
+#define VRX_F1_ANDOR 0
+#endif
 // output rows per wave (tile = 16 x this), per pass: measured best on MI355X at c3
 #ifndef VRX_LDS_LPE_DEF
 #define VRX_LDS_LPE_DEF 4
@@ -299,7 +314,7 @@ constexpr int VRX_CHUNK = 256;  // entries per refill (64 lanes x 16 B of one LD
 #define VRX_LDS_RWC_DEF 48
 #endif
 constexpr int VRX_LDS_RW_VARIANT = VRX_LDS_RWV_DEF, VRX_LDS_RW_CELL = VRX_LDS_RWC_DEF;
-constexpr int VRX_LDS_RW_CELL_SHORT = 32;  // cell pass with one or two slabs, see vrx_problem_create
+constexpr int VRX_LDS_RW_CELL_SHORT = VRX_LDS_LPE_DEF == 1 ? 64 : 32;  // cell pass with one or two slabs, see vrx_problem_create
 constexpr int VRX_LDS_LPE = VRX_LDS_LPE_DEF;  // lanes per output row (16 / this columns per lane)
 constexpr int VRX_LDS_U = VRX_LDS_U_DEF;    // entries per trip and group; rows are padded to it
 
@@ -319,7 +334,11 @@ constexpr int VRX_LDS_U = VRX_LDS_U_DEF;    // entries per trip and group; rows 
 // group that share a slice rotation read different halves whenever one walks AD entries and the
 // other BD entries, which the stream builder arranges (AD-first / BD-first segments).
 template <int LPE, int MODE, int RW, bool PADK, int SPLIT, int FORM = 0>
-__global__ __launch_bounds__(1024) void vrx_spmm_lds(
+__global__ __launch_bounds__(1024)
+#if VRX_LDS_L2PF
+    __attribute__((amdgpu_num_vgpr(120)))
+#endif
+    void vrx_spmm_lds(
     const uint32_t* __restrict__ ent, const int64_t* __restrict__ wave_start,
     const int32_t* __restrict__ bnd, const int32_t* __restrict__ rowmap, int n_slab,
     int slab_rows, int64_t n_contract, int64_t n_rows, const double* __restrict__ X, int K,
@@ -335,9 +354,26 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     constexpr int NV = MODE == 0 ? 2 : 1;  // accumulated values per column
     constexpr int U = VRX_LDS_U;           // entries per trip and group
     static_assert(RW % G == 0 && RW / G < 63, "rows per wave");
-    static_assert(FORM == 0 || (MODE == 1 && LPE == 4 && SPLIT == 1), "AD/BD form");
+    static_assert(FORM == 0 || (MODE == 1 && SPLIT == 1), "AD/BD form");
     extern __shared__ __attribute__((aligned(16))) char vrx_smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#if VRX_LDS_PRIO == 1
+    // waves w, w+4, w+8, w+12 share a SIMD: distinct issue priorities skew them so that one
+    // wave's LDS phase overlaps another's FMA phase
+    switch (wave >> 2) {
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        case 3: __builtin_amdgcn_s_setprio(3); break;
+        default: break;
+    }
+#elif VRX_LDS_PRIO == 2
+    switch (wave & 3) {
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        case 3: __builtin_amdgcn_s_setprio(3); break;
+        default: break;
+    }
+#endif
     // LDS rows are padded to a multiple of 4 columns (zeros); FORM 1: two halves of 16 columns
     const int KP = FORM == 1 ? 16 : (K + 3) & ~3;
     const int slab_doubles = slab_rows * KP * XD;
@@ -458,6 +494,20 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
             : "v"(gsrc), "s"(dst)
             : "memory");
         issued_end = pos + VRX_CHUNK;
+#if VRX_LDS_L2PF
+        // One 1-KiB chunk in flight per wave (16 KiB per CU, 4 MiB on the chip) cannot cover the
+        // HBM latency at the rate the walk consumes the stream (Little: 4 MiB / ~2 us = 2 TB/s).
+        // A plain load touches every 128-B line of the chunk two further ahead, so that the
+        // LDS-DMA of that chunk later hits L2.  Its result is never used; it is always the
+        // YOUNGEST vector-memory operation after a DMA, which is what lets ring_need wait with
+        // vmcnt(1) for every DMA without waiting for the prefetch itself.
+        // (v127 is outside the register budget given to the compiler -- amdgpu_num_vgpr(120) --
+        //  so a result that lands thousands of cycles later can never hit a live value)
+        {
+            const uint32_t* psrc = stream + min(pos + VRX_L2PF_AHEAD * VRX_CHUNK + 4 * lane, clamp_last);
+            asm volatile("global_load_dword v127, %0, off" : : "v"(psrc) : "memory", "v127");
+        }
+#endif
     };
     if (base0 < stream_end) dma_issue(base0);
     if (base0 + VRX_CHUNK < stream_end) dma_issue(base0 + VRX_CHUNK);
@@ -467,7 +517,11 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     auto ring_need = [&](int at) {
         if (at < ring_evt) return;
         if (at >= landed_end) {
+#if VRX_LDS_L2PF
+            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+#else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             landed_end = issued_end;
         }
         if ((at & (VRX_CHUNK - 1)) == 0 && at > base0 && at + VRX_CHUNK < stream_end &&
@@ -475,16 +529,36 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
             dma_issue(at + VRX_CHUNK);  // into the slot of the chunk just finished
         ring_evt = (at & ~(VRX_CHUNK - 1)) + VRX_CHUNK;
     };
+    // FORM 1: LDS byte offset of a slice = (word & half-row offset bits) | lane offset
+    const uint32_t f1_mask = 0x1ff80u;
+    auto f1_addr = [&](uint32_t w, uint32_t lane_off) -> uint32_t {
+#if VRX_F1_ANDOR
+        uint32_t a;
+        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(a) : "v"(w), "s"(f1_mask), "v"(lane_off));
+        return a;
+#else
+        return (w & f1_mask) | lane_off;
+#endif
+    };
     // one entry of this group's segment: word -> 4 column slices -> FMAs
     auto entry = [&](uint32_t w, double (&a)[NQ][2], double (&a2)[NQ][2]) {
         if (FORM == 1) {  // one value, two adjacent columns per 16-B slice of a 128-B half row
             const double v = (double)((int32_t)w >> 17);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
+#ifdef VRX_X_NOREAD
+                const uint32_t ax = f1_addr(w, qoff[q]);
+                const double2 x = make_double2(__uint_as_float(ax), 1.0);
+#else
                 const double2 x = *reinterpret_cast<const double2*>(
-                    reinterpret_cast<const char*>(slab) + ((w & 0x1ff80u) | qoff[q]));
+                    reinterpret_cast<const char*>(slab) + f1_addr(w, qoff[q]));
+#endif
+#ifdef VRX_X_NOFMA
+                asm volatile("" ::"v"(x.x), "v"(x.y), "v"(v));
+#else
                 a[q][0] = fma(v, x.x, a[q][0]);
                 a[q][1] = fma(v, x.y, a[q][1]);
+#endif
             }
             return;
         }
@@ -510,8 +584,13 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
     slab_fetch(s_lo);
     for (int s = s_lo; s < s_hi; ++s) {
         __syncthreads();  // every wave is done reading the previous slab
+#ifdef VRX_X_NOSTAGE
+        if (s == s_lo)
+#endif
         slab_store();
+#ifndef VRX_X_NOSTAGE
         if (s + 1 < s_hi) slab_fetch(s + 1);
+#endif
         const int bcur = bvec;
         if (s + 1 < s_hi) bvec = bw[(int64_t)(s + 1) * NR + min(lane, NR)];
         __syncthreads();
@@ -525,6 +604,75 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
             const int base = braw & ~(U * G - 1), tail = braw & (U - 1);
             const int end = __builtin_amdgcn_readlane(bcur, r + 1) & ~(U * G - 1);
             const int full_end = tail ? end - U * G : end;
+#if VRX_F1_SCHED == 2
+            if (FORM == 1 && U == 4) {
+                // Software pipeline over half trips: the slices of two entries are requested
+                // while the FMAs of the previous two run, so that the LDS and the VALU phases of
+                // consecutive half trips overlap INSIDE a wave (all 16 waves leave the barrier
+                // together and the LDS arbiter serves them round-robin: without this every wave
+                // waits for the same LDS phase and then every wave computes).  The zero words
+                // that pad a round's last trip are executed (value 0, row 0: harmless).
+                if (base < end) {
+                    auto rd = [&](uint32_t w, int q) {
+                        return *reinterpret_cast<const double2*>(
+                            reinterpret_cast<const char*>(slab) + f1_addr(w, qoff[q]));
+                    };
+                    auto fma2 = [&](uint32_t w0, uint32_t w1, const double2 (&x)[2][NQ]) {
+                        const double v0 = (double)((int32_t)w0 >> 17), v1 = (double)((int32_t)w1 >> 17);
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) {
+                            acc[r][q][0] = fma(v0, x[0][q].x, acc[r][q][0]);
+                            acc[r][q][1] = fma(v0, x[0][q].y, acc[r][q][1]);
+                        }
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) {
+                            acc[r][q][0] = fma(v1, x[1][q].x, acc[r][q][0]);
+                            acc[r][q][1] = fma(v1, x[1][q].y, acc[r][q][1]);
+                        }
+                    };
+                    uint32_t w[4], wb0 = 0u, wb1 = 0u;
+                    double2 xa[2][NQ], xb[2][NQ];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) xb[u][q] = make_double2(0.0, 0.0);
+                    ring_need(base);
+                    {
+                        const uint32_t* rp = ring_g + (base & (VRX_RING - 1));
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) w[u] = rp[u * G];
+                    }
+                    for (int at = base; at < end; at += U * G) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) xa[u][q] = rd(w[u], q);
+                        __builtin_amdgcn_sched_barrier(0);
+                        fma2(wb0, wb1, xb);  // previous trip's second half (zeros the first time)
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) xb[u][q] = rd(w[2 + u], q);
+                        wb0 = w[2];
+                        wb1 = w[3];
+                        const uint32_t wa0 = w[0], wa1 = w[1];
+                        // the next trip's words (past the round: the next round's, unused)
+                        ring_need(at + U * G);
+                        {
+                            const uint32_t* rp = ring_g + ((at + U * G) & (VRX_RING - 1));
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) w[u] = rp[u * G];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        fma2(wa0, wa1, xa);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    fma2(wb0, wb1, xb);
+                }
+                continue;
+            }
+#endif
             for (int at = base; at < full_end; at += U * G) {
                 ring_need(at);
                 // trips start at multiples of U*G = 64 words and the ring is a multiple of
@@ -533,6 +681,28 @@ __global__ __launch_bounds__(1024) void vrx_spmm_lds(
                 uint32_t w[US];
 #pragma unroll
                 for (int u = 0; u < US; ++u) w[u] = rp[u * SPLIT * G];
+#if VRX_F1_SCHED == 1
+                if (FORM == 1) {  // every slice of the trip is requested before the first FMA
+                    double2 x[US][NQ];
+#pragma unroll
+                    for (int u = 0; u < US; ++u)
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q)
+                            x[u][q] = *reinterpret_cast<const double2*>(
+                                reinterpret_cast<const char*>(slab) + f1_addr(w[u], qoff[q]));
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < US; ++u) {
+                        const double v = (double)((int32_t)w[u] >> 17);
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) {
+                            acc[r][q][0] = fma(v, x[u][q].x, acc[r][q][0]);
+                            acc[r][q][1] = fma(v, x[u][q].y, acc[r][q][1]);
+                        }
+                    }
+                    continue;
+                }
+#endif
 #pragma unroll
                 for (int u = 0; u < US; ++u) entry(w[u], acc[r], acc2[r]);
             }

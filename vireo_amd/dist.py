@@ -8,8 +8,9 @@ ELBOs (a few hundred bytes over RCCL/xGMI) plus a broadcast of the winner's stat
 
 Backends
   RcclComm   libvireo_hip.so's RCCL communicator (GPU box)
-  GlooComm   torch.distributed/gloo, used by the CPU-only tests of the sharding logic
   LocalComm  world size 1
+(the CPU-only tests of the sharding logic bring their own gloo communicator with the same
+three methods: tests/gloo_comm.py)
 """
 import ctypes as C
 import os
@@ -76,34 +77,10 @@ class RcclComm:
             self._h = C.c_void_p()
 
 
-class GlooComm:
-    """Same interface over an initialised torch.distributed process group (CPU tests)."""
-
-    def __init__(self):
-        import torch.distributed as dist
-        self._dist = dist
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
-
-    def allgather(self, local):
-        import torch
-        t = torch.from_numpy(_lib.f64(local).ravel().copy())
-        outs = [torch.empty_like(t) for _ in range(self.world)]
-        self._dist.all_gather(outs, t)
-        return torch.cat(outs).numpy()
-
-    def bcast(self, arr, root):
-        import torch
-        t = torch.from_numpy(_lib.f64(arr).copy())
-        self._dist.broadcast(t, src=int(root))
-        return t.numpy()
-
-    def barrier(self):
-        self._dist.barrier()
-
-
 def socket_exchange(rank, world, addr=None, port=None, timeout=600.0):
     """unique-id exchange over a plain TCP socket: rank 0 serves the id on
-    (MASTER_ADDR, VIREO_RDZV_PORT or MASTER_PORT + 1), every other rank fetches it.
+    (MASTER_ADDR, VIREO_RDZV_PORT or MASTER_PORT + 1) -- bound to that address only -- and
+    every other rank fetches it after announcing its rank.
     No PyTorch involved -- importing torch next to libvireo_hip.so puts a second HIP runtime
     (and a second librccl) into the process, and RCCL initialisation then fails."""
     import socket
@@ -113,24 +90,47 @@ def socket_exchange(rank, world, addr=None, port=None, timeout=600.0):
         port = int(os.environ.get("VIREO_RDZV_PORT",
                                   int(os.environ.get("MASTER_PORT", "29500")) + 1))
 
+    hello = b"VRXID1"
+
     def exchange(raw):
         if world == 1:
             return raw
         if rank == 0:
+            # serve the id once to every distinct rank that says hello; anything else that
+            # connects (a port probe, a stale peer) is dropped without using up a slot
             with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as srv:
                 srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-                srv.bind(("", port))
+                srv.bind((addr, port))
                 srv.listen(world)
-                srv.settimeout(timeout)
-                for _ in range(world - 1):
-                    conn, _peer = srv.accept()
+                served, deadline = set(), time.time() + timeout
+                while len(served) < world - 1:
+                    srv.settimeout(max(0.1, deadline - time.time()))
+                    try:
+                        conn, _peer = srv.accept()
+                    except socket.timeout:
+                        raise TimeoutError("ranks %s never asked for the RCCL unique id"
+                                           % sorted(set(range(1, world)) - served))
                     with conn:
-                        conn.sendall(raw)
+                        try:
+                            conn.settimeout(5.0)
+                            msg = b""
+                            while len(msg) < len(hello) + 4:
+                                part = conn.recv(len(hello) + 4 - len(msg))
+                                if not part:
+                                    break
+                                msg += part
+                            peer = int.from_bytes(msg[len(hello):], "little") if len(msg) == len(hello) + 4 else -1
+                            if msg[:len(hello)] == hello and 0 < peer < world and peer not in served:
+                                conn.sendall(raw)
+                                served.add(peer)
+                        except OSError:
+                            pass
             return raw
         deadline = time.time() + timeout
         while True:
             try:
                 with socket.create_connection((addr, port), timeout=10.0) as s:
+                    s.sendall(hello + int(rank).to_bytes(4, "little"))
                     buf = b""
                     while len(buf) < _lib.UNIQUE_ID_BYTES:
                         chunk = s.recv(_lib.UNIQUE_ID_BYTES - len(buf))
@@ -144,18 +144,6 @@ def socket_exchange(rank, world, addr=None, port=None, timeout=600.0):
             if time.time() > deadline:
                 raise TimeoutError("no RCCL unique id from rank 0 at %s:%d" % (addr, port))
             time.sleep(0.2)
-    return exchange
-
-
-def torch_store_exchange():
-    """unique-id exchange through an initialised torch.distributed group (any backend).
-    Only for processes that use torch on the CPU alone (see socket_exchange)."""
-    import torch.distributed as dist
-
-    def exchange(raw):
-        box = [raw]
-        dist.broadcast_object_list(box, src=0)
-        return box[0]
     return exchange
 
 

@@ -103,6 +103,12 @@ class DeviceModel:
         if idp is not None and idp.shape[1] != self.K:
             raise ValueError("ID_prior has shape %s" % (idp.shape,))
         s1, s2 = f64(theta_s1_prior), f64(theta_s2_prior)
+        if self.kind == _lib.KIND_BMM and s1.ndim == 2 and s1.shape[0] == 1 and not (
+                np.all(s1 == s1.flat[0]) and np.all(s2 == s2.flat[0])):
+            # a (1, n_donor) prior that differs per clone broadcasts over the variants like in
+            # the reference (bmm_model.py:92-98); the kernel reads a 1-row prior at [0] only
+            s1 = f64(np.broadcast_to(s1, self.theta_shape))
+            s2 = f64(np.broadcast_to(s2, self.theta_shape))
         if s1.shape != s2.shape or s1.ndim != 2 or s1.shape[1] != self.theta_shape[1] \
                 or s1.shape[0] not in (1, self.theta_shape[0]):
             raise ValueError("theta prior has shape %s" % (s1.shape,))

@@ -25,6 +25,48 @@ def loglik_amplify(X, axis=-1):
     return X - np.max(X, axis=axis, keepdims=True)
 
 
+def get_binom_coeff(AD, DP, max_val=700, is_log=True):
+    """float32 log C(DP, AD) of every entry with DP > 0, clamped at max_val -- the per-entry
+    helper the reference exports (vireo_base.py:7-22; ``is_log`` is ignored there too).  Host
+    NumPy/SciPy: the fits never call it, they add the GPU-reduced sum (``binom_coeff_sum``).
+    Entry order follows the reference's boolean indexing ``X[DP > 0]``: row-major (variant by
+    variant) for every input format; sparse input gives a (1, n) array like the reference's
+    np.matrix, dense input a 1-D array."""
+    from scipy.sparse import issparse
+    from scipy.special import binom
+    from .counts import merge_counts
+    if issparse(DP):
+        _, _, _, ad, dp = merge_counts(AD.T, DP.T)      # columns of the transpose = rows
+        keep = dp > 0
+        ad, dp = ad[keep].astype(np.int64), dp[keep].astype(np.int64)
+    else:
+        keep = np.asarray(DP) > 0
+        ad, dp = np.asarray(AD)[keep].astype(np.int64), np.asarray(DP)[keep].astype(np.int64)
+    coeff = np.minimum(np.log(binom(dp, ad)), max_val).astype(np.float32)
+    return coeff[None, :] if issparse(DP) else coeff
+
+
+def beta_entropy(X, X_prior=None, axis=None):
+    """Entropy of Beta(X[:, 0], X[:, 1]) distributions, or with X_prior their KL divergence
+    from Beta(X_prior[:, 0], X_prior[:, 1]), summed over ``axis`` (vireo_base.py:77-127).  Host
+    helper with the reference's name; inside the fits the same arithmetic is ``vrx_beta_kl``
+    (vireo_amd/csrc/vrx_kernels.h)."""
+    from scipy.special import betaln, digamma
+
+    def cross(p, q):        # -E_p[log q]
+        return (betaln(q[:, 0], q[:, 1]) - (q[:, 0] - 1) * digamma(p[:, 0])
+                - (q[:, 1] - 1) * digamma(p[:, 1]) + (q.sum(axis=1) - 2) * digamma(p.sum(axis=1)))
+
+    X = np.asarray(X)
+    if X.ndim == 1:
+        if X.shape[0] != 2:
+            print("Error: unsupported shape. Make sure it's (N, 2)")
+        X = X.reshape(-1, 2)
+    if X_prior is None:
+        return np.sum(cross(X, X), axis=axis)
+    return np.sum(cross(X, np.asarray(X_prior)) - cross(X, X), axis=axis)
+
+
 def binom_coeff_sum(AD, DP):
     """np.sum(get_binom_coeff(AD, DP)) of the reference (vireo_base.py:7-22 summed at
     vireo_model.py:313 / bmm_model.py:239): a float32 scalar, computed on the GPU."""

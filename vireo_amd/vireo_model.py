@@ -92,6 +92,13 @@ class Vireo():
             GT_prior[GT_prior > 1 - min_GP] = 1 - min_GP
             self.GT_prior = normalize(GT_prior)
 
+    def __getstate__(self):
+        """plain NumPy state only (the reference ships models through multiprocessing.Pool,
+        vireo_wrap.py:74-83): the handle on the device problem stays behind"""
+        state = dict(self.__dict__)
+        state.pop("_last_counts", None)
+        return state
+
     @property
     def GP_prob(self):
         """pre-0.2.2 name of GT_prob (doc/release.rst:101)."""

@@ -5,6 +5,11 @@ Every fit runs on the GPU.  ``nproc`` is accepted for compatibility (the referen
 multiprocessing.Pool, vireo_wrap.py:74-83) and ignored: restarts are instead sharded
 across GPUs when a communicator is passed (``comm=``, see vireo_amd/dist.py) -- restart i
 on rank i % world, one RCCL all-gather of the ELBOs to pick the winner.
+
+Layout of this module: ``_Plan`` resolves the argument combinations, ``_search`` runs the
+restarts (vireo_amd/restarts.py) and returns the winning model, ``_keep_n_donors`` /
+``_match_prior_subset`` / ``_match_prior_superset`` are the three optional re-fits, and
+``_report`` / ``_result`` produce the reference's prints and its result dict.
 """
 import sys
 
@@ -12,37 +17,162 @@ import numpy as np
 
 from .counts import device_counts
 from .dist import LocalComm, gather_restart_elbos, my_restarts
-from .vireo_base import donor_select, optimal_match
+from .restarts import DeviceRestarts, LegacyStream
+from .vireo_base import donor_select, normalize, optimal_match
 from .vireo_doublet import predict_doublet
 from .vireo_model import Vireo
+
+_INIT_KEYS = ("ID_prob_init", "GT_prob_init", "beta_mu_init", "beta_sum_init")
+
+
+class _Plan:
+    """What the argument combination asks for (vireo_wrap.py:36-62)."""
+
+    def __init__(self, GT_prior, n_donor, learn_GT, n_init, n_extra_donor):
+        if learn_GT == False and n_extra_donor > 0:      # noqa: E712
+            print("Searching from extra donors only works with learn_GT")
+            n_extra_donor = 0
+        if n_donor is None:
+            if GT_prior is None:
+                print("[vireo] Error: requiring n_donor or GT_prior.")
+                sys.exit()
+            n_donor = GT_prior.shape[1]
+        if learn_GT is False and n_init > 1:
+            print("GT is fixed, so use a single initialization")
+            n_init = 1
+        self.n_donor, self.n_init, self.n_extra = n_donor, n_init, n_extra_donor
+        self.learn_GT = learn_GT
+        # donors searched for, and the genotype prior the search starts from
+        self.search_donors = int(n_donor + n_extra_donor)
+        self.search_prior = None
+        if GT_prior is not None and self.search_donors <= GT_prior.shape[1]:
+            self.search_prior = GT_prior.copy()
+            self.search_donors = GT_prior.shape[1]
+
+
+def _template(counts, n_donor, learn_GT, GT_prior, kwargs, **state):
+    """A host Vireo with the job's shapes, flags and priors that consumes no random numbers:
+    whatever the caller does not pin gets a placeholder that a device state replaces."""
+    n_var, n_cell = counts.shape
+    n_GT = kwargs.get("n_GT", 3)
+    rows = n_var if kwargs.get("ASE_mode", False) else 1
+    init = dict(ID_prob_init=np.ones((n_cell, n_donor)),
+                GT_prob_init=np.ones((n_var, n_donor, n_GT)) if GT_prior is None else GT_prior)
+    init.update({k: v for k, v in kwargs.items() if k in _INIT_KEYS and v is not None})
+    init.update(state)
+    flags = {k: v for k, v in kwargs.items() if k not in _INIT_KEYS}
+    m = Vireo(n_var=n_var, n_cell=n_cell, n_donor=n_donor, learn_GT=learn_GT, **init, **flags)
+    m.set_prior(GT_prior=GT_prior)
+    assert m.beta_mu.shape[0] in (1, rows)
+    return m
 
 
 def _bcast_model(comm, model, root):
     """every rank leaves with the root's fitted state."""
     if comm.world == 1:
         return
-    model.ID_prob = comm.bcast(model.ID_prob, root)
-    model.GT_prob = comm.bcast(model.GT_prob, root)
-    model.beta_mu = comm.bcast(model.beta_mu, root)
-    model.beta_sum = comm.bcast(model.beta_sum, root)
+    for name in ("ID_prob", "GT_prob", "beta_mu", "beta_sum"):
+        setattr(model, name, comm.bcast(getattr(model, name), root))
     n = comm.bcast(np.array([float(len(model.ELBO_))]), root)
     trace = model.ELBO_ if comm.rank == root else np.zeros(int(n[0]))
     model.ELBO_ = comm.bcast(trace, root)
 
 
-def _shell_like(n_var, n_cell, n_donor, learn_GT, GT_prior, kwargs):
-    """an un-initialised Vireo with the right shapes and priors; consumes no random numbers"""
-    n_GT = kwargs.get("n_GT", 3)
-    ase = kwargs.get("ASE_mode", False)
-    rows = n_var if ase else 1
-    m = Vireo(n_var=n_var, n_cell=n_cell, n_donor=n_donor, learn_GT=learn_GT,
-              ID_prob_init=np.ones((n_cell, n_donor)),
-              GT_prob_init=np.ones((n_var, n_donor, n_GT)),
-              beta_mu_init=np.zeros((rows, n_GT)), beta_sum_init=np.zeros((rows, n_GT)),
-              **{k: v for k, v in kwargs.items()
-                 if k not in ("ID_prob_init", "GT_prob_init", "beta_mu_init", "beta_sum_init")})
-    m.set_prior(GT_prior=GT_prior)
-    return m
+def _search(counts, plan, comm, max_iter_init, delay_fit_theta, kwargs, restarts_cls):
+    """The n_init restarts (vireo_wrap.py:64-94): every rank walks the random stream of all of
+    them, fits its own share, the ELBOs are all-gathered, the first maximum wins and its owner
+    refines it (unless extra donors are still to be dropped) and broadcasts the state."""
+    n_var, n_cell = counts.shape
+    K, T = plan.search_donors, kwargs.get("n_GT", 3)
+    tmpl = _template(counts, K, plan.learn_GT, plan.search_prior, kwargs)
+    # what one reference constructor draws, in its order (vireo_model.py:98,103)
+    fixed_ID = kwargs.get("ID_prob_init")
+    ID0 = None if fixed_ID is None else normalize(fixed_ID, axis=1)
+    # a genotype prior is every restart's initial GT_prob; the first constructor sees it before
+    # set_prior clips it in place (vireo_model.py:132-133), the later ones after
+    GT0 = GT0_first = None
+    if plan.search_prior is not None:
+        GT0_first, GT0 = tmpl.GT_prob.copy(), normalize(plan.search_prior)
+    stream = LegacyStream()
+    mine = set(my_restarts(plan.n_init, comm.rank, comm.world))
+    runner = restarts_cls(counts, tmpl)
+    local = {}
+    for im in range(plan.n_init):
+        if im in mine:
+            ID_raw = stream.rand(n_cell, K) if ID0 is None else None
+            GT_raw = stream.rand(n_var, K, T) if GT0 is None else None
+            local[im] = runner.run(im, ID_raw, GT_raw, ID0, GT0_first if im == 0 else GT0,
+                                   max_iter_init, delay_fit_theta)
+        else:
+            stream.skip((n_cell * K if ID0 is None else 0) + (n_var * K * T if GT0 is None else 0))
+    elbo_all = gather_restart_elbos(comm, plan.n_init, local)
+    best = int(np.argmax(elbo_all))              # first max wins, vireo_wrap.py:90-91
+    owner = best % comm.world
+    model = runner.winner(best, refine=plan.n_extra == 0) if comm.rank == owner else tmpl
+    runner.close()
+    _bcast_model(comm, model, owner)
+    return model, elbo_all
+
+
+def _keep_n_donors(counts, plan, found, extra_donor_mode, delay_fit_theta, kwargs):
+    """More donors were searched than asked for: keep n_donor of them (by size or by genotype
+    distance) and fit again from their assignments (vireo_wrap.py:95-105)."""
+    n_var, n_cell = counts.shape
+    start = dict(kwargs, beta_mu_init=found.beta_mu, beta_sum_init=found.beta_sum,
+                 ID_prob_init=donor_select(found.GT_prob, found.ID_prob, plan.n_donor,
+                                           mode=extra_donor_mode))
+    model = Vireo(n_var=n_var, n_cell=n_cell, n_donor=plan.n_donor, learn_GT=plan.learn_GT,
+                  GT_prob_init=plan.search_prior, **start)   # draws GT_prob when there is no prior
+    model.set_prior(GT_prior=plan.search_prior)
+    model.fit(counts, None, min_iter=5, delay_fit_theta=delay_fit_theta, verbose=False)
+    return model
+
+
+def _match_prior_subset(counts, plan, found, GT_prior, kwargs):
+    """The prior knows more donors than are in the pool: keep the n_donor largest found ones
+    and fit with their genotypes fixed (vireo_wrap.py:111-119)."""
+    by_size = np.argsort(np.sum(found.ID_prob, axis=0))[::-1]
+    kept = GT_prior[:, by_size[:plan.n_donor], :]
+    n_var, n_cell = counts.shape
+    model = Vireo(n_var=n_var, n_cell=n_cell, n_donor=plan.n_donor, learn_GT=False,
+                  GT_prob_init=kept, **kwargs)
+    model.fit(counts, None, min_iter=20, verbose=False)
+    return model
+
+
+def _match_prior_superset(counts, plan, found, GT_prior, kwargs):
+    """The pool holds more donors than the prior knows: align the known ones to the found
+    genotypes, put them first, and fit again with the learned genotypes of the others as their
+    prior (vireo_wrap.py:121-136)."""
+    known = optimal_match(GT_prior, found.GT_prob)[1]
+    order = np.append(known, np.delete(np.arange(plan.n_donor), known))
+    mixed = found.GT_prob.copy()
+    mixed[:, known, :] = GT_prior
+    mixed = mixed[:, order, :]
+    model = _template(counts, plan.n_donor, plan.learn_GT, mixed, kwargs,
+                      ID_prob_init=found.ID_prob[:, order], beta_mu_init=found.beta_mu,
+                      beta_sum_init=found.beta_sum)
+    model.fit(counts, None, min_iter=20, verbose=False)
+    return model
+
+
+def _report(model):
+    print("[vireo] allelic rate mean and concentrations:")
+    print(np.round(model.beta_mu, 3))
+    print(np.round(model.beta_sum, 1))
+    print("[vireo] donor size before removing doublets:")
+    sizes = np.sum(model.ID_prob, axis=0)
+    print("\t".join("donor%d" % k for k in range(len(sizes))))
+    print("\t".join("%.0f" % s for s in sizes))
+
+
+def _result(model, ID_prob, doublet_prob, doublet_LLR, elbo_all):
+    """the reference's result dict (vireo_wrap.py:170-183)"""
+    s1, s2 = model.beta_mu * model.beta_sum, (1 - model.beta_mu) * model.beta_sum
+    return dict(ID_prob=ID_prob, GT_prob=model.GT_prob, doublet_LLR=doublet_LLR,
+                doublet_prob=doublet_prob, theta_shapes=np.append(s1, s2, axis=0),
+                theta_mean=model.beta_mu, theta_sum=model.beta_sum, ambient_Psi=None,
+                Psi_var=None, Psi_LLRatio=None, LB_list=elbo_all, LB_doublet=model.ELBO_[-1])
 
 
 def vireo_wrap(AD, DP, GT_prior=None, n_donor=None, learn_GT=True, n_init=20,
@@ -51,120 +181,32 @@ def vireo_wrap(AD, DP, GT_prior=None, n_donor=None, learn_GT=True, n_init=20,
                check_ambient=False, nproc=4, comm=None, **kwargs):
     """Run vireo with multiple initialisations; returns the reference's result dict
     (keys: vireo_wrap.py:170-183)."""
-    if comm is None:
-        comm = LocalComm()
+    comm = LocalComm() if comm is None else comm
     counts = device_counts(AD, DP)
-    n_var, n_cell = counts.shape
-
-    if learn_GT == False and n_extra_donor > 0:      # noqa: E712
-        print("Searching from extra donors only works with learn_GT")
-        n_extra_donor = 0
-    if n_donor is None:
-        if GT_prior is None:
-            print("[vireo] Error: requiring n_donor or GT_prior.")
-            sys.exit()
-        n_donor = GT_prior.shape[1]
-    if learn_GT is False and n_init > 1:
-        print("GT is fixed, so use a single initialization")
-        n_init = 1
+    plan = _Plan(GT_prior, n_donor, learn_GT, n_init, n_extra_donor)
     if check_ambient:
         raise NotImplementedError("check_ambient (experimental in the reference, "
                                   "vireo.py:79-81) is out of scope of vireo_amd")
-
     if random_seed is not None:                       # the ONLY seeding, vireo_wrap.py:53-54
         np.random.seed(random_seed)
 
-    GT_prior_use = None
-    n_donor_use = int(n_donor + n_extra_donor)
-    if GT_prior is not None and n_donor_use == GT_prior.shape[1]:
-        GT_prior_use = GT_prior.copy()
-    elif GT_prior is not None and n_donor_use < GT_prior.shape[1]:
-        GT_prior_use = GT_prior.copy()
-        n_donor_use = GT_prior.shape[1]
-
-    # Every rank draws every restart's initial state in the reference's order so the RNG
-    # stream is consumed identically (vireo_wrap.py:66-71), but keeps only its own share.
-    mine = set(my_restarts(n_init, comm.rank, comm.world))
-    models = {}
-    for im in range(n_init):
-        mdl = Vireo(n_var=n_var, n_cell=n_cell, n_donor=n_donor_use, learn_GT=learn_GT,
-                    GT_prob_init=GT_prior_use, **kwargs)
-        mdl.set_prior(GT_prior=GT_prior_use)
-        if im in mine:
-            models[im] = mdl
-
-    for im in sorted(models):                         # vireo_wrap.py:84-87
-        models[im].fit(counts, None, min_iter=5, max_iter=max_iter_init,
-                       delay_fit_theta=delay_fit_theta, verbose=False)
-
-    # select the best initialisation (first max wins, vireo_wrap.py:90-91)
-    elbo_all = gather_restart_elbos(comm, n_init, {i: m.ELBO_[-1] for i, m in models.items()})
-    best = int(np.argmax(elbo_all))
-    owner = best % comm.world
-    if comm.rank == owner:
-        modelCA = models[best]
-        if n_extra_donor == 0:
-            modelCA.fit(counts, None, min_iter=5, verbose=False)
-    else:      # a shell that receives the winner's state (built without touching the RNG)
-        modelCA = _shell_like(n_var, n_cell, n_donor_use, learn_GT, GT_prior_use, kwargs)
-    _bcast_model(comm, modelCA, owner)
-    models.clear()
-
-    if n_extra_donor != 0:                            # vireo_wrap.py:95-105
-        _ID_prob = donor_select(modelCA.GT_prob, modelCA.ID_prob, n_donor,
-                                mode=extra_donor_mode)
-        modelCA = Vireo(n_var=n_var, n_cell=n_cell, n_donor=n_donor, learn_GT=learn_GT,
-                        GT_prob_init=GT_prior_use, ID_prob_init=_ID_prob,
-                        beta_mu_init=modelCA.beta_mu, beta_sum_init=modelCA.beta_sum,
-                        **kwargs)
-        modelCA.set_prior(GT_prior=GT_prior_use)
-        modelCA.fit(counts, None, min_iter=5, delay_fit_theta=delay_fit_theta, verbose=False)
-
+    model, elbo_all = _search(counts, plan, comm, max_iter_init, delay_fit_theta, kwargs,
+                              DeviceRestarts)
+    if plan.n_extra != 0:
+        model = _keep_n_donors(counts, plan, model, extra_donor_mode, delay_fit_theta, kwargs)
     print("[vireo] lower bound ranges [%.1f, %.1f, %.1f]"
           % (np.min(elbo_all), np.median(elbo_all), np.max(elbo_all)))
 
-    # run again when the genotype prior has more / fewer donors than asked for
-    if GT_prior is not None and n_donor < GT_prior.shape[1]:        # vireo_wrap.py:111-119
-        _donor_cnt = np.sum(modelCA.ID_prob, axis=0)
-        _donor_idx = np.argsort(_donor_cnt)[::-1]
-        GT_prior_use = GT_prior[:, _donor_idx[:n_donor], :]
-        modelCA = Vireo(n_var=n_var, n_cell=n_cell, n_donor=n_donor, learn_GT=False,
-                        GT_prob_init=GT_prior_use, **kwargs)
-        modelCA.fit(counts, None, min_iter=20, verbose=False)
-    elif GT_prior is not None and n_donor > GT_prior.shape[1]:      # vireo_wrap.py:121-136
-        GT_prior_use = modelCA.GT_prob.copy()
-        idx = optimal_match(GT_prior, GT_prior_use)[1]
-        GT_prior_use[:, idx, :] = GT_prior
-        _idx_order = np.append(idx, np.delete(np.arange(n_donor), idx))
-        GT_prior_use = GT_prior_use[:, _idx_order, :]
-        ID_prob_use = modelCA.ID_prob[:, _idx_order]
-        modelCA = Vireo(n_var=n_var, n_cell=n_cell, n_donor=n_donor, learn_GT=learn_GT,
-                        ID_prob_init=ID_prob_use, beta_mu_init=modelCA.beta_mu,
-                        beta_sum_init=modelCA.beta_sum, GT_prob_init=GT_prior_use, **kwargs)
-        modelCA.set_prior(GT_prior=GT_prior_use)
-        modelCA.fit(counts, None, min_iter=20, verbose=False)
-
-    print("[vireo] allelic rate mean and concentrations:")
-    print(np.round(modelCA.beta_mu, 3))
-    print(np.round(modelCA.beta_sum, 1))
-    print("[vireo] donor size before removing doublets:")
-    _donor_cnt = np.sum(modelCA.ID_prob, axis=0)
-    print("\t".join(["donor%d" % x for x in range(len(_donor_cnt))]))
-    print("\t".join(["%.0f" % x for x in _donor_cnt]))
+    if GT_prior is not None and plan.n_donor < GT_prior.shape[1]:
+        model = _match_prior_subset(counts, plan, model, GT_prior, kwargs)
+    elif GT_prior is not None and plan.n_donor > GT_prior.shape[1]:
+        model = _match_prior_superset(counts, plan, model, GT_prior, kwargs)
+    _report(model)
 
     if check_doublet:                                 # vireo_wrap.py:151-156
-        doublet_prob, ID_prob, doublet_LLR = predict_doublet(modelCA, counts, None)
+        doublet_prob, ID_prob, doublet_LLR = predict_doublet(model, counts, None)
     else:
-        ID_prob = modelCA.ID_prob
-        doublet_prob = np.zeros((n_cell, int(n_donor * (n_donor - 1) / 2)))
-        doublet_LLR = np.zeros(n_cell)
-
-    theta_shapes = np.append(modelCA.beta_mu * modelCA.beta_sum,
-                             (1 - modelCA.beta_mu) * modelCA.beta_sum, axis=0)
-    return {
-        'ID_prob': ID_prob, 'GT_prob': modelCA.GT_prob, 'doublet_LLR': doublet_LLR,
-        'doublet_prob': doublet_prob, 'theta_shapes': theta_shapes,
-        'theta_mean': modelCA.beta_mu, 'theta_sum': modelCA.beta_sum,
-        'ambient_Psi': None, 'Psi_var': None, 'Psi_LLRatio': None,
-        'LB_list': elbo_all, 'LB_doublet': modelCA.ELBO_[-1],
-    }
+        n_cell, K = counts.shape[1], plan.n_donor
+        ID_prob, doublet_LLR = model.ID_prob, np.zeros(n_cell)
+        doublet_prob = np.zeros((n_cell, int(K * (K - 1) / 2)))
+    return _result(model, ID_prob, doublet_prob, doublet_LLR, elbo_all)
