@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- EM iterations/sec of the Vireo VB hot path on MI355X (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|mid|c2] [--no-cpu]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|mid|c2] [--no-cpu] [--no-c4]
 
 A step is ONE full coordinate-ascent iteration (theta update, GT update, ID update, ELBO:
 vireoSNP/utils/vireo_model.py:257-264) over the synthetic AD/DP of SURVEY.md 8(d), inputs
@@ -11,8 +11,24 @@ W warm-up iterations run without the theta update (the protocol's delay_fit_thet
 timed ones with it.  N > 1 (launched by torch.distributed.run, one rank per GPU): every
 rank holds the problem and iterates its own restart (vireo_wrap's restart shard, weak
 scaling); the per-restart ELBOs are all-gathered over RCCL.  Rank 0 prints ONE JSON line.
+
+Besides the headline value the line carries
+  roofline      the dominant sparse pass against the HBM roofline (HIP events on the library's
+                stream; PMC traffic from profiles/traffic_<config>.json when it was collected
+                on the same kernel sources),
+  cpu_baseline  the CPU oracle (the reference's NumPy/SciPy op sequence, 1 core) running the
+                WHOLE timing protocol fit(min_iter=5, max_iter=20, delay_fit_theta=3) on the
+                same inputs,
+  parity        that run against the same fit on the GPU: iteration count, whole ELBO trace,
+                final assignments (the metric is "EM iterations/sec + ELBO-match"),
+  c4            BASELINE.json configs[3]: vireo_wrap(n_init=32) on the same data with the
+                restarts sharded over the N ranks (strong scaling: the 32 restarts are the
+                fixed job), restart-iterations/s, wall time and the per-phase split.
 """
 import argparse
+import contextlib
+import hashlib
+import io
 import json
 import os
 import sys
@@ -24,6 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+PROTOCOL = dict(min_iter=5, max_iter=20, delay_fit_theta=3)
 
 
 def algorithmic_bytes(N, M, K, T, nnz):
@@ -36,8 +53,16 @@ def algorithmic_bytes(N, M, K, T, nnz):
                 total=variant + cell + dense)
 
 
-def cpu_baseline_leg(w, K, seed):
-    """ONE full-size iteration of the oracle (the reference's SciPy op sequence, 1 core)."""
+def kernel_source_hash():
+    """what a PMC traffic record must have been collected on to be quoted"""
+    h = hashlib.sha256()
+    for f in ("vrx_kernels.h", "vrx_engine.hip", "vrx_common.h"):
+        h.update(open(os.path.join(ROOT, "vireo_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_protocol_leg(w, K, seed):
+    """the whole timing protocol on the oracle (1 core), from the same initial state"""
     from oracle import vireo_oracle as O
     from vireo_amd.synth import as_scipy
     AD, DP = as_scipy(w)
@@ -45,12 +70,46 @@ def cpu_baseline_leg(w, K, seed):
     np.random.seed(seed)
     st = O.vireo_new(M, N, K)
     t0 = time.perf_counter()
-    O.vireo_theta_step(st, AD, DP)
-    O.vireo_gt_step(st, AD, DP)
-    L = O.vireo_id_step(st, AD, DP)
-    elbo = O.vireo_elbo(st, L)
+    trace, it = O.vireo_fit_vb(st, AD, DP, **PROTOCOL)     # (the trace without the constant)
     dt = time.perf_counter() - t0
-    return dt, elbo, st
+    return dt, st, trace, it
+
+
+def c4_leg(counts, K, comm, n_init=32):
+    """BASELINE.json configs[3]: the n_init=32 restart search of vireo_wrap, sharded."""
+    from vireo_amd import restarts
+    W = sys.modules["vireo_amd.vireo_wrap"]
+    restarts.PHASES = {}
+    comm.barrier()
+    t0 = time.perf_counter()
+    with contextlib.redirect_stdout(io.StringIO()):
+        rv = W.vireo_wrap(counts, None, n_donor=K, n_init=n_init, max_iter_init=20,
+                          random_seed=1, check_doublet=False, comm=comm)
+    wall = time.perf_counter() - t0
+    comm.barrier()
+    phases, restarts.PHASES = restarts.PHASES, None
+    stats = dict(W.LAST_SEARCH)
+    # per-rank numbers -> rank-major arrays on every rank
+    keys = ["draw", "skip", "upload+normalise", "fit", "snapshot", "gather", "final_fit",
+            "download", "broadcast"]
+    mine = np.array([wall, stats["restart_iterations"], stats["final_iterations"]] +
+                    [phases.get(k, 0.0) for k in keys])
+    allr = np.asarray(comm.allgather(mine)).reshape(comm.world, -1)
+    wall_max = float(allr[:, 0].max())
+    restart_its = int(allr[:, 1].sum())
+    final_its = int(allr[:, 2].sum())
+    # the restart-shard phase ends when the slowest rank has fitted its share
+    shard = allr[:, 3:3 + 5].sum(axis=1)          # draw + skip + upload + fit + snapshot
+    return dict(
+        workload="c4: vireo_wrap(n_init=%d, max_iter_init=20, random_seed=1, no doublets) on the "
+                 "c3 data, restart i on rank i %% %d" % (n_init, comm.world),
+        n_init=n_init, wall_s=wall_max, restart_iterations=restart_its,
+        final_fit_iterations=final_its,
+        restart_iterations_per_s=restart_its / float(shard.max()),
+        whole_job_iterations_per_s=(restart_its + final_its) / wall_max,
+        restart_shard_phase_s=float(shard.max()),
+        phases_s_max_over_ranks={k: float(allr[:, 3 + i].max()) for i, k in enumerate(keys)},
+        LB_list_head=[float(x) for x in rv["LB_list"][:4]], best_restart=stats["best"])
 
 
 def main():
@@ -59,7 +118,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c3")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity leg")
+    ap.add_argument("--no-c4", action="store_true", help="skip the n_init=32 restart-shard leg")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -107,37 +167,6 @@ def main():
     dm.set_state(host.ID_prob, host.GT_prob, host.beta_mu, host.beta_sum)
     dm.set_prior(host.ID_prior, host.GT_prior, host.theta_s1_prior, host.theta_s2_prior)
 
-    # parity probe (rank 0): the very first iteration against the oracle, same init
-    parity = None
-    cpu = None
-    if rank == 0:
-        first, _ = dm.run_iters(1, theta_from_iter=0)
-        ID1 = dm.get_state(want_GT=False)[0]
-        dm.set_state(host.ID_prob, host.GT_prob, host.beta_mu, host.beta_sum)
-        if not args.no_cpu:
-            dt, elbo_cpu, st = cpu_baseline_leg(w, K, seed=1)
-            # after ONE iteration from a random start the posteriors are still uniform to
-            # ~3e-7, so a few cells have a top-2 gap below fp64 summation-order noise; they
-            # are counted separately
-            srt = np.sort(st.ID_prob, axis=1)
-            near_tie = (srt[:, -1] - srt[:, -2]) <= 1e-9 * srt[:, -1]
-            differ = ID1.argmax(1) != st.ID_prob.argmax(1)
-            parity = dict(elbo_gpu=float(first[0]), elbo_cpu=float(elbo_cpu),
-                          elbo_rel_err=float(abs(first[0] - elbo_cpu) / abs(elbo_cpu)),
-                          id_prob_max_rel_err=float(np.max(
-                              np.abs(ID1 - st.ID_prob) / np.maximum(st.ID_prob, 1e-300))),
-                          assignment_mismatches=int(differ.sum()),
-                          near_tie_cells=int(near_tie.sum()),
-                          assignments_identical_outside_near_ties=bool(
-                              not np.any(differ & ~near_tie)))
-            cpu = dict(value=1.0 / dt, unit="EM iterations/s", cores=1, kind="port",
-                       sample="1 full-size EM iteration (theta+GT+ID+ELBO) of the NumPy/SciPy "
-                              "oracle (the reference's 13 SpMM + 2 sparse-subtract op sequence, "
-                              "single-threaded like scipy.sparse) on the same %s inputs; %.1f s; "
-                              "box has %d cores" % (args.config, dt, os.cpu_count()))
-            del st
-    del w
-
     if args.warmup > 0:
         dm.run_iters(args.warmup, theta_from_iter=10 ** 9)
     comm.barrier()
@@ -156,9 +185,63 @@ def main():
     dm.run_iters(args.steps, theta_from_iter=0)
     ms, n = dm.profile_read()
     dm.profile(False)
+    kinfo = dm.info()
+    dm.close()
+
+    c4 = None
+    if not args.no_c4 and args.config == "c3":
+        c4 = c4_leg(counts, K, comm)
+
+    # whole-protocol parity + CPU baseline (rank 0): the same fit on the GPU and on the oracle
+    parity = None
+    cpu = None
+    if rank == 0 and not args.no_cpu:
+        np.random.seed(1)
+        dev = Vireo(n_var=N, n_cell=M, n_donor=K)
+        tg = time.perf_counter()
+        gtrace = dev._fit_VB(counts, None, verbose=False, **PROTOCOL)   # ELBO[:it], no constant
+        tg = time.perf_counter() - tg
+        # how far a 1e-13 relative perturbation of the initial ID_prob (the size of the GPU/CPU
+        # difference over the first iterations) moves the trace on the GPU itself: the first
+        # iterations leave a symmetric, unstable state (posteriors uniform to ~3e-7), and
+        # rounding-order differences are amplified while the clusters form; no two
+        # implementations can agree better mid-trace than this self-sensitivity
+        np.random.seed(1)
+        pert = Vireo(n_var=N, n_cell=M, n_donor=K)
+        pert.ID_prob = pert.ID_prob * (1.0 + 1e-13 * np.random.default_rng(7).standard_normal(pert.ID_prob.shape))
+        ptrace = pert._fit_VB(counts, None, verbose=False, **PROTOCOL)
+        self_rel = (np.abs(ptrace - gtrace) / np.abs(gtrace) if len(ptrace) == len(gtrace) else None)
+        del pert
+        dt, st, ctrace, it_cpu = cpu_protocol_leg(w, K, seed=1)
+        n_cpu = len(ctrace)
+        same_len = len(gtrace) == n_cpu
+        rel_it = np.abs(gtrace - ctrace) / np.abs(ctrace) if same_len else None
+        rel = None if rel_it is None else np.max(rel_it)
+        differ = dev.ID_prob.argmax(1) != st.ID_prob.argmax(1)
+        parity = dict(protocol="_fit_VB(min_iter=5, max_iter=20, delay_fit_theta=3) from "
+                               "np.random.seed(1): ELBO[:it] without the binomial constant",
+                      iterations_gpu=len(gtrace), iterations_cpu=n_cpu,
+                      elbo_trace_max_rel_err=None if rel is None else float(rel),
+                      elbo_trace_rel_err_per_iteration=None if rel_it is None else
+                      [float("%.3g" % x) for x in rel_it],
+                      elbo_final_rel_err=None if rel_it is None else float(rel_it[-1]),
+                      gpu_self_sensitivity_1e-13_per_iteration=None if self_rel is None else
+                      [float("%.3g" % x) for x in self_rel],
+                      elbo_final_gpu=float(gtrace[-1]), elbo_final_cpu=float(ctrace[-1]),
+                      id_prob_max_abs_err=float(np.max(np.abs(dev.ID_prob - st.ID_prob))),
+                      assignment_mismatches=int(differ.sum()),
+                      identical_assignments=bool(not differ.any()),
+                      gpu_fit_wall_s=round(tg, 3))
+        # the oracle executes one more iteration than it keeps (ELBO[:it], vireo_model.py:276)
+        cpu = dict(value=(n_cpu + 1) / dt, unit="EM iterations/s", cores=1, kind="port",
+                   sample="the whole timing protocol on the NumPy/SciPy oracle (the reference's 13 "
+                          "SpMM + 2 sparse-subtract op sequence per iteration, single-threaded "
+                          "like scipy.sparse): %d iterations of the %s inputs in %.1f s; box has "
+                          "%d cores" % (n_cpu + 1, args.config, dt, os.cpu_count()))
+        del st
+    del w
 
     if rank == 0:
-        kinfo = dm.info()
         B = algorithmic_bytes(N, M, K, T, nnz)
         avg_v = ms[_lib.KERN_VARIANT_PASS] / max(n[_lib.KERN_VARIANT_PASS], 1)
         avg_c = ms[_lib.KERN_CELL_PASS] / max(n[_lib.KERN_CELL_PASS], 1)
@@ -168,16 +251,23 @@ def main():
         ach = B[dom] / (avg * 1e-3) / 1e9
         info = _lib.device_info(local)
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this
-        # process; the figure comes from the committed rocprofv3 --pmc run of this same
-        # command (profiles/traffic_<config>.json) and is null when none matches.
+        # process; the figure comes from the committed rocprofv3 --pmc run of this same command
+        # (profiles/traffic_<config>.json, scratch/collect_traffic.py) and is quoted only when
+        # that run used the kernel sources this process was built from.
         traffic, traffic_src = None, None
-        kname = ("vrx_spmm_lds<4,%d>" % (dom == "cell")) if kinfo["lds_" + dom] else None
+        kname = ("vrx_spmm_lds<%d>" % (dom == "cell")) if kinfo["lds_" + dom] else None
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
         if kname and os.path.exists(tpath):
-            rec = json.load(open(tpath)).get("kernels", {}).get(kname)
-            if rec:
+            doc = json.load(open(tpath))
+            rec = doc.get("kernels", {}).get(kname)
+            if rec and doc.get("kernel_source_hash") == kernel_source_hash():
                 traffic = rec["traffic_bytes"]
-                traffic_src = "profiles/traffic_%s.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)" % args.config
+                traffic_src = ("profiles/traffic_%s.json (rocprofv3 --pmc FETCH_SIZE x2 + "
+                               "WRITE_SIZE, kernel sources %s)" % (args.config, kernel_source_hash()))
+            elif rec:
+                traffic_src = ("profiles/traffic_%s.json was collected on other kernel sources "
+                               "(%s, now %s): not quoted" % (args.config, doc.get("kernel_source_hash"),
+                                                             kernel_source_hash()))
         out = {
             "metric": "EM iterations/sec", "value": world * args.steps / wall_max,
             "unit": "EM iterations/s", "n_gpus": world, "steps": args.steps,
@@ -193,7 +283,8 @@ def main():
                        "host_setup_s": {"generate": round(t_gen, 1), "upload+transpose": round(t_up, 1)}},
             "roofline": {"bound": "hbm",
                          "kernel": "%s (%s pass)" % (
-                             "vrx_spmm_lds<4,%d>" % (dom == "cell") if kinfo["lds_" + dom]
+                             "vrx_spmm_lds<MODE %d, FORM %d>" % (dom == "cell", kinfo["cell_form"] if dom == "cell" else 0)
+                             if kinfo["lds_" + dom]
                              else "vrx_spmm<..,%d,fmt%d>" % (dom == "cell", kinfo["fmt_" + dom]), dom),
                          "kernel_info": kinfo,
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -208,6 +299,7 @@ def main():
                                              "frac": B["total"] / (wall_max / args.steps) / 1e9 / HBM_PEAK_GBS}},
             "cpu_baseline": cpu,
             "parity": parity,
+            "c4": c4,
         }
         if cpu:
             out["speedup_vs_cpu_1core"] = out["value"] / cpu["value"]

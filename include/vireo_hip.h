@@ -224,6 +224,32 @@ int vrx_comm_bcast_f64(vrx_comm* c, double* buf, int64_t n, int root);
  * `out`, or (out == NULL) skip them, advancing the MT19937 state of np.random.get_state()
  * (key[624], pos) in place.  Host only; no GPU needed. */
 int vrx_mt19937_random_sample(uint32_t* key624, int32_t* pos, double* out, int64_t n);
+/* np.sum() of a contiguous float32 array, bit for bit (NumPy's pairwise summation per 8192-element
+ * iterator chunk).  vrx_problem_binom_const adds the float32 terms of get_binom_coeff
+ * (vireo_base.py:7-22) with it, like vireo_model.py:313 does with np.sum.  Host only. */
+int vrx_np_sum_f32(const float* a, int64_t n, float* out);
+
+/* ---- MatrixMarket input (f4) -----------------------------------------------------------
+ * cellSNP.tag.{AD,DP}.mtx and the vartrix matrices, which the reference reads with
+ * scipy.io.mmread (io_utils.py:57,72-73): a multi-threaded parser of `coordinate`
+ * `integer` / `real` (integral values) / `pattern`, `general` files.  vrx_mtx_header returns
+ * the shape and entry count; vrx_mtx_read fills caller-allocated COO arrays (0-based, file
+ * order, duplicates kept).  n_threads <= 0: all cores (at most 64).  Host only. */
+int vrx_mtx_header(const char* path, int64_t* n_rows, int64_t* n_cols, int64_t* nnz);
+/* AD and DP (canonical CSC, any of the dtypes the reference's loaders produce) -> the union
+ * pattern with an (ad, dp) pair per entry, the input of vrx_problem_create: what
+ * `BD = DP - AD` and the separate AD / DP products of the reference (vireo_model.py:167-170)
+ * are replaced by.  Two passes: with rowidx == NULL the per-column entry counts go to
+ * colptr[1..n_cell]; the caller accumulates them and calls again to fill.  *_ptr64 / *_idx64:
+ * the index arrays are int64 (else int32); *_kind: counts are 0 int32, 1 int64, 2 float64.
+ * Host only, multi-threaded. */
+int vrx_merge_counts(int64_t n_var, int64_t n_cell, const void* ad_ptr, const void* ad_idx,
+                     const void* ad_dat, int ad_ptr64, int ad_idx64, int ad_kind,
+                     const void* dp_ptr, const void* dp_idx, const void* dp_dat, int dp_ptr64,
+                     int dp_idx64, int dp_kind, int64_t* colptr, int32_t* rowidx, int32_t* ad,
+                     int32_t* dp, int n_threads);
+int vrx_mtx_read(const char* path, int64_t nnz, int32_t* row, int32_t* col, int32_t* val,
+                 int n_threads);
 
 #ifdef __cplusplus
 }

@@ -54,9 +54,11 @@ def test_binom_const(va):
     AD, DP = gold.c1()
     c = va.device_counts(AD, DP).binom_const()
     assert c.dtype == np.float32
-    close(c, g["c1"], rtol=1e-6)
+    assert c == g["c1"]                         # bit-identical to np.sum(get_binom_coeff(...))
     mAD, mDP = gold.mito()                      # exercises the 700 clamp (DP up to 85197)
-    close(va.device_counts(mAD, mDP).binom_const(), g["mito"], rtol=1e-6)
+    assert va.device_counts(mAD, mDP).binom_const() == g["mito"]
+    for fmt in (csr_matrix, lambda x: x.toarray()):          # same constant for every input format
+        assert va.device_counts(fmt(AD), fmt(DP)).binom_const() == g["c1"]
 
 
 def test_onestep_each_update(va):

@@ -273,3 +273,23 @@ def test_socket_rendezvous_ignores_strangers():
     for t in threads:
         t.join()
     assert res == {r: bytes(range(128)) for r in range(3)}
+
+
+def test_float32_sum_is_numpys():
+    """vrx_np_sum_f32 (host C; adds the binomial-coefficient terms, vireo_model.py:313) against
+    np.sum itself at sizes around every block boundary of NumPy's chunked pairwise summation,
+    and on the reference's own terms of the demo data"""
+    from vireo_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    terms = gold.load("binom_const")["c1_terms"]
+    cases = [terms] + [(rng.random(n) * 9).astype(np.float32)
+                       for n in (0, 1, 7, 8, 9, 127, 128, 129, 255, 1000, 8191, 8192, 8193, 16385,
+                                 72858, 100003, 300001)]
+    for a in cases:
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        out = ctypes.c_float(0)
+        _lib.check(L.vrx_np_sum_f32(a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), a.size,
+                                    ctypes.byref(out)))
+        assert np.float32(out.value) == np.sum(a), a.size
+    assert np.float32(out.value) != 0

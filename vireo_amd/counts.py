@@ -28,36 +28,63 @@ def _as_canonical_csc(X, name):
     if not X.has_canonical_format:
         X = X.copy()
         X.sum_duplicates()      # also sorts the indices
-    d = X.data
-    if d.size:
-        if d.dtype.kind == "f":
-            if not np.all(d == np.floor(d)):
-                raise ValueError("%s holds non-integer counts" % name)
-        elif d.dtype.kind not in "iub":
-            raise ValueError("%s has unsupported dtype %s" % (name, d.dtype))
-        if d.min() < 0:
-            raise ValueError("%s holds negative counts" % name)
-        if d.max() > _I32_MAX:
-            raise ValueError("%s holds counts >= 2^31" % name)
+    if X.data.dtype.kind not in "fiub":
+        raise ValueError("%s has unsupported dtype %s" % (name, X.data.dtype))
     return X
+
+
+_KIND = {np.dtype(np.int32): 0, np.dtype(np.int64): 1, np.dtype(np.float64): 2}
+
+
+def _view(X):
+    """(indptr, indices, data, is64(indptr), is64(indices), count kind) for vrx_merge_counts"""
+    data = X.data if X.data.dtype in _KIND else X.data.astype(
+        np.float64 if X.data.dtype.kind == "f" else np.int64)
+    ptr = np.ascontiguousarray(X.indptr)
+    idx = np.ascontiguousarray(X.indices)
+    if ptr.dtype not in (np.int32, np.int64):
+        ptr = ptr.astype(np.int64)
+    if idx.dtype not in (np.int32, np.int64):
+        idx = idx.astype(np.int64)
+    return ptr, idx, np.ascontiguousarray(data), int(ptr.dtype == np.int64), \
+        int(idx.dtype == np.int64), _KIND[data.dtype]
 
 
 def merge_counts(AD, DP):
     """-> (shape, colptr int64[M+1], rowidx int32[nnz], ad int32[nnz], dp int32[nnz])
-    on the union pattern of AD and DP (entries where both are zero are dropped)."""
+    on the union pattern of AD and DP (entries where both are zero are dropped): a per-column
+    two-pointer merge in the library (vrx_merge_counts, all cores), which also checks that the
+    counts are non-negative integers below 2^31."""
     AD = _as_canonical_csc(AD, "AD")
     DP = _as_canonical_csc(DP, "DP")
     if AD.shape != DP.shape:
         raise ValueError("AD %s and DP %s differ in shape" % (AD.shape, DP.shape))
-    # one sparse add on packed (ad << 32 | dp) values gives the union pattern
-    hi = csc_matrix((AD.data.astype(np.int64) << 32, AD.indices, AD.indptr), shape=AD.shape)
-    lo = csc_matrix((DP.data.astype(np.int64), DP.indices, DP.indptr), shape=DP.shape)
-    U = hi + lo
-    if not U.has_sorted_indices:
-        U.sort_indices()
-    ad = (U.data >> 32).astype(np.int32)
-    dp = (U.data & 0xFFFFFFFF).astype(np.int32)
-    return (U.shape, U.indptr.astype(np.int64), U.indices.astype(np.int32), ad, dp)
+    n_var, n_cell = AD.shape
+    a, d = _view(AD), _view(DP)
+    vp = C.c_void_p
+
+    def call(colptr, rowidx, ad, dp):
+        i32 = C.POINTER(C.c_int32)
+        rc = _lib.lib().vrx_merge_counts(
+            n_var, n_cell, a[0].ctypes.data_as(vp), a[1].ctypes.data_as(vp), a[2].ctypes.data_as(vp),
+            a[3], a[4], a[5], d[0].ctypes.data_as(vp), d[1].ctypes.data_as(vp),
+            d[2].ctypes.data_as(vp), d[3], d[4], d[5],
+            colptr.ctypes.data_as(C.POINTER(C.c_int64)),
+            None if rowidx is None else rowidx.ctypes.data_as(i32),
+            None if ad is None else ad.ctypes.data_as(i32),
+            None if dp is None else dp.ctypes.data_as(i32), 0)
+        if rc != 0:
+            raise ValueError(_lib.lib().vrx_last_error().decode())
+
+    colptr = np.zeros(n_cell + 1, dtype=np.int64)
+    call(colptr, None, None, None)
+    np.cumsum(colptr, out=colptr)
+    nnz = int(colptr[-1])
+    rowidx = np.empty(nnz, dtype=np.int32)
+    ad = np.empty(nnz, dtype=np.int32)
+    dp = np.empty(nnz, dtype=np.int32)
+    call(colptr, rowidx, ad, dp)
+    return ((n_var, n_cell), colptr, rowidx, ad, dp)
 
 
 class DeviceCounts:
@@ -99,8 +126,10 @@ class DeviceCounts:
         return self._h
 
     def binom_const(self):
-        """float32(sum_{DP>0} float32(min(log C(DP,AD), 700))) -- what the reference adds
-        to the ELBO trace (vireo_model.py:313, bmm_model.py:239; a float32 scalar)."""
+        """np.sum(get_binom_coeff(AD, DP)): the float32 scalar the reference adds to the ELBO
+        trace (vireo_model.py:313, bmm_model.py:239).  The float32 terms come from the device,
+        in the reference's row-major entry order, and are added in NumPy's float32 pairwise
+        order, so the value equals the reference's bit for bit."""
         if self._binom is None:
             s = C.c_double(0.0)
             _lib.check(_lib.lib().vrx_problem_binom_const(self._h, C.byref(s)))

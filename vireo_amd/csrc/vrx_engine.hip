@@ -7,6 +7,7 @@
 #include <thread>
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -63,15 +64,27 @@ static constexpr int kXcd = 8;           // XCDs per MI355X; workgroup b is obse
 static constexpr double kSlabBytes = 1.6e6;  // dense-operand slab per tile (fits a 4 MiB L2)
 
 // Host-side build of a problem (validation, transposition, packing, tiling) is plain loops
-// over the non-zeros; they are spread over host threads (VIREO_HOST_THREADS, default <= 32).
+// over the non-zeros; they are spread over host threads (VIREO_HOST_THREADS, default <= 64).
 static int host_threads() {
     static const int n = [] {
         const char* v = getenv("VIREO_HOST_THREADS");
-        int t = v && *v ? atoi(v) : (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+        int t = v && *v ? atoi(v) : (int)std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
         return std::max(1, t);
     }();
     return n;
 }
+
+// uninitialised host array (a std::vector would zero hundreds of MB on one thread first)
+template <class T>
+struct RawArray {
+    T* p = nullptr;
+    explicit RawArray(size_t n) : p(static_cast<T*>(std::malloc(std::max<size_t>(n, 1) * sizeof(T)))) {}
+    RawArray(const RawArray&) = delete;
+    RawArray& operator=(const RawArray&) = delete;
+    ~RawArray() { std::free(p); }
+    T* data() { return p; }
+    T& operator[](size_t i) { return p[i]; }
+};
 
 // f(begin, end, tid) over [0, n) cut into contiguous chunks, one per thread
 template <class F>
@@ -121,7 +134,8 @@ static int build_orient(Orient& o, int64_t n_rows, int64_t n_contract, const int
     o.n_tiles = n_tiles;
     // ---- entries ------------------------------------------------------------------
     const int ew = fmt + 1;
-    std::vector<uint32_t> ent((size_t)o.nnz * ew);
+    RawArray<uint32_t> ent((size_t)o.nnz * ew);
+    VRX_REQUIRE(ent.p, "out of host memory");
     parallel_chunks(o.nnz, host_threads(), [&](int64_t b, int64_t e_end, int) {
         for (int64_t e = b; e < e_end; ++e) {
             const uint32_t id = (uint32_t)idx[e], ad = (uint32_t)val[e].x, dp = (uint32_t)val[e].y;
@@ -229,7 +243,7 @@ static int build_orient(Orient& o, int64_t n_rows, int64_t n_contract, const int
     o.n_seg = (int64_t)total;
     o.n_multi = (int64_t)multi_row.size();
     o.n_slots = slots;
-    VRX_HIP(o.ent.upload(ent.data(), ent.size(), s));
+    VRX_HIP(o.ent.upload(ent.data(), (size_t)o.nnz * ew, s));
     VRX_HIP(o.seg_begin.upload(seg_begin.data(), seg_begin.size(), s));
     VRX_HIP(o.seg_len.upload(seg_len.data(), seg_len.size(), s));
     VRX_HIP(o.seg_dst.upload(seg_dst.data(), seg_dst.size(), s));
@@ -293,7 +307,6 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
     const int64_t per_wave = (int64_t)t.n_slab * NR + 1;
     std::vector<int64_t> wave_start((size_t)n_wave), wave_len((size_t)n_wave, 0);
     std::vector<int32_t> bnd((size_t)(n_wave * per_wave));
-    std::vector<uint32_t> ent;
     std::atomic<bool> too_long{false};
     // ---- tile position -> piece (-1 = padding position) ---------------------------------
     std::vector<int32_t> rowmap((size_t)(n_wave * RW), -1);
@@ -316,20 +329,32 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
                 rowmap[(size_t)(w * RW + j * G + g)] = order[(size_t)(u * G + g)];
         }
     }
-    // One wave's stream: walks its RW pieces slab by slab; pass 1 (dst == nullptr) records the
-    // (slab, round) offsets and the length, pass 2 writes the words.  Waves are independent.
+    // One wave's stream: walks its RW pieces slab by slab, records the (slab, round) offsets
+    // and appends the words to the wave's own buffer.  Waves are independent.
     const bool parity_order = env_int("VIREO_LDS_PARITY", 1) != 0;
     // the entry bit that selects the LDS bank half of a 128-B dense row: half (form 1), parity
     // of the slab-local index (variant pass); none for the 256-B rows of the (ad, dp) cell pass
     const int bit_shift = form == 1 ? 7 : (mode == 0 ? 22 : -1);
+    // form 1 words carry the LDS address of their half row: the slab starts behind the rings
+    const uint32_t f1_base = 16u * VRX_RING * 4u, pad_word = form == 1 ? f1_base : 0u;
+    // FORM 1 value field: the top 14 bits of the IEEE double (sign, exponent, 2 mantissa bits).
+    // A value with more than three significant bits becomes several entries (9 = 8 + 1, ...).
     auto push_value = [](std::vector<uint32_t>& out, int64_t v, uint32_t off) {
-        while (v != 0) {  // chunks of 15 signed bits (counts past 16383 are rare: clone mode)
-            const int64_t c = std::max<int64_t>(-16384, std::min<int64_t>(16383, v));
-            out.push_back(((uint32_t)(int32_t)c << 17) | off);
+        while (v != 0) {
+            const uint64_t mag = (uint64_t)(v < 0 ? -v : v);
+            const int len = 64 - __builtin_clzll(mag), sh = std::max(0, len - 3);
+            const int64_t c = (int64_t)((mag >> sh) << sh) * (v < 0 ? -1 : 1);
+            const double d = (double)c;
+            uint64_t bits;
+            std::memcpy(&bits, &d, 8);
+            out.push_back((uint32_t)(bits >> 50) << 18 | off);
             v -= c;
         }
     };
-    auto walk = [&](int64_t w, uint32_t* dst) {
+    std::vector<std::vector<uint32_t>> wave_words((size_t)n_wave);
+    auto walk = [&](int64_t w) {
+        std::vector<uint32_t>& dst = wave_words[(size_t)w];
+        dst.reserve((size_t)((double)o.nnz / (double)n_wave * 2.3) + 1024);
         const int32_t* rm = rowmap.data() + w * RW;
         std::vector<int64_t> cursor((size_t)RW);
         std::vector<uint32_t> segw[G], second;
@@ -363,7 +388,7 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
                                              ((uint32_t)val[e].x << 11) | (uint32_t)val[e].y);
                         } else {
                             for (int64_t e = seg + off; e < hi; e += step) {
-                                const uint32_t at = (uint32_t)(idx[e] - base) * 256u;
+                                const uint32_t at = f1_base + (uint32_t)(idx[e] - base) * 256u;
                                 const int64_t ad = val[e].x, bd = (int64_t)val[e].y - val[e].x;
                                 push_value(sw, ad, at);
                                 push_value(sw, bd, at + 128u);
@@ -402,7 +427,7 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
                             continue;
                         }
                         const int64_t z = (zlo + zhi) / 2;
-                        const uint32_t pad1 = 1u << bit_shift;
+                        const uint32_t pad0 = form == 1 ? f1_base : 0u, pad1 = pad0 | 1u << bit_shift;
                         auto lay = [&](std::vector<uint32_t>& out, const std::vector<uint32_t>& first,
                                        uint32_t pad_first, const std::vector<uint32_t>& rest,
                                        uint32_t pad_rest) {
@@ -411,17 +436,17 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
                             out.insert(out.end(), rest.begin(), rest.end());
                             out.resize((size_t)longest, pad_rest);
                         };
-                        lay(segw[g], part[0][0], 0u, part[0][1], pad1);
-                        lay(segw[q], part[1][1], pad1, part[1][0], 0u);
+                        lay(segw[g], part[0][0], pad0, part[0][1], pad1);
+                        lay(segw[q], part[1][1], pad1, part[1][0], pad0);
                     }
                 }
                 // offset | entries in the last trip (0 = full): the kernel skips the padding
                 bw[(int64_t)sl * NR + r] = (int32_t)(rel | (longest % U));
                 longest = (longest + U - 1) / U * U;
-                if (dst)
-                    for (int64_t j = 0; j < longest; ++j)
-                        for (int g = 0; g < G; ++g)  // padding: a zero word (value 0, offset 0)
-                            dst[rel + j * G + g] = j < (int64_t)segw[g].size() ? segw[g][(size_t)j] : 0u;
+                dst.resize((size_t)(rel + longest * G));
+                for (int64_t j = 0; j < longest; ++j)
+                    for (int g = 0; g < G; ++g)  // padding: value 0 (form 1: at the slab's first row)
+                        dst[(size_t)(rel + j * G + g)] = j < (int64_t)segw[g].size() ? segw[g][(size_t)j] : pad_word;
                 rel += longest * G;  // (a multiple of 64 words: streams stay 16-B aligned)
             }
         }
@@ -429,7 +454,7 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
         wave_len[(size_t)w] = rel;
     };
     parallel_chunks(n_wave, host_threads(), [&](int64_t b0, int64_t e0, int) {
-        for (int64_t w = b0; w < e0; ++w) walk(w, nullptr);
+        for (int64_t w = b0; w < e0; ++w) walk(w);
     });
     if (too_long) {
         vrx_set_error("tiled stream: wave stream >= 2^31 words");
@@ -449,12 +474,23 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
         t.ready = false;
         return VRX_OK;
     }
-    ent.assign((size_t)total, 0u);
-    parallel_chunks(n_wave, host_threads(), [&](int64_t b0, int64_t e0, int) {
-        for (int64_t w = b0; w < e0; ++w) walk(w, ent.data() + wave_start[(size_t)w]);
-    });
-    for (int i = 0; i < 8; ++i) ent.push_back(0u);  // slack for the last dwordx4 refill
-    VRX_HIP(t.ent.upload(ent.data(), ent.size(), s));
+    // the waves' buffers go to the device back to back (+ slack for the last dwordx4 refill)
+    VRX_HIP(t.ent.alloc((size_t)total + 8));
+    VRX_HIP(hipMemsetAsync(t.ent.p + total, 0, 8 * sizeof(uint32_t), s));
+    {
+        std::unique_ptr<uint32_t[]> all(new uint32_t[(size_t)total + 1]);
+        parallel_chunks(n_wave, host_threads(), [&](int64_t b0, int64_t e0, int) {
+            for (int64_t w = b0; w < e0; ++w) {
+                std::vector<uint32_t>& src = wave_words[(size_t)w];
+                if (!src.empty())
+                    std::memcpy(all.get() + wave_start[(size_t)w], src.data(), src.size() * sizeof(uint32_t));
+                std::vector<uint32_t>().swap(src);
+            }
+        });
+        VRX_HIP(hipMemcpyAsync(t.ent.p, all.get(), (size_t)total * sizeof(uint32_t),
+                               hipMemcpyHostToDevice, s));
+        VRX_HIP(hipStreamSynchronize(s));
+    }
     VRX_HIP(t.wave_start.upload(wave_start.data(), wave_start.size(), s));
     VRX_HIP(t.bnd.upload(bnd.data(), bnd.size(), s));
     VRX_HIP(t.rowmap.upload(rowmap.data(), rowmap.size(), s));
@@ -495,7 +531,7 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
     // into one contiguous chunk per host thread; every thread keeps its own per-variant
     // histogram, which also gives it private write cursors for the transposition below
     // (a parallel counting sort: cells stay increasing inside each variant row).
-    std::vector<int2> cval((size_t)nnz);
+    RawArray<int2> cval((size_t)nnz);
     std::vector<int64_t> rptr((size_t)n_var + 1, 0);
     p->n_vars.assign((size_t)n_cell, 0);
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), n_cell));
@@ -561,8 +597,9 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
         }
         rptr[(size_t)r + 1] = at;
     }
-    std::vector<int32_t> ridx((size_t)nnz);
-    std::vector<int2> rval((size_t)nnz);
+    RawArray<int32_t> ridx((size_t)nnz);
+    RawArray<int2> rval((size_t)nnz);
+    VRX_REQUIRE(cval.p && ridx.p && rval.p, "out of host memory");
     parallel_chunks(n_cell, nt, [&](int64_t c0, int64_t c1, int tid) {
         auto& cur = hist[(size_t)tid];
         for (int64_t c = c0; c < c1; ++c)
@@ -643,29 +680,39 @@ extern "C" void vrx_problem_destroy(vrx_problem* p) {
     delete p;
 }
 
+// The float32 terms are formed on the device in the reference's indexing order (row-major:
+// the variant-major orientation's storage order), brought to the host and added there in
+// NumPy's float32 pairwise order, so the constant equals the reference's bit for bit (up to a
+// term whose float64 value sits within 1e-16 of a float32 rounding boundary: lgamma here,
+// log(binom()) there).  Once per problem.
 extern "C" int vrx_problem_binom_const(vrx_problem* p, double* sum_out) {
     VRX_REQUIRE(p && sum_out, "vrx_problem_binom_const: null argument");
     if (!p->binom_done) {
         VRX_HIP(hipSetDevice(p->device));
-        const int nb = (int)std::min<int64_t>(std::max<int64_t>((p->nnz + VRX_BLOCK - 1) / VRX_BLOCK, 1),
-                                              (int64_t)p->n_cu * 8);
-        DevBuf<double> part;
-        VRX_HIP(part.alloc((size_t)nb));
-        const Orient& o = p->by_cell;
-        if (o.fmt == VRX_FMT_P32)
-            vrx_binom_partial<VRX_FMT_P32><<<nb, VRX_BLOCK, 0, p->stream>>>(p->nnz, o.ent.p, part.p);
-        else if (o.fmt == VRX_FMT_P64)
-            vrx_binom_partial<VRX_FMT_P64><<<nb, VRX_BLOCK, 0, p->stream>>>(p->nnz, o.ent.p, part.p);
-        else
-            vrx_binom_partial<VRX_FMT_WIDE><<<nb, VRX_BLOCK, 0, p->stream>>>(p->nnz, o.ent.p, part.p);
-        VRX_HIP(hipGetLastError());
-        std::vector<double> h((size_t)nb);
-        VRX_HIP(hipMemcpyAsync(h.data(), part.p, (size_t)nb * sizeof(double), hipMemcpyDeviceToHost,
-                               p->stream));
-        VRX_HIP(hipStreamSynchronize(p->stream));
-        double s = 0.0;
-        for (double v : h) s += v;
-        p->binom_sum = s;
+        const Orient& o = p->by_var;
+        const int64_t n = o.nnz;
+        std::vector<float> h((size_t)n);
+        if (n > 0) {
+            DevBuf<float> terms;
+            VRX_HIP(terms.alloc((size_t)n));
+            const unsigned nb = (unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK);
+            if (o.fmt == VRX_FMT_P32)
+                vrx_binom_terms<VRX_FMT_P32><<<nb, VRX_BLOCK, 0, p->stream>>>(n, o.ent.p, terms.p);
+            else if (o.fmt == VRX_FMT_P64)
+                vrx_binom_terms<VRX_FMT_P64><<<nb, VRX_BLOCK, 0, p->stream>>>(n, o.ent.p, terms.p);
+            else
+                vrx_binom_terms<VRX_FMT_WIDE><<<nb, VRX_BLOCK, 0, p->stream>>>(n, o.ent.p, terms.p);
+            VRX_HIP(hipGetLastError());
+            VRX_HIP(hipMemcpyAsync(h.data(), terms.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost,
+                                   p->stream));
+            VRX_HIP(hipStreamSynchronize(p->stream));
+        }
+        int64_t m = 0;
+        for (int64_t i = 0; i < n; ++i)
+            if (h[(size_t)i] == h[(size_t)i]) h[(size_t)m++] = h[(size_t)i];  // drop the dp == 0 marks
+        float total = 0.f;
+        if (vrx_np_sum_f32(h.data(), m, &total)) return VRX_ERR_ARG;
+        p->binom_sum = (double)total;
         p->binom_done = true;
     }
     *sum_out = p->binom_sum;
@@ -707,6 +754,7 @@ struct vrx_model {
     int nb_theta = 0, nb_nk = 0, nb_cell = 0, nb_throws = 0, n_th_part = 1;
     DevBuf<double> part_theta, part_gt, part_cell, part_th;
     DevBuf<double> d_elbo, d_parts;
+    DevBuf<int32_t> ctl;  // device-side loop control (VRX_CTL_*)
     DevBuf<double> snapID, snapGT, snapTh;  // vrx_model_snapshot
     bool snap_valid = false;
     double* h_pin = nullptr;  // pinned staging for scalar read-backs
@@ -839,6 +887,8 @@ extern "C" int vrx_model_create(vrx_problem* p, const vrx_model_cfg* cfg, vrx_mo
     VRX_HIP(m->part_th.alloc((size_t)m->n_th_part));
     VRX_HIP(hipMemsetAsync(m->part_th.p, 0, (size_t)m->n_th_part * sizeof(double), s));
     VRX_HIP(m->d_elbo.alloc(kMaxTrace));
+    VRX_HIP(m->ctl.alloc(VRX_CTL_WORDS));
+    VRX_HIP(hipMemsetAsync(m->ctl.p, 0, VRX_CTL_WORDS * sizeof(int32_t), s));
     VRX_HIP(m->d_parts.alloc(4));
     VRX_HIP(hipHostMalloc(reinterpret_cast<void**>(&m->h_pin), 64 * sizeof(double), hipHostMallocDefault));
     VRX_HIP(hipEventCreate(&m->t0));
@@ -1044,11 +1094,11 @@ extern "C" int vrx_model_set_prior(vrx_model* m, const double* ID_prior, int64_t
 // ------------------------------------------------------------------------------------
 template <int LPE, int CPL, int MODE>
 static void launch_spmm_fmt(const Orient& o, dim3 grid, hipStream_t s, const double* X, int K,
-                            double* out, double* partial) {
+                            double* out, double* partial, const int32_t* ctl) {
 #define VRX_GO(F)                                                                              \
     vrx_spmm<LPE, CPL, MODE, F><<<grid, VRX_BLOCK, 0, s>>>(o.n_seg, o.seg_begin.p, o.seg_len.p, \
                                                            o.seg_dst.p, o.ent.p, X, K, out,    \
-                                                           partial)
+                                                           partial, ctl)
     if (o.fmt == VRX_FMT_P32)
         VRX_GO(VRX_FMT_P32);
     else if (o.fmt == VRX_FMT_P64)
@@ -1073,7 +1123,8 @@ template <int LPE, int MODE, int RW>
 static auto lds_kernel_rw(int K, bool strided) {
     static const int split_on = env_int("VIREO_LDS_SPLIT_K", 1);
     const int split = std::min(LPE, !split_on ? 1 : K <= 4 ? 4 : K <= 8 ? 2 : 1);
-    const bool pad = K % 4 != 0 || strided;  // (the element-wise slab copy handles row strides)
+    // (the element-wise slab copy handles row strides and rows that do not fill whole lanes)
+    const bool pad = K % (16 / LPE) != 0 || strided;
     if constexpr (LPE >= 4)
         if (split == 4)
             return pad ? vrx_spmm_lds<LPE, MODE, RW, true, 4> : vrx_spmm_lds<LPE, MODE, RW, false, 4>;
@@ -1104,7 +1155,8 @@ static auto lds_kernel(int K, bool strided, int rw, int form) {
 }
 
 template <int LPE, int MODE>
-static int launch_lds_one(const Orient& o, hipStream_t s, const double* X, int K, double* dst) {
+static int launch_lds_one(const Orient& o, hipStream_t s, const double* X, int K, double* dst,
+                          const int32_t* ctl) {
     const TiledStream& t = o.tiled;
     constexpr int XD = MODE == 1 ? 2 : 1, NV = MODE == 0 ? 2 : 1;
     dim3 grid((unsigned)t.n_tile, (unsigned)t.n_range);
@@ -1113,14 +1165,15 @@ static int launch_lds_one(const Orient& o, hipStream_t s, const double* X, int K
     for (int c0 = 0; c0 < K; c0 += 16) {
         const int kb = std::min(16, K - c0);
         const bool f1 = MODE == 1 && t.form == 1;  // planar operand, 256-B LDS rows
-        const size_t lds = (size_t)t.slab_rows * (f1 ? 256 : ((kb + 3) & ~3) * (MODE == 1 ? 16 : 8)) +
+        constexpr int CPL = 16 / LPE;  // columns per lane: LDS rows hold whole lanes
+        const size_t lds = (size_t)t.slab_rows * (f1 ? 256 : (kb + CPL - 1) / CPL * CPL * (MODE == 1 ? 16 : 8)) +
                            16 * VRX_RING * 4;
         auto kern = lds_kernel<LPE, MODE>(kb, K > 16, t.rw, t.form);
         VRX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         kern<<<grid, 1024, lds, s>>>(t.ent.p, t.wave_start.p, t.bnd.p, t.rowmap.p, t.n_slab,
                                      t.slab_rows, o.n_contract, t.n_vrows,
-                                     X + (size_t)c0 * (f1 ? 1 : XD), kb, K, dst + (size_t)c0 * NV);
+                                     X + (size_t)c0 * (f1 ? 1 : XD), kb, K, dst + (size_t)c0 * NV, ctl);
         VRX_HIP(hipGetLastError());
     }
     return VRX_OK;
@@ -1134,21 +1187,21 @@ static int launch_spmm_lds(vrx_model* m, const Orient& o, const double* X, int K
     constexpr int NV = MODE == 0 ? 2 : 1;
     double* dst = t.n_range == 1 && !t.split ? out : range_partial;
     int rc;
-    rc = launch_lds_one<VRX_LDS_LPE, MODE>(o, s, X, K, dst);  // K < 16 leaves lanes idle
+    rc = launch_lds_one<VRX_LDS_LPE, MODE>(o, s, X, K, dst, m->ctl.p);  // K < 16 leaves lanes idle
     if (rc) return rc;
     if (t.split) {  // rows cut into pieces: sum pieces and ranges in one fixed order
         const int64_t n = o.n_rows * K * NV;
         if ((int64_t)t.n_range * t.n_vrows >= 64 * o.n_rows)  // >= 64 terms per row on average
             vrx_sum_pieces_wave<<<(unsigned)((n * 64 + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
-                o.n_rows, K * NV, t.n_range, t.n_vrows, t.vptr.p, range_partial, out);
+                o.n_rows, K * NV, t.n_range, t.n_vrows, t.vptr.p, range_partial, out, m->ctl.p);
         else
             vrx_sum_pieces<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
-                o.n_rows, K * NV, t.n_range, t.n_vrows, t.vptr.p, range_partial, out);
+                o.n_rows, K * NV, t.n_range, t.n_vrows, t.vptr.p, range_partial, out, m->ctl.p);
         VRX_HIP(hipGetLastError());
     } else if (t.n_range > 1 && !defer_sum) {
         const int64_t n = o.n_rows * K * NV;
         vrx_sum_ranges<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
-            n, t.n_range, range_partial, out);
+            n, t.n_range, range_partial, out, m->ctl.p);
         VRX_HIP(hipGetLastError());
     }
     return VRX_OK;
@@ -1167,19 +1220,19 @@ static int launch_spmm(vrx_model* m, const Orient& o, const double* X, int K, do
     if (cpl == 2) {
         if (MODE == 0) {  // (guard keeps the CPL=2 cell-pass templates from being instantiated)
             switch (lpe) {
-                case 1: launch_spmm_fmt<1, 2, 0>(o, grid, s, X, K, out, partial); break;
-                case 2: launch_spmm_fmt<2, 2, 0>(o, grid, s, X, K, out, partial); break;
-                case 4: launch_spmm_fmt<4, 2, 0>(o, grid, s, X, K, out, partial); break;
-                default: launch_spmm_fmt<8, 2, 0>(o, grid, s, X, K, out, partial); break;
+                case 1: launch_spmm_fmt<1, 2, 0>(o, grid, s, X, K, out, partial, m->ctl.p); break;
+                case 2: launch_spmm_fmt<2, 2, 0>(o, grid, s, X, K, out, partial, m->ctl.p); break;
+                case 4: launch_spmm_fmt<4, 2, 0>(o, grid, s, X, K, out, partial, m->ctl.p); break;
+                default: launch_spmm_fmt<8, 2, 0>(o, grid, s, X, K, out, partial, m->ctl.p); break;
             }
         }
     } else {
         switch (lpe) {
-            case 1: launch_spmm_fmt<1, 1, MODE>(o, grid, s, X, K, out, partial); break;
-            case 2: launch_spmm_fmt<2, 1, MODE>(o, grid, s, X, K, out, partial); break;
-            case 4: launch_spmm_fmt<4, 1, MODE>(o, grid, s, X, K, out, partial); break;
-            case 8: launch_spmm_fmt<8, 1, MODE>(o, grid, s, X, K, out, partial); break;
-            default: launch_spmm_fmt<16, 1, MODE>(o, grid, s, X, K, out, partial); break;
+            case 1: launch_spmm_fmt<1, 1, MODE>(o, grid, s, X, K, out, partial, m->ctl.p); break;
+            case 2: launch_spmm_fmt<2, 1, MODE>(o, grid, s, X, K, out, partial, m->ctl.p); break;
+            case 4: launch_spmm_fmt<4, 1, MODE>(o, grid, s, X, K, out, partial, m->ctl.p); break;
+            case 8: launch_spmm_fmt<8, 1, MODE>(o, grid, s, X, K, out, partial, m->ctl.p); break;
+            default: launch_spmm_fmt<16, 1, MODE>(o, grid, s, X, K, out, partial, m->ctl.p); break;
         }
     }
     VRX_HIP(hipGetLastError());
@@ -1187,7 +1240,7 @@ static int launch_spmm(vrx_model* m, const Orient& o, const double* X, int K, do
         constexpr int VPE = MODE == 0 ? 2 : 1;
         const int64_t tot = o.n_multi * K * VPE;
         vrx_sum_slots<VPE><<<(unsigned)((tot + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
-            o.n_multi, K, o.multi_row.p, o.multi_ptr.p, partial, out);
+            o.n_multi, K, o.multi_row.p, o.multi_ptr.p, partial, out, m->ctl.p);
         VRX_HIP(hipGetLastError());
     }
     return VRX_OK;
@@ -1218,7 +1271,7 @@ static int resolve_S(vrx_model* m) {
     if (!m->s_pending) return VRX_OK;
     const int64_t n = m->NK * 2;
     vrx_sum_ranges<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, m->p->stream>>>(
-        n, m->p->by_var.tiled.n_range, m->RV.p, m->S.p);
+        n, m->p->by_var.tiled.n_range, m->RV.p, m->S.p, m->ctl.p);
     VRX_HIP(hipGetLastError());
     m->s_pending = false;
     return VRX_OK;
@@ -1228,7 +1281,7 @@ static int resolve_LID(vrx_model* m) {
     if (!m->l_pending) return VRX_OK;
     const int64_t n = m->M * m->K;
     vrx_sum_ranges<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, m->p->stream>>>(
-        n, m->p->by_cell.tiled.n_range, m->RC.p, m->LID.p);
+        n, m->p->by_cell.tiled.n_range, m->RC.p, m->LID.p, m->ctl.p);
     VRX_HIP(hipGetLastError());
     m->l_pending = false;
     return VRX_OK;
@@ -1247,26 +1300,26 @@ static int theta_step(vrx_model* m, int update) {
         vrx_bmm_theta<<<m->nb_nk, VRX_BLOCK, 0, s>>>(
             m->NK, update, c.fix_beta_sum, reinterpret_cast<const double2*>(m->S.p), m->prior1.p,
             m->prior2.p, m->prior_rows == 1 ? 0 : 1, m->mu.p, m->sm.p, m->W.p, m->K, m->wform,
-            m->part_th.p);
+            m->part_th.p, m->ctl.p);
         m->w_valid = true;
     } else if (c.ase_mode) {
         vrx_theta_ase<<<m->nb_throws, VRX_BLOCK, 0, s>>>(
             m->N, m->K, m->T, update, c.fix_beta_sum, reinterpret_cast<const double2*>(m->S.p),
             m->GT.p, m->prior1.p, m->prior2.p, (int)m->prior_rows, m->mu.p, m->sm.p, m->psi.p,
-            m->part_th.p);
+            m->part_th.p, m->ctl.p);
         m->w_valid = false;
     } else {
         if (update) {
             const int nr = m->s_pending ? m->p->by_var.tiled.n_range : 0;
             vrx_theta_partial<<<m->nb_theta, VRX_BLOCK, 0, s>>>(
                 m->NK, m->T, reinterpret_cast<double2*>(m->S.p), nr,
-                reinterpret_cast<const double2*>(m->RV.p), m->GT.p, m->part_theta.p);
+                reinterpret_cast<const double2*>(m->RV.p), m->GT.p, m->part_theta.p, m->ctl.p);
             VRX_HIP(hipGetLastError());
             m->s_pending = false;
         }
         vrx_theta_final<<<1, VRX_BLOCK, 0, s>>>(m->nb_theta, m->T, update, c.fix_beta_sum,
                                                  m->part_theta.p, m->prior1.p, m->prior2.p, m->mu.p,
-                                                 m->sm.p, m->psi.p, m->part_th.p);
+                                                 m->sm.p, m->psi.p, m->part_th.p, m->ctl.p);
         m->w_valid = false;
     }
     VRX_HIP(hipGetLastError());
@@ -1283,10 +1336,31 @@ static int gt_step(vrx_model* m, int learn) {
     vrx_gt_update<<<m->nb_nk, VRX_BLOCK, 0, m->p->stream>>>(
         m->NK, m->K, m->T, learn, m->cfg.ase_mode, m->N, reinterpret_cast<const double2*>(m->S.p),
         m->psi.p, m->logq_gt.p, m->gt_mode, -std::log((double)m->T), m->GT.p, m->W.p, m->wform,
-        m->part_gt.p);
+        m->part_gt.p, m->ctl.p);
     VRX_HIP(hipGetLastError());
     m->w_valid = true;
     return VRX_OK;
+}
+
+static VrxElboIn elbo_inputs(vrx_model* m) {
+    VrxElboIn e;
+    e.cell_part = m->part_cell.p;
+    e.gt_part = m->part_gt.p;
+    e.th_part = m->part_th.p;
+    e.n_cell_part = m->nb_cell;
+    e.n_gt_part = m->cfg.kind == VRX_KIND_VIREO ? m->nb_nk : 0;
+    e.n_th_part = m->n_th_part;
+    e.elbo = m->d_elbo.p;
+    e.parts = m->d_parts.p;
+    return e;
+}
+
+static VrxStopRule no_rule(int slot) {
+    VrxStopRule r;
+    r.it = slot;
+    r.min_iter = r.max_iter = r.active = 0;
+    r.eps = 0.0;
+    return r;
 }
 
 static int softmax_step(vrx_model* m, int update) {
@@ -1297,10 +1371,9 @@ static int softmax_step(vrx_model* m, int update) {
     m->l_pending = false;
 #define VRX_SM_CASE(KPV)                                                                        \
     case KPV:                                                                                   \
-        vrx_cell_softmax<KPV><<<m->nb_cell, VRX_BLOCK, 0, s>>>(m->M, m->K, update, m->LID.p, nr,\
-                                                               m->RC.p, m->logq_id.p,           \
-                                                               m->id_mode, lu, m->ID.p,         \
-                                                               m->part_cell.p);                 \
+        vrx_cell_softmax<KPV><<<m->nb_cell, VRX_BLOCK, 0, s>>>(                                 \
+            m->M, m->K, update, m->LID.p, nr, m->RC.p, m->logq_id.p, m->id_mode, lu, m->ID.p,   \
+            m->part_cell.p, m->ctl.p);                                                          \
         break;
     switch (m->KP) {
         VRX_SM_CASE(1)
@@ -1316,19 +1389,17 @@ static int softmax_step(vrx_model* m, int update) {
     return VRX_OK;
 }
 
-static int elbo_step(vrx_model* m, int slot) {
+// ELBO of iteration rule.it into the trace; evaluates the stop rule when it is active
+static int elbo_step(vrx_model* m, const VrxStopRule& rule) {
     ProfScope ps(m, VRX_KERN_DENSE);
-    const int n_gt = m->cfg.kind == VRX_KIND_VIREO ? m->nb_nk : 0;
-    vrx_elbo_final<<<1, VRX_BLOCK, 0, m->p->stream>>>(m->part_cell.p, m->nb_cell, m->part_gt.p, n_gt,
-                                                      m->part_th.p, m->n_th_part,
-                                                      m->d_elbo.p + slot, m->d_parts.p);
+    vrx_elbo_final<<<1, VRX_BLOCK, 0, m->p->stream>>>(elbo_inputs(m), rule, m->ctl.p);
     VRX_HIP(hipGetLastError());
     return VRX_OK;
 }
 
 // One iteration of _fit_VB (vireo_model.py:257-264) / _fit_BV (bmm_model.py:183-188).
 // Enqueue only; no host synchronisation.
-static int enqueue_iteration(vrx_model* m, bool do_theta, int slot) {
+static int enqueue_iteration(vrx_model* m, bool do_theta, const VrxStopRule& rule) {
     int rc;
     const auto& c = m->cfg;
     if (c.kind == VRX_KIND_BMM) {
@@ -1353,7 +1424,12 @@ static int enqueue_iteration(vrx_model* m, bool do_theta, int slot) {
     }
     if ((rc = cell_pass(m, true))) return rc;  // range sum fused into the softmax kernel
     if ((rc = softmax_step(m, 1))) return rc;
-    return elbo_step(m, slot);
+    return elbo_step(m, rule);                 // ELBO + the stop rule, on the device
+}
+
+static int reset_ctl(vrx_model* m) {  // stop flag, stop iteration, warn flags (tickets stay 0)
+    VRX_HIP(hipMemsetAsync(m->ctl.p, 0, 3 * sizeof(int32_t), m->p->stream));
+    return VRX_OK;
 }
 
 // psi / KL_theta (and, for fixed GT or BMM, W) consistent with the state just uploaded
@@ -1374,34 +1450,42 @@ extern "C" int vrx_model_fit(vrx_model* m, int32_t max_iter, int32_t min_iter, d
     VRX_HIP(hipSetDevice(m->p->device));
     hipStream_t s = m->p->stream;
     int rc;
+    if ((rc = reset_ctl(m))) return rc;
     if ((rc = prepare(m))) return rc;
-    int flags = 0, it = 0;
-    double prev = 0.0;
-    for (it = 0; it < max_iter; ++it) {
-        const bool do_theta = m->cfg.kind == VRX_KIND_VIREO && m->cfg.learn_theta &&
-                              it >= delay_fit_theta;
-        if ((rc = enqueue_iteration(m, do_theta, it))) return rc;
-        // the convergence test only looks at it > min_iter (and needs ELBO[it-1])
-        if (it >= min_iter || it == max_iter - 1) {
-            VRX_HIP(hipMemcpyAsync(m->h_pin, m->d_elbo.p + it, sizeof(double), hipMemcpyDeviceToHost, s));
-            VRX_HIP(hipStreamSynchronize(s));
-            const double cur = m->h_pin[0];
-            if (it > min_iter) {
-                if (cur < prev - 1e-6) {
-                    flags |= 1;
-                } else if (it == max_iter - 1) {
-                    flags |= 2;
-                } else if (cur - prev < eps) {
-                    break;
-                }
-            }
-            prev = cur;
+    // The stop rule runs on the device (vrx_elbo_final_block); the host enqueues a batch of
+    // iterations, then reads three control words.  The first batch reaches the first iteration
+    // the rule can fire at (min_iter + 1); a kernel launched after the stop returns at once, so
+    // an overshoot costs launches, not work.
+    static const int batch = std::max(1, env_int("VIREO_FIT_BATCH", 4));
+    int32_t* hctl = reinterpret_cast<int32_t*>(m->h_pin);
+    int it = 0, flags = 0, next = 0;
+    bool stopped = false;
+    while (next < max_iter && !stopped) {
+        const int upto = std::min(max_iter, next == 0 ? std::max(min_iter + 2, batch) : next + batch);
+        for (it = next; it < upto; ++it) {
+            VrxStopRule rule;
+            rule.it = it;
+            rule.min_iter = min_iter;
+            rule.max_iter = max_iter;
+            rule.active = 1;
+            rule.eps = eps;
+            const bool do_theta = m->cfg.kind == VRX_KIND_VIREO && m->cfg.learn_theta &&
+                                  it >= delay_fit_theta;
+            if ((rc = enqueue_iteration(m, do_theta, rule))) return rc;
         }
+        next = upto;
+        VRX_HIP(hipMemcpyAsync(hctl, m->ctl.p, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        VRX_HIP(hipStreamSynchronize(s));
+        stopped = hctl[VRX_CTL_STOP] != 0;
+        flags = hctl[VRX_CTL_WARN];
     }
-    if (it == max_iter) it = max_iter - 1;  // Python leaves `it` at the last executed index
+    it = stopped ? hctl[VRX_CTL_IT] : max_iter - 1;  // Python leaves `it` at the last executed index
     VRX_HIP(hipMemcpyAsync(elbo_trace, m->d_elbo.p, (size_t)(it + 1) * sizeof(double),
                            hipMemcpyDeviceToHost, s));
     VRX_HIP(hipStreamSynchronize(s));
+    if (stopped) {  // the launches behind the stop did nothing; the next call starts clean
+        if ((rc = reset_ctl(m))) return rc;
+    }
     if ((rc = prof_drain(m))) return rc;
     *it_out = it;
     if (warn_flags) *warn_flags = flags;
@@ -1414,12 +1498,13 @@ extern "C" int vrx_model_run_iters(vrx_model* m, int32_t n_iter, int32_t theta_f
     VRX_HIP(hipSetDevice(m->p->device));
     hipStream_t s = m->p->stream;
     int rc;
+    if ((rc = reset_ctl(m))) return rc;
     if ((rc = prepare(m))) return rc;
     VRX_HIP(hipEventRecord(m->t0, s));
     for (int it = 0; it < n_iter; ++it) {
         const bool do_theta = m->cfg.kind == VRX_KIND_VIREO && m->cfg.learn_theta &&
                               it >= theta_from_iter;
-        if ((rc = enqueue_iteration(m, do_theta, it))) return rc;
+        if ((rc = enqueue_iteration(m, do_theta, no_rule(it)))) return rc;
     }
     VRX_HIP(hipEventRecord(m->t1, s));
     VRX_HIP(hipStreamSynchronize(s));
@@ -1439,6 +1524,7 @@ extern "C" int vrx_model_step(vrx_model* m, int32_t which, double* elbo_out) {
     hipStream_t s = m->p->stream;
     const auto& c = m->cfg;
     int rc;
+    if ((rc = reset_ctl(m))) return rc;
     switch (which) {
         case VRX_STEP_THETA:
             if ((rc = variant_pass(m))) return rc;
@@ -1468,7 +1554,7 @@ extern "C" int vrx_model_step(vrx_model* m, int32_t which, double* elbo_out) {
             if (c.kind == VRX_KIND_VIREO)
                 if ((rc = gt_step(m, 0))) return rc;
             if ((rc = softmax_step(m, 0))) return rc;
-            if ((rc = elbo_step(m, 0))) return rc;
+            if ((rc = elbo_step(m, no_rule(0)))) return rc;
             VRX_HIP(hipMemcpyAsync(m->h_pin, m->d_elbo.p, sizeof(double), hipMemcpyDeviceToHost, s));
             VRX_HIP(hipStreamSynchronize(s));
             *elbo_out = m->h_pin[0];

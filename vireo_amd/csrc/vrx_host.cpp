@@ -12,7 +12,9 @@
 //   Algorithm restated from NumPy's public implementation (numpy/random/src/mt19937):
 //   MT19937 (Matsumoto & Nishimura 1998) with the genrand_res53 conversion
 //   (a >> 5, b >> 6) -> (a * 2^26 + b) / 2^53.
+#include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 
 #include "../../include/vireo_hip.h"
@@ -106,5 +108,422 @@ extern "C" int vrx_mt19937_random_sample(uint32_t* key624, int32_t* pos, double*
         p += i;
     }
     *pos = p;
+    return VRX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// np.sum of a contiguous float32 array, bit for bit
+// ------------------------------------------------------------------------------------
+// NumPy's pairwise summation of one iterator chunk (blocks of <= 128 terms on eight running
+// sums, halves cut at multiples of 8), in float32 -- how the reference's
+// `np.sum(get_binom_coeff(AD, DP))` (vireo_model.py:313, bmm_model.py:239) adds its terms
+// (restated from numpy/_core/src/umath/loops_utils.h.src; pinned by tests/test_host_cpu.py
+// against np.sum itself and by the golden constants)
+static float np_pairwise_sum_f32(const float* a, int64_t n) {
+    if (n < 8) {
+        float r = 0.f;
+        for (int64_t i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    if (n <= 128) {
+        float r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        int64_t i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum_f32(a, n2) + np_pairwise_sum_f32(a + n2, n - n2);
+}
+
+
+// np.sum walks a 1-D array through its iterator buffer, 8192 elements at a time
+// (np.getbufsize()): every chunk is summed pairwise, the chunk sums are added in order.
+extern "C" int vrx_np_sum_f32(const float* a, int64_t n, float* out) {
+    if ((!a && n > 0) || n < 0 || !out) {
+        vrx_set_error("vrx_np_sum_f32: bad argument");
+        return VRX_ERR_ARG;
+    }
+    float total = 0.f;
+    for (int64_t at = 0; at < n; at += 8192)
+        total += np_pairwise_sum_f32(a + at, n - at < 8192 ? n - at : 8192);
+    *out = total;
+    return VRX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// MatrixMarket coordinate files (cellSNP.tag.AD.mtx / .DP.mtx, vartrix alt / ref matrices)
+// ------------------------------------------------------------------------------------
+// The reference loads them with scipy.io.mmread (vireoSNP/utils/io_utils.py:57,72-73), a
+// single-threaded text parser that takes minutes at 1e8 entries.  Here the file is mapped, cut
+// into one piece per thread at line boundaries, the lines of every piece are counted, and then
+// every thread parses its piece straight into its slice of the caller's COO arrays.  Format
+// (NIST Matrix Market): a `%%MatrixMarket matrix coordinate <field> <symmetry>` banner, `%`
+// comment lines, one `rows cols entries` line, then `row col [value]` lines, 1-based.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdlib>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+struct MtxMap {
+    const char* p = nullptr;
+    size_t n = 0;
+    int fd = -1;
+    ~MtxMap() {
+        if (p) munmap(const_cast<char*>(p), n);
+        if (fd >= 0) close(fd);
+    }
+    bool open_file(const char* path) {
+        fd = open(path, O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0) return false;
+        n = (size_t)st.st_size;
+        if (n == 0) return true;
+        void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) return false;
+        p = static_cast<const char*>(m);
+        madvise(m, n, MADV_SEQUENTIAL);
+        return true;
+    }
+};
+
+struct MtxHead {
+    int64_t rows = 0, cols = 0, nnz = 0;
+    int field = 0;      // 0 integer, 1 real, 2 pattern
+    size_t body = 0;    // offset of the first entry line
+};
+
+// banner, comments and the size line; false on anything this reader does not handle
+bool mtx_head(const MtxMap& f, MtxHead& h, std::string& why) {
+    size_t at = 0;
+    auto line_end = [&](size_t from) {
+        const void* e = memchr(f.p + from, '\n', f.n - from);
+        return e ? (size_t)(static_cast<const char*>(e) - f.p) : f.n;
+    };
+    if (f.n < 15 || std::memcmp(f.p, "%%MatrixMarket", 14) != 0) {
+        why = "no %%MatrixMarket banner";
+        return false;
+    }
+    size_t e = line_end(0);
+    std::string banner(f.p, e);
+    for (auto& c : banner) c = (char)tolower((unsigned char)c);
+    if (banner.find("coordinate") == std::string::npos) {
+        why = "not a coordinate (sparse) matrix";
+        return false;
+    }
+    if (banner.find("general") == std::string::npos) {
+        why = "symmetric / skew / hermitian storage is not supported";
+        return false;
+    }
+    if (banner.find("integer") != std::string::npos)
+        h.field = 0;
+    else if (banner.find("real") != std::string::npos)
+        h.field = 1;
+    else if (banner.find("pattern") != std::string::npos)
+        h.field = 2;
+    else {
+        why = "unsupported field (complex)";
+        return false;
+    }
+    at = e + 1;
+    while (at < f.n && (f.p[at] == '%' || f.p[at] == '\n' || f.p[at] == '\r')) at = line_end(at) + 1;
+    if (at >= f.n) {
+        why = "no size line";
+        return false;
+    }
+    e = line_end(at);
+    std::string size_line(f.p + at, e - at);
+    long long r = 0, c = 0, z = 0;
+    if (sscanf(size_line.c_str(), "%lld %lld %lld", &r, &c, &z) != 3 || r < 0 || c < 0 || z < 0) {
+        why = "bad size line";
+        return false;
+    }
+    h.rows = r;
+    h.cols = c;
+    h.nnz = z;
+    h.body = e + 1 <= f.n ? e + 1 : f.n;
+    return true;
+}
+
+inline const char* skip_ws(const char* p, const char* e) {
+    while (p < e && (*p == ' ' || *p == '\t' || *p == '\r')) ++p;
+    return p;
+}
+
+inline const char* parse_i64(const char* p, const char* e, int64_t& out, bool& ok) {
+    p = skip_ws(p, e);
+    bool neg = false;
+    if (p < e && (*p == '-' || *p == '+')) neg = *p++ == '-';
+    if (p >= e || *p < '0' || *p > '9') {
+        ok = false;
+        return p;
+    }
+    int64_t v = 0;
+    while (p < e && *p >= '0' && *p <= '9') v = v * 10 + (*p++ - '0');
+    out = neg ? -v : v;
+    return p;
+}
+}  // namespace
+
+extern "C" int vrx_mtx_header(const char* path, int64_t* n_rows, int64_t* n_cols, int64_t* nnz) {
+    if (!path || !n_rows || !n_cols || !nnz) {
+        vrx_set_error("vrx_mtx_header: null argument");
+        return VRX_ERR_ARG;
+    }
+    MtxMap f;
+    MtxHead h;
+    std::string why;
+    if (!f.open_file(path)) {
+        vrx_set_error("vrx_mtx_header: cannot read %s", path);
+        return VRX_ERR_ARG;
+    }
+    if (!mtx_head(f, h, why)) {
+        vrx_set_error("vrx_mtx_header: %s: %s", path, why.c_str());
+        return VRX_ERR_UNSUPPORTED;
+    }
+    *n_rows = h.rows;
+    *n_cols = h.cols;
+    *nnz = h.nnz;
+    return VRX_OK;
+}
+
+extern "C" int vrx_mtx_read(const char* path, int64_t nnz, int32_t* row, int32_t* col, int32_t* val,
+                            int n_threads) {
+    if (!path || nnz < 0 || (nnz > 0 && (!row || !col || !val))) {
+        vrx_set_error("vrx_mtx_read: bad argument");
+        return VRX_ERR_ARG;
+    }
+    MtxMap f;
+    MtxHead h;
+    std::string why;
+    if (!f.open_file(path)) {
+        vrx_set_error("vrx_mtx_read: cannot read %s", path);
+        return VRX_ERR_ARG;
+    }
+    if (!mtx_head(f, h, why)) {
+        vrx_set_error("vrx_mtx_read: %s: %s", path, why.c_str());
+        return VRX_ERR_UNSUPPORTED;
+    }
+    if (h.nnz != nnz) {
+        vrx_set_error("vrx_mtx_read: %s holds %lld entries, caller expects %lld", path,
+                      (long long)h.nnz, (long long)nnz);
+        return VRX_ERR_ARG;
+    }
+    if (h.rows >= INT32_MAX || h.cols >= INT32_MAX) {
+        vrx_set_error("vrx_mtx_read: dimension >= 2^31");
+        return VRX_ERR_UNSUPPORTED;
+    }
+    const char* const body = f.p + h.body;
+    const char* const end = f.p + f.n;
+    int T = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(T, 64), (end - body) / (1 << 16) + 1));
+    // piece boundaries at line starts
+    std::vector<const char*> cut((size_t)T + 1, end);
+    cut[0] = body;
+    for (int t = 1; t < T; ++t) {
+        const char* c = body + (size_t)(end - body) * t / T;
+        const void* nl = c < end ? memchr(c, '\n', (size_t)(end - c)) : nullptr;
+        cut[(size_t)t] = nl ? static_cast<const char*>(nl) + 1 : end;
+        if (cut[(size_t)t] < cut[(size_t)t - 1]) cut[(size_t)t] = cut[(size_t)t - 1];
+    }
+    auto is_entry_line = [](const char* p, const char* e) {
+        p = skip_ws(p, e);
+        return p < e && *p != '%';
+    };
+    // pass 1: entry lines per piece
+    std::vector<int64_t> count((size_t)T, 0);
+    {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < T; ++t)
+            pool.emplace_back([&, t] {
+                const char* p = cut[(size_t)t];
+                const char* e = cut[(size_t)t + 1];
+                int64_t c = 0;
+                while (p < e) {
+                    const void* nl = memchr(p, '\n', (size_t)(e - p));
+                    const char* le = nl ? static_cast<const char*>(nl) : e;
+                    if (is_entry_line(p, le)) ++c;
+                    p = le + 1;
+                }
+                count[(size_t)t] = c;
+            });
+        for (auto& th : pool) th.join();
+    }
+    std::vector<int64_t> first((size_t)T + 1, 0);
+    for (int t = 0; t < T; ++t) first[(size_t)t + 1] = first[(size_t)t] + count[(size_t)t];
+    if (first[(size_t)T] != nnz) {
+        vrx_set_error("vrx_mtx_read: %s declares %lld entries but holds %lld entry lines", path,
+                      (long long)nnz, (long long)first[(size_t)T]);
+        return VRX_ERR_ARG;
+    }
+    // pass 2: parse
+    std::vector<int64_t> bad((size_t)T, -1);
+    {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < T; ++t)
+            pool.emplace_back([&, t] {
+                const char* p = cut[(size_t)t];
+                const char* e = cut[(size_t)t + 1];
+                int64_t at = first[(size_t)t];
+                while (p < e) {
+                    const void* nl = memchr(p, '\n', (size_t)(e - p));
+                    const char* le = nl ? static_cast<const char*>(nl) : e;
+                    if (is_entry_line(p, le)) {
+                        bool ok = true;
+                        int64_t r = 0, c = 0, v = 1;
+                        const char* q = parse_i64(p, le, r, ok);
+                        q = parse_i64(q, le, c, ok);
+                        if (ok && h.field == 0) {
+                            q = parse_i64(q, le, v, ok);
+                        } else if (ok && h.field == 1) {  // real: integral counts written as floats
+                            q = skip_ws(q, le);
+                            char buf[64];
+                            const size_t len = std::min<size_t>(sizeof buf - 1, (size_t)(le - q));
+                            std::memcpy(buf, q, len);
+                            buf[len] = 0;
+                            char* stop = nullptr;
+                            const double d = strtod(buf, &stop);
+                            v = (int64_t)d;
+                            ok = stop != buf && (double)v == d;
+                        }
+                        if (!ok || r < 1 || r > h.rows || c < 1 || c > h.cols || v < INT32_MIN ||
+                            v > INT32_MAX) {
+                            bad[(size_t)t] = at;
+                            return;
+                        }
+                        row[at] = (int32_t)(r - 1);
+                        col[at] = (int32_t)(c - 1);
+                        val[at] = (int32_t)v;
+                        ++at;
+                    }
+                    p = le + 1;
+                }
+            });
+        for (auto& th : pool) th.join();
+    }
+    for (int t = 0; t < T; ++t)
+        if (bad[(size_t)t] >= 0) {
+            vrx_set_error("vrx_mtx_read: %s: malformed, out-of-range or non-integral entry (entry %lld)",
+                          path, (long long)bad[(size_t)t]);
+            return VRX_ERR_ARG;
+        }
+    return VRX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// (AD, DP) -> one CSC pattern with an (ad, dp) pair per entry
+// ------------------------------------------------------------------------------------
+// The union of the two patterns, column by column (both inputs in canonical CSC form: row indices
+// strictly increasing inside a column), entries where both counts are zero dropped.  Replaces a
+// SciPy sparse addition on packed values (1.0 s at 1e8 entries) by a two-pointer merge per
+// column over all cores.  Index arrays int32 or int64, count arrays int32 / int64 / float64
+// (the reference's loaders produce int64 from MatrixMarket and float64 from VCF input:
+// io_utils.py:57, vcf_utils.py:204).
+namespace {
+struct CscView {
+    const void *ptr, *idx, *dat;
+    int ptr64, idx64, dkind;  // dkind: 0 int32, 1 int64, 2 float64
+    int64_t p(int64_t c) const {
+        return ptr64 ? static_cast<const int64_t*>(ptr)[c] : static_cast<const int32_t*>(ptr)[c];
+    }
+    int64_t i(int64_t e) const {
+        return idx64 ? static_cast<const int64_t*>(idx)[e] : static_cast<const int32_t*>(idx)[e];
+    }
+    // the count of entry e; ok = false if it is negative, not integral or >= 2^31
+    int32_t v(int64_t e, bool& ok) const {
+        if (dkind == 0) {
+            const int32_t x = static_cast<const int32_t*>(dat)[e];
+            ok &= x >= 0;
+            return x;
+        }
+        if (dkind == 1) {
+            const int64_t x = static_cast<const int64_t*>(dat)[e];
+            ok &= x >= 0 && x <= INT32_MAX;
+            return (int32_t)x;
+        }
+        const double x = static_cast<const double*>(dat)[e];
+        ok &= x >= 0.0 && x <= (double)INT32_MAX && x == (double)(int64_t)x;
+        return (int32_t)x;
+    }
+};
+
+template <class F>
+void over_columns(int64_t n_col, int n_threads, F&& f) {
+    int T = n_threads > 0 ? n_threads : (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+    T = (int)std::max<int64_t>(1, std::min<int64_t>(T, n_col));
+    std::vector<std::thread> pool;
+    for (int t = 0; t < T; ++t)
+        pool.emplace_back([&, t] { f(n_col * t / T, n_col * (t + 1) / T, t); });
+    for (auto& th : pool) th.join();
+}
+}  // namespace
+
+// pass 1 (rowidx == NULL): colptr[c + 1] = entries of column c of the union (caller zeroes
+// colptr[0] and turns the counts into offsets); pass 2: fills rowidx / ad / dp at colptr.
+// Returns VRX_ERR_ARG for unsorted / duplicate row indices or counts that are not
+// non-negative integers below 2^31 (thread-local message names the column).
+extern "C" int vrx_merge_counts(int64_t n_var, int64_t n_cell, const void* ad_ptr, const void* ad_idx,
+                                const void* ad_dat, int ad_ptr64, int ad_idx64, int ad_kind,
+                                const void* dp_ptr, const void* dp_idx, const void* dp_dat,
+                                int dp_ptr64, int dp_idx64, int dp_kind, int64_t* colptr,
+                                int32_t* rowidx, int32_t* ad, int32_t* dp, int n_threads) {
+    if (n_var < 0 || n_cell < 0 || !ad_ptr || !dp_ptr || !colptr || ad_kind < 0 || ad_kind > 2 ||
+        dp_kind < 0 || dp_kind > 2) {
+        vrx_set_error("vrx_merge_counts: bad argument");
+        return VRX_ERR_ARG;
+    }
+    const CscView A{ad_ptr, ad_idx, ad_dat, ad_ptr64, ad_idx64, ad_kind};
+    const CscView D{dp_ptr, dp_idx, dp_dat, dp_ptr64, dp_idx64, dp_kind};
+    const bool fill = rowidx != nullptr;
+    std::vector<int64_t> bad(256, -1);
+    over_columns(n_cell, n_threads, [&](int64_t c0, int64_t c1, int tid) {
+        for (int64_t c = c0; c < c1; ++c) {
+            int64_t a = A.p(c), ae = A.p(c + 1), d = D.p(c), de = D.p(c + 1);
+            int64_t out = fill ? colptr[c] : 0, n = 0;
+            int64_t prev = -1;
+            bool ok = ae >= a && de >= d;
+            while (ok && (a < ae || d < de)) {
+                const int64_t ra = a < ae ? A.i(a) : INT64_MAX, rd = d < de ? D.i(d) : INT64_MAX;
+                const int64_t r = ra < rd ? ra : rd;
+                ok &= r > prev && r < n_var;
+                prev = r;
+                int32_t va = 0, vd = 0;
+                if (ra == r) va = A.v(a++, ok);
+                if (rd == r) vd = D.v(d++, ok);
+                if (va != 0 || vd != 0) {
+                    if (fill) {
+                        rowidx[out] = (int32_t)r;
+                        ad[out] = va;
+                        dp[out] = vd;
+                        ++out;
+                    }
+                    ++n;
+                }
+            }
+            if (!ok) {
+                if (tid < 256) bad[(size_t)tid] = c;
+                return;
+            }
+            if (!fill) colptr[c + 1] = n;
+        }
+    });
+    for (int64_t c : bad)
+        if (c >= 0) {
+            vrx_set_error("vrx_merge_counts: column %lld: row indices not strictly increasing / out of "
+                          "range, or a count that is not a non-negative integer below 2^31",
+                          (long long)c);
+            return VRX_ERR_ARG;
+        }
     return VRX_OK;
 }

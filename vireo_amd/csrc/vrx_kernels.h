@@ -27,6 +27,23 @@ constexpr int VRX_WAVES = VRX_BLOCK / 64;
 constexpr int VRX_MAXT = 8;  // max genotype classes handled by the dense kernels
 
 // ------------------------------------------------------------------------------------
+// Device-side loop control.  The host enqueues several iterations at a time; the stop rule of
+// _fit_VB (vireo_model.py:266-274) is evaluated on the device by the kernel that forms the
+// ELBO, and once it fires every later kernel of the batch returns at once.
+//   ctl[0] stop flag   ctl[1] iteration the loop stopped at   ctl[2] warn flags (1: lower
+//   bound decreased, 2: not converged)
+// (Measured and not adopted: running the one-block final reductions inside the last block of
+//  their producer kernel.  The agent-scope release fence every producer block then needs costs
+//  more than the two small launches it saves: dense kernels 0.136 -> 0.223 ms per iteration at
+//  c3, 41 -> 49 us per iteration at c2.)
+// ------------------------------------------------------------------------------------
+enum { VRX_CTL_STOP = 0, VRX_CTL_IT = 1, VRX_CTL_WARN = 2, VRX_CTL_WORDS = 4 };
+struct VrxStopRule {  // by value to the ELBO kernel
+    int it, min_iter, max_iter, active;
+    double eps;
+};
+
+// ------------------------------------------------------------------------------------
 // wave / block reductions (fixed butterfly order => deterministic)
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
@@ -213,8 +230,10 @@ template <int LPE, int CPL, int MODE, int FMT>
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_spmm(
     int64_t n_seg, const int64_t* __restrict__ seg_begin, const int32_t* __restrict__ seg_len,
     const int32_t* __restrict__ seg_dst, const uint32_t* __restrict__ ent,
-    const double* __restrict__ X, int K, double* __restrict__ out, double* __restrict__ partial) {
+    const double* __restrict__ X, int K, double* __restrict__ out, double* __restrict__ partial,
+    const int32_t* __restrict__ ctl) {
     static_assert(LPE * CPL <= 16 && (MODE == 0 || CPL == 1), "layout");
+    if (ctl[VRX_CTL_STOP]) return;
     const int lane = threadIdx.x & 63;
     const int64_t seg = (int64_t)blockIdx.x * VRX_WAVES + (threadIdx.x >> 6);
     if (seg >= n_seg) return;
@@ -287,13 +306,12 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_spmm(
 //   * the 4 columns of a lane are visited in a group-dependent rotation so that the
 //     16 lanes serviced together by ds_read_b128 hit 16 different 16-B bank slots.
 // Output: one partial array per contracted range (summed in fixed order afterwards).
+typedef double vrx_d2 __attribute__((ext_vector_type(2)));
+typedef uint32_t vrx_u2 __attribute__((ext_vector_type(2)));
 constexpr int VRX_RING = 512;   // entries per wave
 constexpr int VRX_CHUNK = 256;  // entries per refill (64 lanes x 16 B of one LDS-DMA load)
 #ifndef VRX_LDS_U_DEF
 #define VRX_LDS_U_DEF 4
-#endif
-#ifndef VRX_F1_SCHED
-#define VRX_F1_SCHED 0
 #endif
 #ifndef VRX_LDS_L2PF
 #define VRX_LDS_L2PF 0
@@ -329,8 +347,11 @@ constexpr int VRX_LDS_U = VRX_LDS_U_DEF;    // entries per trip and group; rows 
 // data most entries have ad = 0 or ad = dp, so the split stream is only ~1.14x longer while
 // every entry reads 128 B of LDS instead of 256 B and costs 4 FMAs per lane instead of 8.
 // The dense operand is PLANAR: row n = [Wa[n][0..16) | Wb[n][0..16)] (256 B), an entry names
-// one half.  Word = value:15 (signed) | half-row byte offset:17 (a multiple of 128), so the
-// LDS address of a slice is one v_and_or_b32.  The two lane groups of a ds_read_b128 service
+// one half.  Word = top 14 bits of the value's IEEE double (sign, exponent, two mantissa bits:
+// every integer below 8 and m * 2^e with m < 8; other values are sums of such entries) | LDS
+// byte address of the half row:18 (slab base included, a multiple of 128): the value needs no
+// conversion (high dword = word & 0xfffc0000, low dword 0) and the LDS address of a slice is
+// one v_and_or_b32.  The two lane groups of a ds_read_b128 service
 // group that share a slice rotation read different halves whenever one walks AD entries and the
 // other BD entries, which the stream builder arranges (AD-first / BD-first segments).
 template <int LPE, int MODE, int RW, bool PADK, int SPLIT, int FORM = 0>
@@ -342,7 +363,8 @@ __global__ __launch_bounds__(1024)
     const uint32_t* __restrict__ ent, const int64_t* __restrict__ wave_start,
     const int32_t* __restrict__ bnd, const int32_t* __restrict__ rowmap, int n_slab,
     int slab_rows, int64_t n_contract, int64_t n_rows, const double* __restrict__ X, int K,
-    int ld, double* __restrict__ out) {
+    int ld, double* __restrict__ out, const int32_t* __restrict__ ctl) {
+    if (ctl[VRX_CTL_STOP]) return;
     // K <= 16 columns of this launch; ld = columns per row of X and out (ld > K: one block of a
     // wider operand, always with PADK = true: the flat slab copy needs contiguous rows)
     constexpr int G = 64 / LPE;            // rows per round
@@ -374,8 +396,8 @@ __global__ __launch_bounds__(1024)
         default: break;
     }
 #endif
-    // LDS rows are padded to a multiple of 4 columns (zeros); FORM 1: two halves of 16 columns
-    const int KP = FORM == 1 ? 16 : (K + 3) & ~3;
+    // LDS rows are padded to a multiple of CP columns (zeros); FORM 1: two halves of 16 columns
+    const int KP = FORM == 1 ? 16 : (K + CP - 1) / CP * CP;  // (whole lanes: CP columns each)
     const int slab_doubles = slab_rows * KP * XD;
     // LDS = [16 entry rings][slab]: the rings first, so that the LDS-DMA destinations stay
     // below 64 KiB
@@ -542,26 +564,6 @@ __global__ __launch_bounds__(1024)
     };
     // one entry of this group's segment: word -> 4 column slices -> FMAs
     auto entry = [&](uint32_t w, double (&a)[NQ][2], double (&a2)[NQ][2]) {
-        if (FORM == 1) {  // one value, two adjacent columns per 16-B slice of a 128-B half row
-            const double v = (double)((int32_t)w >> 17);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-#ifdef VRX_X_NOREAD
-                const uint32_t ax = f1_addr(w, qoff[q]);
-                const double2 x = make_double2(__uint_as_float(ax), 1.0);
-#else
-                const double2 x = *reinterpret_cast<const double2*>(
-                    reinterpret_cast<const char*>(slab) + f1_addr(w, qoff[q]));
-#endif
-#ifdef VRX_X_NOFMA
-                asm volatile("" ::"v"(x.x), "v"(x.y), "v"(v));
-#else
-                a[q][0] = fma(v, x.x, a[q][0]);
-                a[q][1] = fma(v, x.y, a[q][1]);
-#endif
-            }
-            return;
-        }
         const double ad = (double)((w >> 11) & 2047u), dp = (double)(w & 2047u);
         const uint32_t idx = w >> 22;  // < 1024 and row_bytes <= 256: 24-bit multiply-add
 #pragma unroll
@@ -604,75 +606,90 @@ __global__ __launch_bounds__(1024)
             const int base = braw & ~(U * G - 1), tail = braw & (U - 1);
             const int end = __builtin_amdgcn_readlane(bcur, r + 1) & ~(U * G - 1);
             const int full_end = tail ? end - U * G : end;
-#if VRX_F1_SCHED == 2
-            if (FORM == 1 && U == 4) {
-                // Software pipeline over half trips: the slices of two entries are requested
-                // while the FMAs of the previous two run, so that the LDS and the VALU phases of
-                // consecutive half trips overlap INSIDE a wave (all 16 waves leave the barrier
-                // together and the LDS arbiter serves them round-robin: without this every wave
-                // waits for the same LDS phase and then every wave computes).  The zero words
-                // that pad a round's last trip are executed (value 0, row 0: harmless).
-                if (base < end) {
-                    auto rd = [&](uint32_t w, int q) {
-                        return *reinterpret_cast<const double2*>(
-                            reinterpret_cast<const char*>(slab) + f1_addr(w, qoff[q]));
-                    };
-                    auto fma2 = [&](uint32_t w0, uint32_t w1, const double2 (&x)[2][NQ]) {
-                        const double v0 = (double)((int32_t)w0 >> 17), v1 = (double)((int32_t)w1 >> 17);
+            if (FORM == 1) {
+                // A trip of NE <= U entries: every slice is requested (ds_read_b128, integer
+                // addresses: word offset bits | lane offset, the slab base is part of the word)
+                // before the first FMA; the FMAs of the first half wait for their four reads
+                // only.  The value is the high dword of an IEEE double (low dword 0), so there
+                // is no conversion: 3 VALU instructions of overhead per entry.
+                auto trip = [&](int at, auto ne_tag) {
+                    constexpr int NE = decltype(ne_tag)::value;
+#ifndef VRX_X_NODMA
+                    ring_need(at);
+#endif
+                    const uint32_t* rp = ring_g + (at & (VRX_RING - 1));
+                    uint32_t w[NE];
+#ifdef VRX_X_NORING
 #pragma unroll
-                        for (int q = 0; q < NQ; ++q) {
-                            acc[r][q][0] = fma(v0, x[0][q].x, acc[r][q][0]);
-                            acc[r][q][1] = fma(v0, x[0][q].y, acc[r][q][1]);
+                    for (int u = 0; u < NE; ++u) w[u] = 0x3ff00000u | 32768u | (uint32_t)((at + u * 64 + g * 8) & 0xff80);
+                    (void)rp;
+#else
+#pragma unroll
+                    for (int u = 0; u < NE; ++u) w[u] = rp[u * G];
+#endif
+#ifdef VRX_X_EMPTY
+#pragma unroll
+                    for (int u = 0; u < NE; ++u) asm volatile("" ::"v"(w[u]));
+                    return;
+#endif
+                    vrx_d2 x[NE][2];
+                    // (all words have landed before the first slice is requested: the compiler's
+                    //  own waits do not count the reads issued from inline assembly)
+                    if (NE == 4) asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[NE - 1]));
+                    if (NE == 3) asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[NE - 1]));
+                    if (NE == 2) asm volatile("" : "+v"(w[0]), "+v"(w[NE - 1]));
+#pragma unroll
+                    for (int u = 0; u < NE; ++u)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            uint32_t a;
+                            asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(a) : "v"(w[u]), "s"(0x3ff80u), "v"(qoff[q]));
+#ifdef VRX_X_NOREAD
+                            x[u][q] = vrx_d2{(double)__uint_as_float(a), 1.0};
+#else
+                            asm volatile("ds_read_b128 %0, %1" : "=v"(x[u][q]) : "v"(a) : "memory");
+#endif
                         }
-#pragma unroll
-                        for (int q = 0; q < NQ; ++q) {
-                            acc[r][q][0] = fma(v1, x[1][q].x, acc[r][q][0]);
-                            acc[r][q][1] = fma(v1, x[1][q].y, acc[r][q][1]);
-                        }
-                    };
-                    uint32_t w[4], wb0 = 0u, wb1 = 0u;
-                    double2 xa[2][NQ], xb[2][NQ];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int q = 0; q < NQ; ++q) xb[u][q] = make_double2(0.0, 0.0);
-                    ring_need(base);
-                    {
-                        const uint32_t* rp = ring_g + (base & (VRX_RING - 1));
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) w[u] = rp[u * G];
+                    constexpr int H = NE > 2 ? 2 : NE;  // entries of the first half
+                    if (NE > 2) {
+                        if (NE == 4)
+                            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[1][0]), "+v"(x[1][1]));
+                        else
+                            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[1][0]), "+v"(x[1][1]));
                     }
-                    for (int at = base; at < end; at += U * G) {
 #pragma unroll
-                        for (int u = 0; u < 2; ++u)
-#pragma unroll
-                            for (int q = 0; q < NQ; ++q) xa[u][q] = rd(w[u], q);
-                        __builtin_amdgcn_sched_barrier(0);
-                        fma2(wb0, wb1, xb);  // previous trip's second half (zeros the first time)
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int u = 0; u < 2; ++u)
-#pragma unroll
-                            for (int q = 0; q < NQ; ++q) xb[u][q] = rd(w[2 + u], q);
-                        wb0 = w[2];
-                        wb1 = w[3];
-                        const uint32_t wa0 = w[0], wa1 = w[1];
-                        // the next trip's words (past the round: the next round's, unused)
-                        ring_need(at + U * G);
-                        {
-                            const uint32_t* rp = ring_g + ((at + U * G) & (VRX_RING - 1));
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) w[u] = rp[u * G];
+                    for (int u = 0; u < NE; ++u) {
+                        if (u == H || NE <= 2) {
+                            // (the accumulators tie this wait behind the first half's FMAs)
+                            if (u == H && NE == 4)
+                                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[2][0]), "+v"(x[2][1]), "+v"(x[3][0]), "+v"(x[3][1]),
+                                             "+v"(acc[r][0][0]), "+v"(acc[r][0][1]), "+v"(acc[r][1][0]), "+v"(acc[r][1][1]));
+                            else if (u == H && NE == 3)
+                                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[2][0]), "+v"(x[2][1]),
+                                             "+v"(acc[r][0][0]), "+v"(acc[r][0][1]), "+v"(acc[r][1][0]), "+v"(acc[r][1][1]));
+                            else if (u == 0 && NE == 2)
+                                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[1][0]), "+v"(x[1][1]));
+                            else if (u == 0 && NE == 1)
+                                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0][0]), "+v"(x[0][1]));
                         }
-                        __builtin_amdgcn_sched_barrier(0);
-                        fma2(wa0, wa1, xa);
-                        __builtin_amdgcn_sched_barrier(0);
+                        const double v = __builtin_bit_cast(double, vrx_u2{0u, w[u] & 0xfffc0000u});
+#ifdef VRX_X_NOFMA
+                        asm volatile("" ::"v"(v), "v"(x[u][0]), "v"(x[u][1]));
+#else
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            acc[r][q][0] = fma(v, x[u][q][0], acc[r][q][0]);
+                            acc[r][q][1] = fma(v, x[u][q][1], acc[r][q][1]);
+                        }
+#endif
                     }
-                    fma2(wb0, wb1, xb);
-                }
+                };
+                for (int at = base; at < full_end; at += U * G) trip(at, std::integral_constant<int, 4>());
+                if (tail == 1) trip(full_end, std::integral_constant<int, 1>());
+                if (tail == 2) trip(full_end, std::integral_constant<int, 2>());
+                if (tail == 3) trip(full_end, std::integral_constant<int, 3>());
                 continue;
             }
-#endif
             for (int at = base; at < full_end; at += U * G) {
                 ring_need(at);
                 // trips start at multiples of U*G = 64 words and the ring is a multiple of
@@ -681,28 +698,6 @@ __global__ __launch_bounds__(1024)
                 uint32_t w[US];
 #pragma unroll
                 for (int u = 0; u < US; ++u) w[u] = rp[u * SPLIT * G];
-#if VRX_F1_SCHED == 1
-                if (FORM == 1) {  // every slice of the trip is requested before the first FMA
-                    double2 x[US][NQ];
-#pragma unroll
-                    for (int u = 0; u < US; ++u)
-#pragma unroll
-                        for (int q = 0; q < NQ; ++q)
-                            x[u][q] = *reinterpret_cast<const double2*>(
-                                reinterpret_cast<const char*>(slab) + f1_addr(w[u], qoff[q]));
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int u = 0; u < US; ++u) {
-                        const double v = (double)((int32_t)w[u] >> 17);
-#pragma unroll
-                        for (int q = 0; q < NQ; ++q) {
-                            acc[r][q][0] = fma(v, x[u][q].x, acc[r][q][0]);
-                            acc[r][q][1] = fma(v, x[u][q].y, acc[r][q][1]);
-                        }
-                    }
-                    continue;
-                }
-#endif
 #pragma unroll
                 for (int u = 0; u < US; ++u) entry(w[u], acc[r], acc2[r]);
             }
@@ -770,7 +765,8 @@ __global__ __launch_bounds__(1024)
 // out[row][c] = sum over ranges (outer) and the row's pieces (inner), fixed order
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_pieces(
     int64_t n_rows, int width, int n_range, int64_t n_vrows, const int32_t* __restrict__ vptr,
-    const double* __restrict__ partial, double* __restrict__ out) {
+    const double* __restrict__ partial, double* __restrict__ out, const int32_t* __restrict__ ctl) {
+    if (ctl[VRX_CTL_STOP]) return;
     const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
     if (i >= n_rows * width) return;
     const int64_t row = i / width;
@@ -798,7 +794,8 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_pieces(
 // butterfly of wave_sum
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_pieces_wave(
     int64_t n_rows, int width, int n_range, int64_t n_vrows, const int32_t* __restrict__ vptr,
-    const double* __restrict__ partial, double* __restrict__ out) {
+    const double* __restrict__ partial, double* __restrict__ out, const int32_t* __restrict__ ctl) {
+    if (ctl[VRX_CTL_STOP]) return;
     const int64_t i = ((int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (i >= n_rows * width) return;
@@ -817,7 +814,9 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_pieces_wave(
 // partial[range][...] summed over the contracted ranges in order
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_ranges(int64_t n, int n_range,
                                                             const double* __restrict__ partial,
-                                                            double* __restrict__ out) {
+                                                            double* __restrict__ out,
+                                                            const int32_t* __restrict__ ctl) {
+    if (ctl[VRX_CTL_STOP]) return;
     const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
     if (i >= n) return;
     double s = 0.0;
@@ -838,7 +837,9 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_slots(int64_t n_multi, int 
                                                            const int32_t* __restrict__ multi_row,
                                                            const int32_t* __restrict__ multi_ptr,
                                                            const double* __restrict__ partial,
-                                                           double* __restrict__ out) {
+                                                           double* __restrict__ out,
+                                                           const int32_t* __restrict__ ctl) {
+    if (ctl[VRX_CTL_STOP]) return;
     const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
     const int64_t per = (int64_t)K * VPE;
     if (i >= n_multi * per) return;
@@ -851,43 +852,6 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_slots(int64_t n_multi, int 
 // ------------------------------------------------------------------------------------
 // theta  (Vireo.update_theta_size, vireoSNP/utils/vireo_model.py:165-185)
 // ------------------------------------------------------------------------------------
-// stage 1 (shared theta): per-block partial sums of S1*GT_t and S2*GT_t over all (n,k).
-// n_range > 0: S has not been formed yet -- it is the in-order sum of the n_range partial
-// arrays the LDS-resident variant pass left in `ranges` (fused here to save a launch).
-__global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_partial(int64_t NK, int T, double2* S,
-                                                               int n_range,
-                                                               const double2* __restrict__ ranges,
-                                                               const double* __restrict__ GT,
-                                                               double* __restrict__ part) {
-    double acc[2 * VRX_MAXT];
-#pragma unroll
-    for (int t = 0; t < 2 * VRX_MAXT; ++t) acc[t] = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x; i < NK;
-         i += (int64_t)gridDim.x * VRX_BLOCK) {
-        double2 s;
-        if (n_range > 0) {
-            s = make_double2(0.0, 0.0);
-            for (int r = 0; r < n_range; ++r) {
-                const double2 v = ranges[(int64_t)r * NK + i];
-                s.x += v.x;
-                s.y += v.y;
-            }
-            S[i] = s;
-        } else {
-            s = S[i];
-        }
-        const double s1 = s.x, s2 = s.y - s.x;
-#pragma unroll
-        for (int t = 0; t < VRX_MAXT; ++t)
-            if (t < T) {
-                const double g = GT[i * T + t];
-                acc[t] += s1 * g;
-                acc[VRX_MAXT + t] += s2 * g;
-            }
-    }
-    block_sum_store<2 * VRX_MAXT>(acc, part + (int64_t)blockIdx.x * 2 * VRX_MAXT);
-}
-
 // Beta update + digammas + KL for ONE theta row.  psi is laid out [3][rows][T].
 // update == 0: only derive psi / KL from the current beta_mu, beta_sum.
 __device__ __forceinline__ double vrx_theta_row(int T, int update, int fix_sum, const double* add1,
@@ -916,13 +880,10 @@ __device__ __forceinline__ double vrx_theta_row(int T, int update, int fix_sum, 
 }
 
 // stage 2 (shared theta): one block sums the stage-1 partials in a fixed order.
-__global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_final(int n_part, int T, int update,
-                                                             int fix_sum,
-                                                             const double* __restrict__ part,
-                                                             const double* __restrict__ prior1,
-                                                             const double* __restrict__ prior2,
-                                                             double* mu, double* sm, double* psi,
-                                                             double* kl_out) {
+__device__ __forceinline__ void vrx_theta_final_block(int n_part, int T, int update, int fix_sum,
+                                                      const double* part, const double* prior1,
+                                                      const double* prior2, double* mu, double* sm,
+                                                      double* psi, double* kl_out) {
     __shared__ double tot[2 * VRX_MAXT];
     double acc[2 * VRX_MAXT];
 #pragma unroll
@@ -992,6 +953,53 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_final(int n_part, int T, 
     }
 }
 
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_final(int n_part, int T, int update,
+                                                             int fix_sum, const double* part,
+                                                             const double* prior1,
+                                                             const double* prior2, double* mu,
+                                                             double* sm, double* psi,
+                                                             double* kl_out,
+                                                             const int32_t* __restrict__ ctl) {
+    if (ctl[VRX_CTL_STOP]) return;
+    vrx_theta_final_block(n_part, T, update, fix_sum, part, prior1, prior2, mu, sm, psi, kl_out);
+}
+
+// stage 1 (shared theta): per-block partial sums of S1*GT_t and S2*GT_t over all (n,k).
+// n_range > 0: S has not been formed yet -- it is the in-order sum of the n_range partial
+// arrays the LDS-resident variant pass left in `ranges` (fused here to save a launch).
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_partial(
+    int64_t NK, int T, double2* S, int n_range, const double2* __restrict__ ranges,
+    const double* __restrict__ GT, double* __restrict__ part, const int32_t* __restrict__ ctl) {
+    if (ctl[VRX_CTL_STOP]) return;
+    double acc[2 * VRX_MAXT];
+#pragma unroll
+    for (int t = 0; t < 2 * VRX_MAXT; ++t) acc[t] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x; i < NK;
+         i += (int64_t)gridDim.x * VRX_BLOCK) {
+        double2 s;
+        if (n_range > 0) {
+            s = make_double2(0.0, 0.0);
+            for (int r = 0; r < n_range; ++r) {
+                const double2 v = ranges[(int64_t)r * NK + i];
+                s.x += v.x;
+                s.y += v.y;
+            }
+            S[i] = s;
+        } else {
+            s = S[i];
+        }
+        const double s1 = s.x, s2 = s.y - s.x;
+#pragma unroll
+        for (int t = 0; t < VRX_MAXT; ++t)
+            if (t < T) {
+                const double g = GT[i * T + t];
+                acc[t] += s1 * g;
+                acc[VRX_MAXT + t] += s2 * g;
+            }
+    }
+    block_sum_store<2 * VRX_MAXT>(acc, part + (int64_t)blockIdx.x * 2 * VRX_MAXT);
+}
+
 // ASE mode: one theta row per variant (vireo_model.py:82,:177 axis=1).  Thread per variant.
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_ase(int64_t N, int K, int T, int update,
                                                            int fix_sum,
@@ -1000,7 +1008,9 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_ase(int64_t N, int K, int
                                                            const double* __restrict__ prior1,
                                                            const double* __restrict__ prior2,
                                                            int prior_rows, double* mu, double* sm,
-                                                           double* psi, double* kl_part) {
+                                                           double* psi, double* kl_part,
+                                                           const int32_t* __restrict__ ctl) {
+    if (ctl[VRX_CTL_STOP]) return;
     const int64_t n = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
     double kl[1] = {0.0};
     if (n < N) {
@@ -1049,8 +1059,10 @@ __device__ __forceinline__ void vrx_store_w(double* W, int wform, int64_t n, int
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_gt_update(
     int64_t NK, int K, int T, int learn, int ase, int64_t N, const double2* __restrict__ S,
     const double* __restrict__ psi, const double* __restrict__ logq, int gt_mode, double logq_uni,
-    double* __restrict__ GT, double* __restrict__ W, int wform, double* __restrict__ kl_part) {
+    double* __restrict__ GT, double* __restrict__ W, int wform, double* __restrict__ kl_part,
+    const int32_t* __restrict__ ctl) {
 #pragma clang fp contract(off)
+    if (ctl[VRX_CTL_STOP]) return;
     const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
     double kl[1] = {0.0};
     if (i < NK) {
@@ -1183,8 +1195,10 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_bmm_theta(int64_t NK, int updat
                                                            const double* __restrict__ prior2,
                                                            int prior_full, double* mu, double* sm,
                                                            double* __restrict__ W, int K, int wform,
-                                                           double* __restrict__ kl_part) {
+                                                           double* __restrict__ kl_part,
+                                                           const int32_t* __restrict__ ctl) {
 #pragma clang fp contract(off)
+    if (ctl[VRX_CTL_STOP]) return;
     const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
     double kl[1] = {0.0};
     if (i < NK) {
@@ -1208,6 +1222,83 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_bmm_theta(int64_t NK, int updat
 }
 
 // ------------------------------------------------------------------------------------
+// ELBO  = LB_p - KL_ID - KL_GT - KL_theta  (vireo_model.py:247-248, bmm_model.py:175)
+// One block; each term is the fixed-order sum of a partial array.
+// ------------------------------------------------------------------------------------
+struct VrxElboIn {  // by value
+    const double *cell_part, *gt_part, *th_part;
+    int n_cell_part, n_gt_part, n_th_part;
+    double *elbo, *parts;  // elbo: the trace (slot rule.it is written)
+};
+
+__device__ __forceinline__ void vrx_elbo_final_block(const double* cell_part, int n_cell_part,
+                                                     const double* gt_part, int n_gt_part,
+                                                     const double* th_part, int n_th_part,
+                                                     double* elbo_out, double* parts_out,
+                                                     const VrxStopRule& rule, int32_t* ctl) {
+    __shared__ double tot[4];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    // the loads of 8 strides are issued together (one memory round trip instead of 8), the
+    // additions keep the order of the plain strided loop
+    constexpr int UN = 8;
+    for (int b0 = threadIdx.x; b0 < n_cell_part; b0 += UN * VRX_BLOCK) {
+        double2 v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int b = b0 + u * VRX_BLOCK;
+            v[u] = b < n_cell_part ? reinterpret_cast<const double2*>(cell_part)[b]
+                                   : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            acc[0] += v[u].x;
+            acc[1] += v[u].y;
+        }
+    }
+    auto strided = [&](const double* p, int n, double& a) {
+        for (int b0 = threadIdx.x; b0 < n; b0 += UN * VRX_BLOCK) {
+            double v[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int b = b0 + u * VRX_BLOCK;
+                v[u] = b < n ? p[b] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) a += v[u];
+        }
+    };
+    strided(gt_part, n_gt_part, acc[2]);
+    strided(th_part, n_th_part, acc[3]);
+    block_sum_store<4>(acc, tot);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double cur = tot[0] - tot[1] - tot[2] - tot[3];
+        elbo_out[rule.it] = cur;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) parts_out[i] = tot[i];
+        // the stop rule of _fit_VB / _fit_BV (vireo_model.py:266-274, bmm_model.py:190-199)
+        if (rule.active && rule.it > rule.min_iter) {
+            const double prev = elbo_out[rule.it - 1];
+            if (cur < prev - 1e-6) {
+                ctl[VRX_CTL_WARN] |= 1;
+            } else if (rule.it == rule.max_iter - 1) {
+                ctl[VRX_CTL_WARN] |= 2;
+            } else if (cur - prev < rule.eps) {
+                ctl[VRX_CTL_IT] = rule.it;
+                __threadfence();
+                ctl[VRX_CTL_STOP] = 1;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_elbo_final(VrxElboIn e, VrxStopRule rule, int32_t* ctl) {
+    if (ctl[VRX_CTL_STOP]) return;
+    vrx_elbo_final_block(e.cell_part, e.n_cell_part, e.gt_part, e.n_gt_part, e.th_part, e.n_th_part,
+                         e.elbo, e.parts, rule, ctl);
+}
+
+// ------------------------------------------------------------------------------------
 // cell posterior  (Vireo.update_ID_prob vireo_model.py:198-199, bmm_model.py:153-154) fused
 // with the LB_p and KL(ID || prior) partials of get_ELBO (vireo_model.py:236-237).
 // A KP-lane group per cell; K > KP loops.  update == 0: ID_prob is left alone and only the
@@ -1221,7 +1312,8 @@ template <int KP>
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_cell_softmax(
     int64_t M, int K, int update, double* LID, int n_range, const double* __restrict__ ranges,
     const double* __restrict__ logq, int id_mode, double logq_uni, double* __restrict__ ID,
-    double* __restrict__ part) {
+    double* __restrict__ part, const int32_t* __restrict__ ctl) {
+    if (ctl[VRX_CTL_STOP]) return;
     const int64_t cell = ((int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x) / KP;
     const int kl = threadIdx.x % KP;
     double acc[2] = {0.0, 0.0};
@@ -1265,59 +1357,6 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_cell_softmax(
         }
     }
     block_sum_store<2>(acc, part + (int64_t)blockIdx.x * 2);
-}
-
-// ------------------------------------------------------------------------------------
-// ELBO  = LB_p - KL_ID - KL_GT - KL_theta  (vireo_model.py:247-248, bmm_model.py:175)
-// One block; each term is the fixed-order sum of a partial array.
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(VRX_BLOCK) void vrx_elbo_final(const double* __restrict__ cell_part,
-                                                            int n_cell_part,
-                                                            const double* __restrict__ gt_part,
-                                                            int n_gt_part,
-                                                            const double* __restrict__ th_part,
-                                                            int n_th_part, double* elbo_out,
-                                                            double* parts_out) {
-    __shared__ double tot[4];
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    // the loads of 8 strides are issued together (one memory round trip instead of 8), the
-    // additions keep the order of the plain strided loop
-    constexpr int UN = 8;
-    for (int b0 = threadIdx.x; b0 < n_cell_part; b0 += UN * VRX_BLOCK) {
-        double2 v[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int b = b0 + u * VRX_BLOCK;
-            v[u] = b < n_cell_part ? reinterpret_cast<const double2*>(cell_part)[b]
-                                   : make_double2(0.0, 0.0);
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            acc[0] += v[u].x;
-            acc[1] += v[u].y;
-        }
-    }
-    auto strided = [&](const double* __restrict__ p, int n, double& a) {
-        for (int b0 = threadIdx.x; b0 < n; b0 += UN * VRX_BLOCK) {
-            double v[UN];
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int b = b0 + u * VRX_BLOCK;
-                v[u] = b < n ? p[b] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < UN; ++u) a += v[u];
-        }
-    };
-    strided(gt_part, n_gt_part, acc[2]);
-    strided(th_part, n_th_part, acc[3]);
-    block_sum_store<4>(acc, tot);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        elbo_out[0] = tot[0] - tot[1] - tot[2] - tot[3];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) parts_out[i] = tot[i];
-    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1367,24 +1406,26 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_normalize_rows(int64_t rows, in
 
 // ------------------------------------------------------------------------------------
 // binomial-coefficient constant  (get_binom_coeff, vireo_base.py:7-22)
-//   sum over dp>0 of float32( min( log C(dp, ad), 700 ) )
+//   float32( min( log C(dp, ad), 700 ) ) for every entry with dp > 0; summed on the host in
+//   NumPy's float32 pairwise order (vrx_problem_binom_const)
 // ------------------------------------------------------------------------------------
+// per-entry terms in storage order; entries with dp == 0 (never indexed by the reference's
+// DP > 0 mask) are marked with a NaN
 template <int FMT>
-__global__ __launch_bounds__(VRX_BLOCK) void vrx_binom_partial(int64_t nnz,
-                                                               const uint32_t* __restrict__ ent,
-                                                               double* __restrict__ part) {
-    double acc[1] = {0.0};
-    for (int64_t e = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x; e < nnz;
-         e += (int64_t)gridDim.x * VRX_BLOCK) {
-        uint32_t id;
-        int ad, dp;
-        vrx_unpack<FMT>(vrx_load_words<FMT>(ent, e, true), id, ad, dp);
-        if (dp > 0) {
-            const double n = (double)dp, k = (double)ad;
-            double c = lgamma(n + 1.0) - lgamma(k + 1.0) - lgamma(n - k + 1.0);
-            if (c > 700.0) c = 700.0;
-            acc[0] += (double)(float)c;
-        }
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_binom_terms(int64_t nnz,
+                                                             const uint32_t* __restrict__ ent,
+                                                             float* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    if (e >= nnz) return;
+    uint32_t id;
+    int ad, dp;
+    vrx_unpack<FMT>(vrx_load_words<FMT>(ent, e, true), id, ad, dp);
+    float t = __builtin_nanf("");
+    if (dp > 0) {
+        const double n = (double)dp, k = (double)ad;
+        double c = lgamma(n + 1.0) - lgamma(k + 1.0) - lgamma(n - k + 1.0);
+        if (c > 700.0) c = 700.0;
+        t = (float)c;
     }
-    block_sum_store<1>(acc, part + blockIdx.x);
+    out[e] = t;
 }

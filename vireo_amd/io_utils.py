@@ -9,10 +9,34 @@ import gzip
 import shutil
 from itertools import combinations
 
-import numpy as np
-from scipy.io import mmread
+import ctypes as C
 
+import numpy as np
+from scipy.sparse import coo_matrix
+
+from . import _lib
 from .vcf_utils import load_VCF, match_SNPs
+
+
+def read_mtx(path, n_threads=0):
+    """MatrixMarket coordinate file -> scipy COO matrix (int64 counts), parsed by the library's
+    multi-threaded reader (vrx_mtx_read) instead of scipy.io.mmread (io_utils.py:57): the same
+    entries in file order, duplicates kept (``.tocsc()`` sums them, like after mmread).
+    Gzipped files and symmetric / complex / array storage fall back to scipy."""
+    path = str(path)
+    L = _lib.lib()
+    n_rows, n_cols, nnz = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    if path.endswith(".gz") or L.vrx_mtx_header(path.encode(), C.byref(n_rows), C.byref(n_cols),
+                                                C.byref(nnz)) != 0:
+        from scipy.io import mmread
+        return mmread(path)
+    row = np.empty(nnz.value, dtype=np.int32)
+    col = np.empty(nnz.value, dtype=np.int32)
+    val = np.empty(nnz.value, dtype=np.int32)
+    i32 = C.POINTER(C.c_int32)
+    _lib.check(L.vrx_mtx_read(path.encode(), nnz.value, row.ctypes.data_as(i32),
+                              col.ctypes.data_as(i32), val.ctypes.data_as(i32), int(n_threads)))
+    return coo_matrix((val.astype(np.int64), (row, col)), shape=(n_rows.value, n_cols.value))
 
 
 def read_cellSNP(dir_name, layers=['AD', 'DP']):
@@ -20,7 +44,7 @@ def read_cellSNP(dir_name, layers=['AD', 'DP']):
     (io_utils.py:42-59)."""
     dat = load_VCF(dir_name + "/cellSNP.base.vcf.gz", load_sample=False, biallelic_only=False)
     for layer in layers:
-        dat[layer] = mmread(dir_name + "/cellSNP.tag.%s.mtx" % layer).tocsc()
+        dat[layer] = read_mtx(dir_name + "/cellSNP.tag.%s.mtx" % layer).tocsc()
     dat['samples'] = np.genfromtxt(dir_name + "/cellSNP.samples.tsv", dtype=str)
     return dat
 
@@ -32,8 +56,8 @@ def read_vartrix(alt_mtx, ref_mtx, cell_file, vcf_file=None):
         dat['variants'] = np.array(dat['variants'])
     else:
         dat = {}
-    dat['AD'] = mmread(alt_mtx).tocsc()
-    dat['DP'] = mmread(ref_mtx).tocsc() + dat['AD']
+    dat['AD'] = read_mtx(alt_mtx).tocsc()
+    dat['DP'] = read_mtx(ref_mtx).tocsc() + dat['AD']
     dat['samples'] = np.genfromtxt(cell_file, dtype=str)
     return dat
 

@@ -12,11 +12,30 @@ double), uploads the raw draws, normalises them on the device in NumPy's summati
 runs all its restarts through ONE device model whose best state so far stays in HBM.
 """
 import ctypes as C
+import time
 
 import numpy as np
 
 from . import _lib
 from .engine import DeviceModel
+
+
+# Optional phase timers (bench.py's c4 leg): set to a dict and the restart loop adds the
+# seconds it spends drawing / skipping random numbers, uploading + normalising, fitting, and
+# refining the winner.  None = no timing, no overhead.
+PHASES = None
+
+
+class _phase:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.t0 = time.perf_counter() if PHASES is not None else 0.0
+
+    def __exit__(self, *exc):
+        if PHASES is not None:
+            PHASES[self.name] = PHASES.get(self.name, 0.0) + time.perf_counter() - self.t0
 
 
 class LegacyStream:
@@ -38,12 +57,14 @@ class LegacyStream:
     def rand(self, *shape):
         """== np.random.rand(*shape), bit for bit"""
         out = np.empty(shape)
-        self._advance(out.reshape(-1), out.size)
+        with _phase("draw"):
+            self._advance(out.reshape(-1), out.size)
         return out
 
     def skip(self, n):
         """consume n doubles without forming them"""
-        self._advance(None, n)
+        with _phase("skip"):
+            self._advance(None, n)
 
 
 class DeviceRestarts:
@@ -69,13 +90,17 @@ class DeviceRestarts:
         rows = t.n_var if t.ASE_mode else 1
         mu = np.broadcast_to(t.beta_mu, (rows, t.n_GT))
         sm = np.broadcast_to(t.beta_sum, (rows, t.n_GT))
-        if ID_fixed is not None or GT_fixed is not None:
-            self.dm.set_state(ID_fixed, GT_fixed, None, None)
-        self.dm.set_state_raw(ID_raw, GT_raw, mu, sm)
-        trace, it, _ = self.dm.fit(max_iter, 5, 1e-2, delay_fit_theta)
+        with _phase("upload+normalise"):
+            if ID_fixed is not None or GT_fixed is not None:
+                self.dm.set_state(ID_fixed, GT_fixed, None, None)
+            self.dm.set_state_raw(ID_raw, GT_raw, mu, sm)
+        with _phase("fit"):
+            trace, it, _ = self.dm.fit(max_iter, 5, 1e-2, delay_fit_theta)
+        self.iterations = getattr(self, "iterations", 0) + it + 1
         elbo = trace[:it] + self.const
         if self.best is None or elbo[-1] > self.best[0]:     # first max wins
-            self.dm.snapshot()
+            with _phase("snapshot"):
+                self.dm.snapshot()
             self.best = (elbo[-1], im, elbo)
         return elbo[-1]
 
@@ -87,9 +112,12 @@ class DeviceRestarts:
         self.dm.restore()
         t.ELBO_ = np.append(t.ELBO_, self.best[2])
         if refine:
-            trace, it, _ = self.dm.fit(200, 5, 1e-2, 0)
+            with _phase("final_fit"):
+                trace, it, _ = self.dm.fit(200, 5, 1e-2, 0)
+            self.final_iterations = it + 1
             t.ELBO_ = np.append(t.ELBO_, trace[:it] + self.const)
-        t._pull(self.dm, want_GT=True)
+        with _phase("download"):
+            t._pull(self.dm, want_GT=True)
         return t
 
     def close(self):

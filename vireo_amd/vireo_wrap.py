@@ -17,12 +17,13 @@ import numpy as np
 
 from .counts import device_counts
 from .dist import LocalComm, gather_restart_elbos, my_restarts
-from .restarts import DeviceRestarts, LegacyStream
+from .restarts import DeviceRestarts, LegacyStream, _phase
 from .vireo_base import donor_select, normalize, optimal_match
 from .vireo_doublet import predict_doublet
 from .vireo_model import Vireo
 
 _INIT_KEYS = ("ID_prob_init", "GT_prob_init", "beta_mu_init", "beta_sum_init")
+LAST_SEARCH = {}     # what the last restart search did on this rank (read by bench.py)
 
 
 class _Plan:
@@ -105,12 +106,18 @@ def _search(counts, plan, comm, max_iter_init, delay_fit_theta, kwargs, restarts
                                    max_iter_init, delay_fit_theta)
         else:
             stream.skip((n_cell * K if ID0 is None else 0) + (n_var * K * T if GT0 is None else 0))
-    elbo_all = gather_restart_elbos(comm, plan.n_init, local)
+    with _phase("gather"):
+        elbo_all = gather_restart_elbos(comm, plan.n_init, local)
     best = int(np.argmax(elbo_all))              # first max wins, vireo_wrap.py:90-91
     owner = best % comm.world
     model = runner.winner(best, refine=plan.n_extra == 0) if comm.rank == owner else tmpl
+    LAST_SEARCH.clear()
+    LAST_SEARCH.update(restarts=len(local), restart_iterations=getattr(runner, "iterations", 0),
+                       final_iterations=getattr(runner, "final_iterations", 0), best=best,
+                       owner=owner)
     runner.close()
-    _bcast_model(comm, model, owner)
+    with _phase("broadcast"):
+        _bcast_model(comm, model, owner)
     return model, elbo_all
 
 
