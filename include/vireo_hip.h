@@ -62,6 +62,11 @@ void vrx_problem_destroy(vrx_problem* p);
  * vireo_model.py:313 and bmm_model.py:239).  Computed once per problem and cached. */
 int vrx_problem_binom_const(vrx_problem* p, double* sum_out);
 
+/* Checksums (64-bit FNV-1a) of the device-resident problem, per orientation (variant-major
+ * first): packed entries, tiled stream words, stream boundaries, wave starts, row map, number of
+ * gather segments.  Two builds of one input are identical iff the first five agree; the tests
+ * hold the device builder (vrx_build.h) to the host builder with it. */
+int vrx_problem_digest(vrx_problem* p, uint64_t* out12);
 /* per-cell count of variants with dp>0 (vireoSNP/vireo.py:191, "n_vars") */
 int vrx_problem_n_vars(vrx_problem* p, int32_t* out /* n_cell */);
 

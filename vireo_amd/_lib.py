@@ -44,6 +44,7 @@ SIGNATURES = {
     "vrx_problem_destroy": (None, [_P]),
     "vrx_problem_binom_const": (C.c_int, [_P, _D]),
     "vrx_problem_n_vars": (C.c_int, [_P, _I32]),
+    "vrx_problem_digest": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "vrx_model_create": (C.c_int, [_P, C.POINTER(ModelCfg), C.POINTER(_P)]),
     "vrx_model_destroy": (None, [_P]),
     "vrx_model_set_state": (C.c_int, [_P, _D, _D, _D, _D]),

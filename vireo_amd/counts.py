@@ -136,6 +136,12 @@ class DeviceCounts:
             self._binom = np.float32(s.value)
         return self._binom
 
+    def digest(self):
+        """checksums of the device arrays (vrx_problem_digest): equal for identical builds"""
+        out = (C.c_uint64 * 12)()
+        _lib.check(_lib.lib().vrx_problem_digest(self._h, out))
+        return [int(x) for x in out]
+
     def n_vars(self):
         """number of variants with DP > 0 per cell (vireo.py:191)."""
         out = np.zeros(self.n_cell, dtype=np.int32)

@@ -1,0 +1,325 @@
+// Device-side construction of a problem (f4): from the merged CSC arrays to both orientations and
+// their tiled entry streams, in HIP kernels.  The reference's counterpart is
+// `mmread(...).tocsc()` plus the implicit CSR<->CSC conversions inside SciPy's products
+// (vireoSNP/utils/io_utils.py:57, vireo_model.py:167-170); the host builder of vrx_engine.hip is
+// the specification: every stream built here is bit-identical to the one it builds
+// (tests/test_gpu_parity.py::test_device_builder_equals_host_builder).
+//
+//   validate        thread per entry: column of the entry (binary search in colptr), row order,
+//                   range, sign; per-cell count of covered variants; largest count
+//   transpose       stable radix sort of (variant, entry id) pairs (hipCUB): cells stay
+//                   increasing inside a variant row; row pointers by binary search
+//   pack            the 4 / 8 / 12-byte entry arrays of both orientations
+//   tiled streams   count: thread per (wave, slab, tile position): the segment of that row in
+//                          that slab (two binary searches), its entry count (AD/BD chunks in
+//                          form 1), the round's length by a 16-lane max
+//                   offsets: thread per wave: running sum of the padded round lengths
+//                   fill:  thread per (wave, slab, round, pair of lane groups): the parity /
+//                          half pairing of build_tiled, emitted straight to the words'
+//                          positions (two running counters per group, no temporary lists)
+// Row pieces, their sort by length and the snake order (O(rows) work) stay on the host.
+#pragma once
+
+#include <hipcub/hipcub.hpp>
+
+#include "vrx_common.h"
+#include "vrx_kernels.h"
+
+struct VrxTileArgs {  // one orientation's tiled-stream geometry, by value to the kernels
+    const int64_t* ptr;
+    const int32_t* idx;
+    const int2* val;
+    const int32_t *rowmap, *vptr, *vrow_row;
+    int RW, NR, G, U, n_slab, slab_rows, form, bit_shift, pairing, xor_partner;
+    uint32_t f1_base, pad_word;
+    int64_t n_wave;
+};
+
+// number of FORM 1 entries a count becomes (build_tiled's push_value: top three significant bits
+// at a time)
+__device__ __forceinline__ int vrx_chunks(int64_t v) {
+    int n = 0;
+    while (v != 0) {
+        const uint64_t mag = (uint64_t)(v < 0 ? -v : v);
+        const int len = 64 - __clzll((long long)mag), sh = len > 3 ? len - 3 : 0;
+        const int64_t c = (int64_t)((mag >> sh) << sh);
+        v -= v < 0 ? -c : c;
+        ++n;
+    }
+    return n;
+}
+
+__device__ __forceinline__ int64_t vrx_lower_bound(const int32_t* a, int64_t lo, int64_t hi, int64_t key) {
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (a[mid] < key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// ---- validation -----------------------------------------------------------------------------
+// status[0] = smallest offending column (INT_MAX if none), status[1] = its kind, status[2] = max count
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_build_validate(
+    int64_t nnz, int64_t n_var, int64_t n_cell, const int64_t* __restrict__ colptr,
+    const int32_t* __restrict__ rowidx, const int32_t* __restrict__ ad, const int32_t* __restrict__ dp,
+    int32_t* __restrict__ ecol, int32_t* __restrict__ n_vars, int32_t* status) {
+    const int64_t e = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    if (e >= nnz) return;
+    // column of entry e: the last c with colptr[c] <= e
+    int64_t lo = 0, hi = n_cell;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi + 1) >> 1;
+        if (colptr[mid] <= e)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const int32_t c = (int32_t)lo;
+    ecol[e] = c;
+    const int32_t r = rowidx[e], a = ad[e], d = dp[e];
+    int kind = 0;
+    if (r < 0 || r >= n_var || (e > colptr[c] && rowidx[e - 1] >= r)) kind = 2;
+    else if (a < 0 || d < 0) kind = 3;
+    if (kind) {
+        if (atomicMin(&status[0], c) > c) status[1] = kind;  // (a benign race picks some kind)
+    }
+    atomicMax(&status[2], a > d ? a : d);
+    if (d > 0) atomicAdd(&n_vars[c], 1);
+}
+
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_build_iota_keys(int64_t nnz, const int32_t* __restrict__ rowidx,
+                                                                 uint32_t* __restrict__ keys,
+                                                                 uint32_t* __restrict__ vals) {
+    const int64_t e = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    if (e >= nnz) return;
+    keys[e] = (uint32_t)rowidx[e];
+    vals[e] = (uint32_t)e;
+}
+
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_build_rptr(int64_t n_var, int64_t nnz,
+                                                            const uint32_t* __restrict__ keys_sorted,
+                                                            int64_t* __restrict__ rptr) {
+    const int64_t r = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    if (r > n_var) return;
+    int64_t lo = 0, hi = nnz;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)keys_sorted[mid] < r)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    rptr[r] = lo;
+}
+
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_build_gather(int64_t nnz, const uint32_t* __restrict__ perm,
+                                                              const int32_t* __restrict__ ecol,
+                                                              const int32_t* __restrict__ ad,
+                                                              const int32_t* __restrict__ dp,
+                                                              int32_t* __restrict__ ridx, int2* __restrict__ rval,
+                                                              int2* __restrict__ cval) {
+    const int64_t q = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    if (q >= nnz) return;
+    const uint32_t e = perm[q];
+    ridx[q] = ecol[e];
+    rval[q] = make_int2(ad[e], dp[e]);
+    cval[q] = make_int2(ad[q], dp[q]);
+}
+
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_build_pack(int64_t nnz, int fmt, const int32_t* __restrict__ idx,
+                                                            const int2* __restrict__ val, uint32_t* __restrict__ ent) {
+    const int64_t e = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    if (e >= nnz) return;
+    const uint32_t id = (uint32_t)idx[e], a = (uint32_t)val[e].x, d = (uint32_t)val[e].y;
+    if (fmt == VRX_FMT_P32) {
+        ent[e] = (id << 12) | (a << 6) | d;
+    } else if (fmt == VRX_FMT_P64) {
+        ent[e * 2] = id;
+        ent[e * 2 + 1] = a | (d << 16);
+    } else {
+        ent[e * 3] = id;
+        ent[e * 3 + 1] = a;
+        ent[e * 3 + 2] = d;
+    }
+}
+
+// ---- tiled streams: segment of every (wave, slab, tile position), round lengths ------------------
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_build_count(VrxTileArgs A, int32_t* __restrict__ seg_lo,
+                                                             int32_t* __restrict__ seg_hi,
+                                                             int32_t* __restrict__ rlen) {
+    const int64_t t = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    const int64_t total = A.n_wave * A.n_slab * A.RW;
+    int n = 0;
+    if (t < total) {
+        const int pos = (int)(t % A.RW);
+        const int64_t ws = t / A.RW;
+        const int sl = (int)(ws % A.n_slab);
+        const int64_t w = ws / A.n_slab;
+        const int32_t v = A.rowmap[w * A.RW + pos];
+        int32_t lo = 0, hi = 0;
+        if (v >= 0) {
+            const int32_t row = A.vrow_row[v];
+            const int64_t r0 = A.ptr[row], r1 = A.ptr[row + 1];
+            const int64_t base = (int64_t)sl * A.slab_rows;
+            const int64_t seg = vrx_lower_bound(A.idx, r0, r1, base);
+            const int64_t end = vrx_lower_bound(A.idx, seg, r1, base + A.slab_rows);
+            const int step = A.vptr[row + 1] - A.vptr[row];
+            const int off = (int)(((int64_t)(v - A.vptr[row]) + sl) % step);
+            lo = (int32_t)(seg + off);
+            hi = (int32_t)end;
+            for (int64_t e = seg + off; e < end; e += step) {
+                if (A.form == 0) {
+                    ++n;
+                } else {
+                    const int2 x = A.val[e];
+                    n += vrx_chunks(x.x) + vrx_chunks((int64_t)x.y - x.x);
+                }
+            }
+        }
+        seg_lo[t] = lo;
+        seg_hi[t] = hi;
+    }
+    // longest segment of the round: the G positions of a round are G consecutive threads
+    int L = n;
+    for (int m = 1; m < A.G; m <<= 1) L = max(L, __shfl_xor(L, m, 64));
+    if (t < total && (t % A.G) == 0) rlen[t / A.G] = L;
+}
+
+// per wave: stream offset of every (slab, round) | entries in its last trip; total length
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_build_offsets(VrxTileArgs A, const int32_t* __restrict__ rlen,
+                                                               int32_t* __restrict__ bnd,
+                                                               int64_t* __restrict__ wave_len, int32_t* too_long) {
+    const int64_t w = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    if (w >= A.n_wave) return;
+    const int64_t nsr = (int64_t)A.n_slab * A.NR;
+    int64_t rel = 0;
+    for (int64_t i = 0; i < nsr; ++i) {
+        if (rel >= INT32_MAX - 4096) {
+            *too_long = 1;
+            return;
+        }
+        const int L = rlen[w * nsr + i];
+        bnd[w * (nsr + 1) + i] = (int32_t)(rel | (L % A.U));
+        rel += (int64_t)((L + A.U - 1) / A.U * A.U) * A.G;
+    }
+    bnd[w * (nsr + 1) + nsr] = (int32_t)rel;
+    wave_len[w] = rel;
+}
+
+// the words of one segment, in the order of build_tiled: f(word) for every entry / chunk
+template <class F>
+__device__ __forceinline__ void vrx_segment_words(const VrxTileArgs& A, int64_t lo, int64_t hi, int step,
+                                                  int64_t base, F&& f) {
+    for (int64_t e = lo; e < hi; e += step) {
+        const int2 x = A.val[e];
+        const uint32_t loc = (uint32_t)(A.idx[e] - base);
+        if (A.form == 0) {
+            f((loc << 22) | ((uint32_t)x.x << 11) | (uint32_t)x.y);
+        } else {
+            int64_t parts[2] = {x.x, (int64_t)x.y - x.x};
+            for (int h = 0; h < 2; ++h) {
+                int64_t v = parts[h];
+                const uint32_t off = A.f1_base + loc * 256u + (uint32_t)h * 128u;
+                while (v != 0) {
+                    const uint64_t mag = (uint64_t)(v < 0 ? -v : v);
+                    const int len = 64 - __clzll((long long)mag), sh = len > 3 ? len - 3 : 0;
+                    const int64_t c = (int64_t)((mag >> sh) << sh) * (v < 0 ? -1 : 1);
+                    const uint64_t bits = (uint64_t)__double_as_longlong((double)c);
+                    f((uint32_t)(bits >> 50) << 18 | off);
+                    v -= c;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_build_fill(VrxTileArgs A, const int32_t* __restrict__ seg_lo,
+                                                            const int32_t* __restrict__ seg_hi,
+                                                            const int32_t* __restrict__ rlen,
+                                                            const int32_t* __restrict__ bnd,
+                                                            const int64_t* __restrict__ wave_start,
+                                                            uint32_t* __restrict__ ent) {
+    const int half = A.G / 2;
+    const int64_t t = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    const int64_t nsr = (int64_t)A.n_slab * A.NR;
+    if (t >= A.n_wave * nsr * half) return;
+    const int p = (int)(t % half);
+    const int64_t wr = t / half;
+    const int64_t i = wr % nsr;  // (slab, round)
+    const int64_t w = wr / nsr;
+    const int sl = (int)(i / A.NR), r = (int)(i % A.NR);
+    const int L = rlen[w * nsr + i];
+    if (L == 0) return;
+    const int Lr = (L + A.U - 1) / A.U * A.U;
+    // the p-th lane group whose partner (g ^ xor_partner) has the larger index
+    int hb = 1;
+    while (hb * 2 <= A.xor_partner) hb *= 2;
+    const int g0 = ((p / hb) * hb * 2) | (p % hb), g1 = g0 ^ A.xor_partner;
+    uint32_t* dst = ent + wave_start[w] + (bnd[w * (nsr + 1) + i] & ~(A.U * A.G - 1));
+    const int64_t base = (int64_t)sl * A.slab_rows;
+    int64_t lo[2], hi[2];
+    int step[2];
+    const int gs[2] = {g0, g1};
+    for (int m = 0; m < 2; ++m) {
+        const int64_t at = (w * A.n_slab + sl) * A.RW + r * A.G + gs[m];
+        lo[m] = seg_lo[at];
+        hi[m] = seg_hi[at];
+        const int32_t v = A.rowmap[w * A.RW + r * A.G + gs[m]];
+        step[m] = 1;
+        if (v >= 0) {
+            const int32_t row = A.vrow_row[v];
+            step[m] = A.vptr[row + 1] - A.vptr[row];
+        }
+    }
+    const bool pair = A.pairing && A.bit_shift >= 0;
+    if (!pair) {  // natural order, zero-valued words behind the segment
+        for (int m = 0; m < 2; ++m) {
+            int n = 0;
+            vrx_segment_words(A, lo[m], hi[m], step[m], base, [&](uint32_t wd) { dst[(int64_t)n++ * A.G + gs[m]] = wd; });
+            for (; n < Lr; ++n) dst[(int64_t)n * A.G + gs[m]] = A.pad_word;
+        }
+        return;
+    }
+    // counts per bank bit: [group][bit]
+    int cnt[2][2] = {{0, 0}, {0, 0}};
+    for (int m = 0; m < 2; ++m)
+        vrx_segment_words(A, lo[m], hi[m], step[m], base, [&](uint32_t wd) { ++cnt[m][(wd >> A.bit_shift) & 1u]; });
+    const int p0 = cnt[0][0], p1 = cnt[0][1], q0 = cnt[1][0], q1 = cnt[1][1];
+    const int zlo = max(p0, q1), zhi = min(L - p1, L - q0);
+    const bool fits = zlo <= zhi;
+    const int z = (zlo + zhi) / 2;
+    const uint32_t pad0 = A.form == 1 ? A.f1_base : 0u, pad1 = pad0 | 1u << A.bit_shift;
+    // group g0: bit-0 words from position 0, bit-1 words from z (or right behind when it does not fit)
+    {
+        int c0 = 0, c1 = fits ? z : p0;
+        vrx_segment_words(A, lo[0], hi[0], step[0], base, [&](uint32_t wd) {
+            const int at = ((wd >> A.bit_shift) & 1u) ? c1++ : c0++;
+            dst[(int64_t)at * A.G + g0] = wd;
+        });
+        if (fits) {
+            for (int n = p0; n < z; ++n) dst[(int64_t)n * A.G + g0] = pad0;
+            for (int n = z + p1; n < L; ++n) dst[(int64_t)n * A.G + g0] = pad1;
+            for (int n = L; n < Lr; ++n) dst[(int64_t)n * A.G + g0] = A.pad_word;
+        } else {
+            for (int n = p0 + p1; n < Lr; ++n) dst[(int64_t)n * A.G + g0] = A.pad_word;
+        }
+    }
+    // its partner: bit-1 words first
+    {
+        int c1 = 0, c0 = fits ? z : q1;
+        vrx_segment_words(A, lo[1], hi[1], step[1], base, [&](uint32_t wd) {
+            const int at = ((wd >> A.bit_shift) & 1u) ? c1++ : c0++;
+            dst[(int64_t)at * A.G + g1] = wd;
+        });
+        if (fits) {
+            for (int n = q1; n < z; ++n) dst[(int64_t)n * A.G + g1] = pad1;
+            for (int n = z + q0; n < L; ++n) dst[(int64_t)n * A.G + g1] = pad0;
+            for (int n = L; n < Lr; ++n) dst[(int64_t)n * A.G + g1] = A.pad_word;
+        } else {
+            for (int n = q0 + q1; n < Lr; ++n) dst[(int64_t)n * A.G + g1] = A.pad_word;
+        }
+    }
+}

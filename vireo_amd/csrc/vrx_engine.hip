@@ -13,6 +13,7 @@
 
 #include "vrx_common.h"
 #include "vrx_kernels.h"
+#include "vrx_build.h"
 
 // ------------------------------------------------------------------------------------
 // errors
@@ -267,8 +268,17 @@ static int build_orient(Orient& o, int64_t n_rows, int64_t n_contract, const int
 // form 1 (cell pass): every (ad, dp) entry becomes single-valued entries of AD and of
 // BD = DP - AD (none for a zero, several for a value outside 15 signed bits), see FORM 1 in
 // vrx_kernels.h.  Word = value:15 | (2 * slab-local index + half) * 128.
+// `dev` != nullptr: the rows of this orientation live on the device (idx / val are then unused
+// host pointers) and the stream is built there (vrx_build.h); ptr is always the host copy.
+struct DevRows {
+    const int64_t* ptr;
+    const int32_t* idx;
+    const int2* val;
+};
+
 static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const int2* val,
-                       int RW, int slab_rows, bool guard, int form, int mode, hipStream_t s) {
+                       int RW, int slab_rows, bool guard, int form, int mode, hipStream_t s,
+                       const DevRows* dev = nullptr) {
     constexpr int G = 64 / VRX_LDS_LPE, U = VRX_LDS_U;
     const int NR = RW / G;
     TiledStream& t = o.tiled;
@@ -351,6 +361,83 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
             v -= c;
         }
     };
+    if (dev) {  // ---- the stream is built on the device --------------------------------------
+        DevBuf<int32_t> d_rowmap, d_vptr, d_vrow, seg_lo, seg_hi, rlen, d_too;
+        VRX_HIP(d_rowmap.upload(rowmap.data(), rowmap.size(), s));
+        VRX_HIP(d_vptr.upload(vptr.data(), vptr.size(), s));
+        VRX_HIP(d_vrow.upload(vrow_row.data(), vrow_row.size(), s));
+        VrxTileArgs A;
+        A.ptr = dev->ptr;
+        A.idx = dev->idx;
+        A.val = dev->val;
+        A.rowmap = d_rowmap.p;
+        A.vptr = d_vptr.p;
+        A.vrow_row = d_vrow.p;
+        A.RW = RW;
+        A.NR = NR;
+        A.G = G;
+        A.U = U;
+        A.n_slab = t.n_slab;
+        A.slab_rows = slab_rows;
+        A.form = form;
+        A.bit_shift = bit_shift;
+        A.pairing = parity_order ? 1 : 0;
+        A.xor_partner = 24 / VRX_LDS_LPE;
+        A.f1_base = f1_base;
+        A.pad_word = pad_word;
+        A.n_wave = n_wave;
+        const int64_t n_pos = n_wave * t.n_slab * RW, nsr = (int64_t)t.n_slab * NR;
+        VRX_REQUIRE(n_pos < INT32_MAX * (int64_t)VRX_BLOCK, "tiled stream: too many segments");
+        VRX_HIP(seg_lo.alloc((size_t)n_pos));
+        VRX_HIP(seg_hi.alloc((size_t)n_pos));
+        VRX_HIP(rlen.alloc((size_t)(n_wave * nsr)));
+        VRX_HIP(d_too.alloc(1));
+        VRX_HIP(hipMemsetAsync(d_too.p, 0, sizeof(int32_t), s));
+        VRX_HIP(t.bnd.alloc((size_t)(n_wave * per_wave)));
+        DevBuf<int64_t> d_wlen;
+        VRX_HIP(d_wlen.alloc((size_t)n_wave));
+        vrx_build_count<<<(unsigned)((n_pos + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
+            A, seg_lo.p, seg_hi.p, rlen.p);
+        VRX_HIP(hipGetLastError());
+        vrx_build_offsets<<<(unsigned)((n_wave + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
+            A, rlen.p, t.bnd.p, d_wlen.p, d_too.p);
+        VRX_HIP(hipGetLastError());
+        int32_t h_too = 0;
+        VRX_HIP(hipMemcpyAsync(wave_len.data(), d_wlen.p, (size_t)n_wave * sizeof(int64_t),
+                               hipMemcpyDeviceToHost, s));
+        VRX_HIP(hipMemcpyAsync(&h_too, d_too.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        VRX_HIP(hipStreamSynchronize(s));
+        if (h_too) {
+            vrx_set_error("tiled stream: wave stream >= 2^31 words");
+            return VRX_ERR_UNSUPPORTED;
+        }
+        int64_t total = 0, longest_wave = 0;
+        for (int64_t w = 0; w < n_wave; ++w) {
+            wave_start[(size_t)w] = total;
+            total += wave_len[(size_t)w];
+            longest_wave = std::max(longest_wave, wave_len[(size_t)w]);
+        }
+        t.pad_ratio = o.nnz > 0 ? (double)total / (double)o.nnz : 0.0;
+        t.imbalance = total > 0 ? (double)longest_wave * (double)n_wave / (double)total : 1.0;
+        if (guard && t.pad_ratio * std::max(1.0, t.imbalance / 1.5) > (double)env_int("VIREO_LDS_MAX_PAD", 3)) {
+            t.bnd.release();
+            t.ready = false;
+            return VRX_OK;
+        }
+        VRX_HIP(t.ent.alloc((size_t)total + 8));
+        VRX_HIP(hipMemsetAsync(t.ent.p + total, 0, 8 * sizeof(uint32_t), s));
+        VRX_HIP(t.wave_start.upload(wave_start.data(), wave_start.size(), s));
+        const int64_t n_fill = n_wave * nsr * (G / 2);
+        VRX_REQUIRE(n_fill < INT32_MAX * (int64_t)VRX_BLOCK, "tiled stream: too many rounds");
+        vrx_build_fill<<<(unsigned)((n_fill + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
+            A, seg_lo.p, seg_hi.p, rlen.p, t.bnd.p, t.wave_start.p, t.ent.p);
+        VRX_HIP(hipGetLastError());
+        VRX_HIP(t.rowmap.upload(rowmap.data(), rowmap.size(), s));
+        if (t.split) VRX_HIP(t.vptr.upload(vptr.data(), vptr.size(), s));
+        VRX_HIP(hipStreamSynchronize(s));
+        t.ready = true;
+        return VRX_OK;
+    }
     std::vector<std::vector<uint32_t>> wave_words((size_t)n_wave);
     auto walk = [&](int64_t w) {
         std::vector<uint32_t>& dst = wave_words[(size_t)w];
@@ -500,6 +587,164 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
     return VRX_OK;
 }
 
+// Rows per wave of the cell pass.  One workgroup per CU at a time: a launch of W workgroups
+// takes ceil(W / 256) rounds.  With many slabs W is ~1000 whatever the tile height; with one or
+// two slabs (few variants: clone mode) W = tiles x slabs, and the shorter tile wins when it
+// fills the last round better (200 k cells: 261 tiles of 768 rows = 2 rounds at 51 %, 391 tiles
+// of 512 rows = 2 rounds at 76 %).
+static int pick_rw_cell(int64_t n_var, int64_t n_cell) {
+    const int n_slab_c = (int)((n_var + 511) / 512);
+    auto cost = [&](int rw) {  // rounds x rows per wave x slabs per workgroup
+        const int64_t tiles = (n_cell + 16 * (int64_t)rw - 1) / (16 * (int64_t)rw);
+        const int64_t ranges = std::max<int64_t>(
+            1, std::min<int64_t>(n_slab_c, env_int("VIREO_LDS_BLOCKS", 1024) / std::max<int64_t>(tiles, 1)));
+        const int64_t w = tiles * ranges;
+        return (double)((w + 255) / 256) * rw * (double)n_slab_c / (double)ranges;
+    };
+    const int forced = env_int("VIREO_LDS_RW_CELL", 0);
+    return forced == VRX_LDS_RW_CELL_SHORT ||
+                   (forced == 0 && n_slab_c <= 2 && cost(VRX_LDS_RW_CELL_SHORT) < cost(VRX_LDS_RW_CELL))
+               ? VRX_LDS_RW_CELL_SHORT
+               : VRX_LDS_RW_CELL;
+}
+
+// Large problems: everything from the merged CSC arrays onwards happens on the device
+// (vrx_build.h).  *built = false means "not applicable here" (small problem, counts the pair
+// words cannot hold, a stream the padding guard rejects): the caller then runs the host builder.
+static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* rowidx,
+                        const int32_t* ad, const int32_t* dp, int rw_cell, int slab_cell, int slab_var,
+                        int cell_form, bool guard, bool* built) {
+    *built = false;
+    const int64_t nnz = p->nnz, n_var = p->n_var, n_cell = p->n_cell;
+    hipStream_t s = p->stream;
+    if (nnz <= 0 || nnz >= INT32_MAX) return VRX_OK;
+    for (int64_t c = 0; c < n_cell; ++c)
+        if (colptr[c + 1] < colptr[c]) {
+            vrx_set_error("vrx_problem_create: colptr not monotone at column %lld", (long long)c);
+            return VRX_ERR_ARG;
+        }
+    DevBuf<int64_t> d_colptr, d_rptr;
+    DevBuf<int32_t> d_row, d_ad, d_dp, d_ecol, d_nvars, d_status, d_ridx;
+    DevBuf<int2> d_cval, d_rval;
+    DevBuf<uint32_t> keys_in, keys_out, vals_in, vals_out;
+    VRX_HIP(d_colptr.upload(colptr, (size_t)n_cell + 1, s));
+    VRX_HIP(d_row.upload(rowidx, (size_t)nnz, s));
+    VRX_HIP(d_ad.upload(ad, (size_t)nnz, s));
+    VRX_HIP(d_dp.upload(dp, (size_t)nnz, s));
+    VRX_HIP(d_ecol.alloc((size_t)nnz));
+    VRX_HIP(d_nvars.alloc((size_t)n_cell));
+    VRX_HIP(hipMemsetAsync(d_nvars.p, 0, (size_t)n_cell * sizeof(int32_t), s));
+    const int32_t st0[3] = {INT32_MAX, 0, 0};
+    VRX_HIP(d_status.upload(st0, 3, s));
+    const unsigned nb = (unsigned)((nnz + VRX_BLOCK - 1) / VRX_BLOCK);
+    vrx_build_validate<<<nb, VRX_BLOCK, 0, s>>>(nnz, n_var, n_cell, d_colptr.p, d_row.p, d_ad.p, d_dp.p,
+                                                d_ecol.p, d_nvars.p, d_status.p);
+    VRX_HIP(hipGetLastError());
+    int32_t st[3];
+    p->n_vars.assign((size_t)n_cell, 0);
+    VRX_HIP(hipMemcpyAsync(st, d_status.p, sizeof st, hipMemcpyDeviceToHost, s));
+    VRX_HIP(hipMemcpyAsync(p->n_vars.data(), d_nvars.p, (size_t)n_cell * sizeof(int32_t),
+                           hipMemcpyDeviceToHost, s));
+    VRX_HIP(hipStreamSynchronize(s));
+    if (st[0] != INT32_MAX) {
+        if (st[1] == 3)
+            vrx_set_error("vrx_problem_create: negative count in column %lld", (long long)st[0]);
+        else
+            vrx_set_error("vrx_problem_create: row indices of column %lld not strictly "
+                          "increasing / out of range", (long long)st[0]);
+        return VRX_ERR_ARG;
+    }
+    const int32_t max_count = st[2];
+    if (max_count >= 2048) return VRX_OK;  // (the variant stream holds 11-bit counts)
+    // ---- transposition: stable sort of (variant, entry) ---------------------------------------
+    VRX_HIP(keys_in.alloc((size_t)nnz));
+    VRX_HIP(keys_out.alloc((size_t)nnz));
+    VRX_HIP(vals_in.alloc((size_t)nnz));
+    VRX_HIP(vals_out.alloc((size_t)nnz));
+    vrx_build_iota_keys<<<nb, VRX_BLOCK, 0, s>>>(nnz, d_row.p, keys_in.p, vals_in.p);
+    VRX_HIP(hipGetLastError());
+    int bits = 1;
+    while (((int64_t)1 << bits) < n_var) ++bits;
+    {
+        size_t tmp_bytes = 0;
+        VRX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in.p, keys_out.p, vals_in.p,
+                                                   vals_out.p, (int)nnz, 0, bits, s));
+        DevBuf<char> tmp;
+        VRX_HIP(tmp.alloc(tmp_bytes));
+        VRX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, keys_in.p, keys_out.p, vals_in.p,
+                                                   vals_out.p, (int)nnz, 0, bits, s));
+        VRX_HIP(hipStreamSynchronize(s));
+    }
+    keys_in.release();
+    vals_in.release();
+    VRX_HIP(d_rptr.alloc((size_t)n_var + 1));
+    vrx_build_rptr<<<(unsigned)((n_var + 1 + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
+        n_var, nnz, keys_out.p, d_rptr.p);
+    VRX_HIP(hipGetLastError());
+    VRX_HIP(d_ridx.alloc((size_t)nnz));
+    VRX_HIP(d_rval.alloc((size_t)nnz));
+    VRX_HIP(d_cval.alloc((size_t)nnz));
+    vrx_build_gather<<<nb, VRX_BLOCK, 0, s>>>(nnz, vals_out.p, d_ecol.p, d_ad.p, d_dp.p, d_ridx.p,
+                                              d_rval.p, d_cval.p);
+    VRX_HIP(hipGetLastError());
+    std::vector<int64_t> rptr((size_t)n_var + 1);
+    VRX_HIP(hipMemcpyAsync(rptr.data(), d_rptr.p, rptr.size() * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    VRX_HIP(hipStreamSynchronize(s));
+    keys_out.release();
+    vals_out.release();
+    d_ecol.release();
+    d_ad.release();
+    d_dp.release();
+    // ---- the packed entry arrays of both orientations (no segment tables: the LDS-resident
+    //      passes below serve every K) ------------------------------------------------------------
+    auto pick_fmt = [&](int64_t n_contract) {
+        int f = VRX_FMT_WIDE;
+        if (max_count < (1 << 16)) f = VRX_FMT_P64;
+        if (max_count < 64 && n_contract <= (1 << 20)) f = VRX_FMT_P32;
+        const int forced = env_int("VIREO_ENTRY_FMT", -1);
+        return forced >= f && forced <= VRX_FMT_WIDE ? forced : f;
+    };
+    auto set_orient = [&](Orient& o, int64_t n_rows, int64_t n_contract, const int32_t* d_idx,
+                          const int2* d_val) {
+        o.n_rows = n_rows;
+        o.n_contract = n_contract;
+        o.nnz = nnz;
+        o.fmt = pick_fmt(n_contract);
+        o.n_tiles = 1;
+        o.n_seg = 0;
+        o.n_multi = o.n_slots = 0;
+        VRX_HIP(o.ent.alloc((size_t)nnz * (o.fmt + 1)));
+        vrx_build_pack<<<nb, VRX_BLOCK, 0, s>>>(nnz, o.fmt, d_idx, d_val, o.ent.p);
+        VRX_HIP(hipGetLastError());
+        return VRX_OK;
+    };
+    int rc;
+    if ((rc = set_orient(p->by_cell, n_cell, n_var, d_row.p, d_cval.p))) return rc;
+    if ((rc = set_orient(p->by_var, n_var, n_cell, d_ridx.p, d_rval.p))) return rc;
+    const DevRows cell_rows{d_colptr.p, d_row.p, d_cval.p}, var_rows{d_rptr.p, d_ridx.p, d_rval.p};
+    rc = build_tiled(p->by_cell, colptr, nullptr, nullptr, rw_cell, slab_cell, guard, cell_form, 1, s,
+                     &cell_rows);
+    if (rc) return rc;
+    rc = build_tiled(p->by_var, rptr.data(), nullptr, nullptr, VRX_LDS_RW_VARIANT, slab_var, guard, 0, 0,
+                     s, &var_rows);
+    if (rc) return rc;
+    VRX_HIP(hipStreamSynchronize(s));
+    if (!p->by_cell.tiled.ready || !p->by_var.tiled.ready) {  // rejected by the padding guard
+        for (Orient* o : {&p->by_cell, &p->by_var}) {
+            o->ent.release();
+            o->tiled.ent.release();
+            o->tiled.wave_start.release();
+            o->tiled.bnd.release();
+            o->tiled.rowmap.release();
+            o->tiled.vptr.release();
+            o->tiled.ready = false;
+        }
+        return VRX_OK;
+    }
+    *built = true;
+    return VRX_OK;
+}
+
 extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int64_t nnz,
                                   const int64_t* colptr, const int32_t* rowidx, const int32_t* ad,
                                   const int32_t* dp, vrx_problem** out) {
@@ -526,6 +771,30 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
     VRX_HIP(hipGetDeviceProperties(&prop, device));
     p->n_cu = prop.multiProcessorCount;
     VRX_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+
+    // Problems that will run on the LDS-resident passes anyway (both thresholds met) are built
+    // on the device; VIREO_BUILD=host keeps the host builder (the specification the device
+    // build is tested against), VIREO_BUILD=device takes the device path whenever VIREO_LDS
+    // allows the streams.
+    {
+        const int lds0 = env_int("VIREO_LDS", -1);
+        const char* bm = getenv("VIREO_BUILD");
+        const bool force_dev = bm && !strcmp(bm, "device"), force_host = bm && !strcmp(bm, "host");
+        const bool big = nnz >= (int64_t)env_int("VIREO_LDS_MIN_NNZ", 4000000) &&
+                         nnz >= (int64_t)env_int("VIREO_LDS_MIN_NNZ_VAR", 32000000);
+        if (!force_host && lds0 != 0 && env_int("VIREO_CELL_FORM", 1) == 1 && (force_dev || big)) {
+            bool built = false;
+            int rc = device_build(p.get(), colptr, rowidx, ad, dp, pick_rw_cell(n_var, n_cell),
+                                  std::min(512, std::max(16, env_int("VIREO_LDS_SLAB_CELL", 512))),
+                                  std::min(1024, std::max(16, env_int("VIREO_LDS_SLAB_VAR", 1024))), 1,
+                                  lds0 != 1, &built);
+            if (rc) return rc;
+            if (built) {
+                *out = p.release();
+                return VRX_OK;
+            }
+        }
+    }
 
     // validate + interleave (ad, dp); count per-cell and per-variant entries.  Cells are cut
     // into one contiguous chunk per host thread; every thread keeps its own per-variant
@@ -635,25 +904,7 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
     if ((max_count < 2048 || cell_form == 1) && lds != 0) {
         // cell pass: slabs of 512 W rows (128 KiB at K = 16); variant pass: 1024 ID rows
         if (lds == 1 || nnz >= (int64_t)env_int("VIREO_LDS_MIN_NNZ", 4000000)) {
-            // One workgroup per CU at a time: a launch of W workgroups takes ceil(W / 256)
-            // rounds.  With many slabs W is ~1000 whatever the tile height; with one or two
-            // slabs (few variants: clone mode) W = tiles x slabs, and the shorter tile wins
-            // when it fills the last round better (200 k cells: 261 tiles of 768 rows = 2
-            // rounds at 51 %, 391 tiles of 512 rows = 2 rounds at 76 %).
-            const int n_slab_c = (int)((n_var + 511) / 512);
-            auto cost = [&](int rw) {  // rounds x rows per wave x slabs per workgroup
-                const int64_t tiles = (n_cell + 16 * (int64_t)rw - 1) / (16 * (int64_t)rw);
-                const int64_t ranges = std::max<int64_t>(
-                    1, std::min<int64_t>(n_slab_c, env_int("VIREO_LDS_BLOCKS", 1024) / std::max<int64_t>(tiles, 1)));
-                const int64_t w = tiles * ranges;
-                return (double)((w + 255) / 256) * rw * (double)n_slab_c / (double)ranges;
-            };
-            const int forced = env_int("VIREO_LDS_RW_CELL", 0);
-            const int rw_cell =
-                forced == VRX_LDS_RW_CELL_SHORT ||
-                        (forced == 0 && n_slab_c <= 2 && cost(VRX_LDS_RW_CELL_SHORT) < cost(VRX_LDS_RW_CELL))
-                    ? VRX_LDS_RW_CELL_SHORT
-                    : VRX_LDS_RW_CELL;
+            const int rw_cell = pick_rw_cell(n_var, n_cell);
             if (cell_form == 1 || max_count < 2048) {
                 rc = build_tiled(p->by_cell, colptr, rowidx, cval.data(), rw_cell,
                                  std::min(512, std::max(16, env_int("VIREO_LDS_SLAB_CELL", 512))),
@@ -716,6 +967,36 @@ extern "C" int vrx_problem_binom_const(vrx_problem* p, double* sum_out) {
         p->binom_done = true;
     }
     *sum_out = p->binom_sum;
+    return VRX_OK;
+}
+
+// 64-bit FNV-1a of a device array (downloaded): tests compare the streams of the host and the
+// device builder with it
+template <class T>
+static int fnv_of(const DevBuf<T>& b, hipStream_t s, uint64_t* out) {
+    std::vector<unsigned char> h(b.n * sizeof(T));
+    if (!h.empty()) {
+        VRX_HIP(hipMemcpyAsync(h.data(), b.p, h.size(), hipMemcpyDeviceToHost, s));
+        VRX_HIP(hipStreamSynchronize(s));
+    }
+    uint64_t x = 1469598103934665603ull;
+    for (unsigned char c : h) x = (x ^ c) * 1099511628211ull;
+    *out = x;
+    return VRX_OK;
+}
+
+extern "C" int vrx_problem_digest(vrx_problem* p, uint64_t* out12) {
+    VRX_REQUIRE(p && out12, "vrx_problem_digest: null argument");
+    VRX_HIP(hipSetDevice(p->device));
+    int rc, k = 0;
+    for (Orient* o : {&p->by_var, &p->by_cell}) {
+        if ((rc = fnv_of(o->ent, p->stream, out12 + k++))) return rc;
+        if ((rc = fnv_of(o->tiled.ent, p->stream, out12 + k++))) return rc;
+        if ((rc = fnv_of(o->tiled.bnd, p->stream, out12 + k++))) return rc;
+        if ((rc = fnv_of(o->tiled.wave_start, p->stream, out12 + k++))) return rc;
+        if ((rc = fnv_of(o->tiled.rowmap, p->stream, out12 + k++))) return rc;
+        out12[k++] = (uint64_t)o->n_seg;
+    }
     return VRX_OK;
 }
 
@@ -1115,6 +1396,7 @@ static bool lds_eligible(const Orient& o, int K) {
     static const int mask = env_int("VIREO_LDS_PASS", 3);  // bit 0: variant pass, bit 1: cell pass
     static const int kmin = env_int("VIREO_LDS_MIN_K", 2);
     static const int kmax = env_int("VIREO_LDS_MAX_K", 1 << 20);  // > 16: column blocks of 16
+    if (o.tiled.ready && o.n_seg == 0) return true;  // (device-built: no gather tables)
     return o.tiled.ready && (mask >> MODE & 1) && K <= kmax && K >= kmin;
 }
 
