@@ -382,19 +382,22 @@ def test_lds_resident_passes_vs_oracle(va, monkeypatch, fmt, blocks, sort):
         close(dev.GT_prob, ref.GT_prob)
 
 
-@pytest.mark.parametrize("top,expect_lds", [(2047, True), (2048, False), (16383, False),
-                                            (16384, False), (90000, False)])
-def test_lds_count_limit_and_tiny_shapes(va, monkeypatch, top, expect_lds):
-    """the (ad, dp) pair words of the variant stream hold counts < 2048: at the limit the LDS
-    variant pass is used, one above that pass silently stays on the global-gather kernel; the
-    single-valued AD / BD words of the cell stream hold 15 signed bits and cut larger counts
-    into several entries, so the LDS cell pass takes any count (16383 / 16384: the chunk
-    boundary; 90000: data/mitoDNA-like depth).  Shapes smaller than one tile / one slab
-    (N=70 variants, M=40 cells) and a single contracted range."""
+@pytest.mark.parametrize("top,var_form", [(2047, 0), (2048, 0), (7, 2), (2048, 2), (16383, 2),
+                                          (16384, 2), (90000, 2)])
+def test_lds_count_limit_and_tiny_shapes(va, monkeypatch, top, var_form):
+    """The single-valued AD / BD words (cell stream, FORM 1; variant stream, FORM 2: the
+    default) carry the top bits of the value's double and cut a count with more than three
+    significant bits into several entries, so the LDS-resident passes take any count (7 / 2048 /
+    16383 / 16384: chunk boundaries; 90000: data/mitoDNA-like depth).  The (ad, dp) pair words of
+    the older variant stream (VIREO_VAR_FORM=0) hold counts < 2048: at the limit that pass is
+    used, one above it silently stays on the global-gather kernel.  Shapes smaller than one
+    tile / one slab (N=70 variants, M=40 cells) and a single contracted range."""
     from vireo_amd import _lib
     from vireo_amd.counts import DeviceCounts
     from vireo_amd.engine import DeviceModel
     monkeypatch.setenv("VIREO_LDS", "1")
+    monkeypatch.setenv("VIREO_VAR_FORM", str(var_form))
+    expect_lds = var_form == 2 or top < 2048
     rng = np.random.default_rng(5)
     dp = (rng.random((70, 40)) < 0.3) * rng.integers(1, 60, (70, 40))
     dp[3, 7] = top

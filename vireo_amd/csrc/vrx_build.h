@@ -30,7 +30,7 @@ struct VrxTileArgs {  // one orientation's tiled-stream geometry, by value to th
     const int32_t* idx;
     const int2* val;
     const int32_t *rowmap, *vptr, *vrow_row;
-    int RW, NR, G, U, n_slab, slab_rows, form, bit_shift, pairing, xor_partner;
+    int RW, NR, G, U, n_slab, slab_rows, form, PH, bit_shift, pairing, xor_partner;
     uint32_t f1_base, pad_word;
     int64_t n_wave;
 };
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_build_count(VrxTileArgs A, int3
                                                              int32_t* __restrict__ rlen) {
     const int64_t t = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
     const int64_t total = A.n_wave * A.n_slab * A.RW;
-    int n = 0;
+    int n = 0, n2 = 0;  // entries of phase 0 (all forms) and phase 1 (form 2)
     if (t < total) {
         const int pos = (int)(t % A.RW);
         const int64_t ws = t / A.RW;
@@ -175,7 +175,13 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_build_count(VrxTileArgs A, int3
                     ++n;
                 } else {
                     const int2 x = A.val[e];
-                    n += vrx_chunks(x.x) + vrx_chunks((int64_t)x.y - x.x);
+                    const int ca = vrx_chunks(x.x), cb = vrx_chunks((int64_t)x.y - x.x);
+                    if (A.form == 1) {
+                        n += ca + cb;
+                    } else {
+                        n += ca;
+                        n2 += cb;
+                    }
                 }
             }
         }
@@ -183,9 +189,15 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_build_count(VrxTileArgs A, int3
         seg_hi[t] = hi;
     }
     // longest segment of the round: the G positions of a round are G consecutive threads
-    int L = n;
-    for (int m = 1; m < A.G; m <<= 1) L = max(L, __shfl_xor(L, m, 64));
-    if (t < total && (t % A.G) == 0) rlen[t / A.G] = L;
+    int L = n, L2 = n2;
+    for (int m = 1; m < A.G; m <<= 1) {
+        L = max(L, __shfl_xor(L, m, 64));
+        L2 = max(L2, __shfl_xor(L2, m, 64));
+    }
+    if (t < total && (t % A.G) == 0) {
+        rlen[t / A.G * A.PH] = L;
+        if (A.PH == 2) rlen[t / A.G * 2 + 1] = L2;
+    }
 }
 
 // per wave: stream offset of every (slab, round) | entries in its last trip; total length
@@ -194,7 +206,7 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_build_offsets(VrxTileArgs A, co
                                                                int64_t* __restrict__ wave_len, int32_t* too_long) {
     const int64_t w = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
     if (w >= A.n_wave) return;
-    const int64_t nsr = (int64_t)A.n_slab * A.NR;
+    const int64_t nsr = (int64_t)A.n_slab * A.NR * A.PH;
     int64_t rel = 0;
     for (int64_t i = 0; i < nsr; ++i) {
         if (rel >= INT32_MAX - 4096) {
@@ -212,7 +224,7 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_build_offsets(VrxTileArgs A, co
 // the words of one segment, in the order of build_tiled: f(word) for every entry / chunk
 template <class F>
 __device__ __forceinline__ void vrx_segment_words(const VrxTileArgs& A, int64_t lo, int64_t hi, int step,
-                                                  int64_t base, F&& f) {
+                                                  int64_t base, int ph, F&& f) {
     for (int64_t e = lo; e < hi; e += step) {
         const int2 x = A.val[e];
         const uint32_t loc = (uint32_t)(A.idx[e] - base);
@@ -221,8 +233,10 @@ __device__ __forceinline__ void vrx_segment_words(const VrxTileArgs& A, int64_t 
         } else {
             int64_t parts[2] = {x.x, (int64_t)x.y - x.x};
             for (int h = 0; h < 2; ++h) {
+                if (A.form == 2 && h != ph) continue;  // form 2: one of the two per phase
                 int64_t v = parts[h];
-                const uint32_t off = A.f1_base + loc * 256u + (uint32_t)h * 128u;
+                const uint32_t off = A.form == 2 ? A.f1_base + loc * 128u
+                                                 : A.f1_base + loc * 256u + (uint32_t)h * 128u;
                 while (v != 0) {
                     const uint64_t mag = (uint64_t)(v < 0 ? -v : v);
                     const int len = 64 - __clzll((long long)mag), sh = len > 3 ? len - 3 : 0;
@@ -244,13 +258,14 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_build_fill(VrxTileArgs A, const
                                                             uint32_t* __restrict__ ent) {
     const int half = A.G / 2;
     const int64_t t = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
-    const int64_t nsr = (int64_t)A.n_slab * A.NR;
+    const int64_t nsr = (int64_t)A.n_slab * A.NR * A.PH;
     if (t >= A.n_wave * nsr * half) return;
     const int p = (int)(t % half);
     const int64_t wr = t / half;
-    const int64_t i = wr % nsr;  // (slab, round)
+    const int64_t i = wr % nsr;  // (slab, round, phase)
     const int64_t w = wr / nsr;
-    const int sl = (int)(i / A.NR), r = (int)(i % A.NR);
+    const int ph = (int)(i % A.PH);
+    const int sl = (int)(i / A.PH / A.NR), r = (int)(i / A.PH % A.NR);
     const int L = rlen[w * nsr + i];
     if (L == 0) return;
     const int Lr = (L + A.U - 1) / A.U * A.U;
@@ -278,7 +293,7 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_build_fill(VrxTileArgs A, const
     if (!pair) {  // natural order, zero-valued words behind the segment
         for (int m = 0; m < 2; ++m) {
             int n = 0;
-            vrx_segment_words(A, lo[m], hi[m], step[m], base, [&](uint32_t wd) { dst[(int64_t)n++ * A.G + gs[m]] = wd; });
+            vrx_segment_words(A, lo[m], hi[m], step[m], base, ph, [&](uint32_t wd) { dst[(int64_t)n++ * A.G + gs[m]] = wd; });
             for (; n < Lr; ++n) dst[(int64_t)n * A.G + gs[m]] = A.pad_word;
         }
         return;
@@ -286,16 +301,16 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_build_fill(VrxTileArgs A, const
     // counts per bank bit: [group][bit]
     int cnt[2][2] = {{0, 0}, {0, 0}};
     for (int m = 0; m < 2; ++m)
-        vrx_segment_words(A, lo[m], hi[m], step[m], base, [&](uint32_t wd) { ++cnt[m][(wd >> A.bit_shift) & 1u]; });
+        vrx_segment_words(A, lo[m], hi[m], step[m], base, ph, [&](uint32_t wd) { ++cnt[m][(wd >> A.bit_shift) & 1u]; });
     const int p0 = cnt[0][0], p1 = cnt[0][1], q0 = cnt[1][0], q1 = cnt[1][1];
     const int zlo = max(p0, q1), zhi = min(L - p1, L - q0);
     const bool fits = zlo <= zhi;
     const int z = (zlo + zhi) / 2;
-    const uint32_t pad0 = A.form == 1 ? A.f1_base : 0u, pad1 = pad0 | 1u << A.bit_shift;
+    const uint32_t pad0 = A.form != 0 ? A.f1_base : 0u, pad1 = pad0 | 1u << A.bit_shift;
     // group g0: bit-0 words from position 0, bit-1 words from z (or right behind when it does not fit)
     {
         int c0 = 0, c1 = fits ? z : p0;
-        vrx_segment_words(A, lo[0], hi[0], step[0], base, [&](uint32_t wd) {
+        vrx_segment_words(A, lo[0], hi[0], step[0], base, ph, [&](uint32_t wd) {
             const int at = ((wd >> A.bit_shift) & 1u) ? c1++ : c0++;
             dst[(int64_t)at * A.G + g0] = wd;
         });
@@ -310,7 +325,7 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_build_fill(VrxTileArgs A, const
     // its partner: bit-1 words first
     {
         int c1 = 0, c0 = fits ? z : q1;
-        vrx_segment_words(A, lo[1], hi[1], step[1], base, [&](uint32_t wd) {
+        vrx_segment_words(A, lo[1], hi[1], step[1], base, ph, [&](uint32_t wd) {
             const int at = ((wd >> A.bit_shift) & 1u) ? c1++ : c0++;
             dst[(int64_t)at * A.G + g1] = wd;
         });

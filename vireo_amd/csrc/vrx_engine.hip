@@ -311,10 +311,12 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
     t.n_tile = (int)((n_vrows + tile_rows - 1) / tile_rows);
     // one workgroup per CU at a time (LDS), so the grid should fill whole rounds of CUs:
     // the largest n_range with n_tile * n_range <= target (4 rounds of 256 CUs by default)
-    const int want = env_int("VIREO_LDS_BLOCKS", 1024);
+    const int want = env_int(mode == 1 ? "VIREO_LDS_BLOCKS_CELL" : "VIREO_LDS_BLOCKS_VAR",
+                             env_int("VIREO_LDS_BLOCKS", 1024));
     t.n_range = std::max(1, std::min(t.n_slab, want / std::max(1, t.n_tile)));
     const int64_t n_wave = (int64_t)t.n_tile * 16;
-    const int64_t per_wave = (int64_t)t.n_slab * NR + 1;
+    const int PH = form == 2 ? 2 : 1;  // phases of a round (form 2: AD entries, then BD entries)
+    const int64_t per_wave = (int64_t)t.n_slab * NR * PH + 1;
     std::vector<int64_t> wave_start((size_t)n_wave), wave_len((size_t)n_wave, 0);
     std::vector<int32_t> bnd((size_t)(n_wave * per_wave));
     std::atomic<bool> too_long{false};
@@ -344,9 +346,9 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
     const bool parity_order = env_int("VIREO_LDS_PARITY", 1) != 0;
     // the entry bit that selects the LDS bank half of a 128-B dense row: half (form 1), parity
     // of the slab-local index (variant pass); none for the 256-B rows of the (ad, dp) cell pass
-    const int bit_shift = form == 1 ? 7 : (mode == 0 ? 22 : -1);
+    const int bit_shift = form != 0 ? 7 : (mode == 0 ? 22 : -1);
     // form 1 words carry the LDS address of their half row: the slab starts behind the rings
-    const uint32_t f1_base = 16u * VRX_RING * 4u, pad_word = form == 1 ? f1_base : 0u;
+    const uint32_t f1_base = 16u * VRX_RING * 4u, pad_word = form != 0 ? f1_base : 0u;
     // FORM 1 value field: the top 14 bits of the IEEE double (sign, exponent, 2 mantissa bits).
     // A value with more than three significant bits becomes several entries (9 = 8 + 1, ...).
     auto push_value = [](std::vector<uint32_t>& out, int64_t v, uint32_t off) {
@@ -380,13 +382,14 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
         A.n_slab = t.n_slab;
         A.slab_rows = slab_rows;
         A.form = form;
+        A.PH = PH;
         A.bit_shift = bit_shift;
         A.pairing = parity_order ? 1 : 0;
         A.xor_partner = 24 / VRX_LDS_LPE;
         A.f1_base = f1_base;
         A.pad_word = pad_word;
         A.n_wave = n_wave;
-        const int64_t n_pos = n_wave * t.n_slab * RW, nsr = (int64_t)t.n_slab * NR;
+        const int64_t n_pos = n_wave * t.n_slab * RW, nsr = (int64_t)t.n_slab * NR * PH;
         VRX_REQUIRE(n_pos < INT32_MAX * (int64_t)VRX_BLOCK, "tiled stream: too many segments");
         VRX_HIP(seg_lo.alloc((size_t)n_pos));
         VRX_HIP(seg_hi.alloc((size_t)n_pos));
@@ -455,11 +458,12 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
                     too_long = true;
                     return;
                 }
-                int64_t longest = 0;
+                // the groups' segments of this slab
+                int64_t s_lo[G], s_hi[G], s_step[G];
                 for (int g = 0; g < G; ++g) {
                     const int32_t v = rm[r * G + g];
-                    std::vector<uint32_t>& sw = segw[g];
-                    sw.clear();
+                    s_lo[g] = s_hi[g] = 0;
+                    s_step[g] = 1;
                     if (v >= 0) {
                         const int32_t row = vrow_row[(size_t)v];
                         int64_t hi = cursor[(size_t)(r * G + g)];
@@ -467,19 +471,27 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
                         while (hi < stop && idx[hi] < lim) ++hi;
                         cursor[(size_t)(r * G + g)] = hi;
                         // this piece's share of the row's slab segment [seg, hi)
-                        const int64_t step = vptr[(size_t)row + 1] - vptr[(size_t)row];
-                        const int64_t off = ((int64_t)(v - vptr[(size_t)row]) + sl) % step;
+                        s_step[g] = vptr[(size_t)row + 1] - vptr[(size_t)row];
+                        s_lo[g] = seg + ((int64_t)(v - vptr[(size_t)row]) + sl) % s_step[g];
+                        s_hi[g] = hi;
+                    }
+                }
+                for (int ph = 0; ph < PH; ++ph) {
+                int64_t longest = 0;
+                for (int g = 0; g < G; ++g) {
+                    std::vector<uint32_t>& sw = segw[g];
+                    sw.clear();
+                    for (int64_t e = s_lo[g]; e < s_hi[g]; e += s_step[g]) {
                         if (form == 0) {
-                            for (int64_t e = seg + off; e < hi; e += step)
-                                sw.push_back(((uint32_t)(idx[e] - base) << 22) |
-                                             ((uint32_t)val[e].x << 11) | (uint32_t)val[e].y);
-                        } else {
-                            for (int64_t e = seg + off; e < hi; e += step) {
-                                const uint32_t at = f1_base + (uint32_t)(idx[e] - base) * 256u;
-                                const int64_t ad = val[e].x, bd = (int64_t)val[e].y - val[e].x;
-                                push_value(sw, ad, at);
-                                push_value(sw, bd, at + 128u);
-                            }
+                            sw.push_back(((uint32_t)(idx[e] - base) << 22) |
+                                         ((uint32_t)val[e].x << 11) | (uint32_t)val[e].y);
+                        } else if (form == 1) {
+                            const uint32_t at = f1_base + (uint32_t)(idx[e] - base) * 256u;
+                            push_value(sw, val[e].x, at);
+                            push_value(sw, (int64_t)val[e].y - val[e].x, at + 128u);
+                        } else {  // form 2: AD entries in phase 0, BD entries in phase 1
+                            const uint32_t at = f1_base + (uint32_t)(idx[e] - base) * 128u;
+                            push_value(sw, ph == 0 ? (int64_t)val[e].x : (int64_t)val[e].y - val[e].x, at);
                         }
                     }
                     longest = std::max<int64_t>(longest, (int64_t)sw.size());
@@ -514,7 +526,7 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
                             continue;
                         }
                         const int64_t z = (zlo + zhi) / 2;
-                        const uint32_t pad0 = form == 1 ? f1_base : 0u, pad1 = pad0 | 1u << bit_shift;
+                        const uint32_t pad0 = form != 0 ? f1_base : 0u, pad1 = pad0 | 1u << bit_shift;
                         auto lay = [&](std::vector<uint32_t>& out, const std::vector<uint32_t>& first,
                                        uint32_t pad_first, const std::vector<uint32_t>& rest,
                                        uint32_t pad_rest) {
@@ -528,16 +540,17 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
                     }
                 }
                 // offset | entries in the last trip (0 = full): the kernel skips the padding
-                bw[(int64_t)sl * NR + r] = (int32_t)(rel | (longest % U));
+                bw[((int64_t)sl * NR + r) * PH + ph] = (int32_t)(rel | (longest % U));
                 longest = (longest + U - 1) / U * U;
                 dst.resize((size_t)(rel + longest * G));
                 for (int64_t j = 0; j < longest; ++j)
-                    for (int g = 0; g < G; ++g)  // padding: value 0 (form 1: at the slab's first row)
+                    for (int g = 0; g < G; ++g)  // padding: value 0 (forms 1, 2: at the slab's first row)
                         dst[(size_t)(rel + j * G + g)] = j < (int64_t)segw[g].size() ? segw[g][(size_t)j] : pad_word;
                 rel += longest * G;  // (a multiple of 64 words: streams stay 16-B aligned)
+                }
             }
         }
-        bw[(int64_t)t.n_slab * NR] = (int32_t)rel;
+        bw[(int64_t)t.n_slab * NR * PH] = (int32_t)rel;
         wave_len[(size_t)w] = rel;
     };
     parallel_chunks(n_wave, host_threads(), [&](int64_t b0, int64_t e0, int) {
@@ -655,7 +668,8 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
         return VRX_ERR_ARG;
     }
     const int32_t max_count = st[2];
-    if (max_count >= 2048) return VRX_OK;  // (the variant stream holds 11-bit counts)
+    const int var_form = env_int("VIREO_VAR_FORM", 2);
+    if (var_form != 2 && max_count >= 2048) return VRX_OK;  // (pair words hold 11-bit counts)
     // ---- transposition: stable sort of (variant, entry) ---------------------------------------
     VRX_HIP(keys_in.alloc((size_t)nnz));
     VRX_HIP(keys_out.alloc((size_t)nnz));
@@ -725,8 +739,8 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
     rc = build_tiled(p->by_cell, colptr, nullptr, nullptr, rw_cell, slab_cell, guard, cell_form, 1, s,
                      &cell_rows);
     if (rc) return rc;
-    rc = build_tiled(p->by_var, rptr.data(), nullptr, nullptr, VRX_LDS_RW_VARIANT, slab_var, guard, 0, 0,
-                     s, &var_rows);
+    rc = build_tiled(p->by_var, rptr.data(), nullptr, nullptr, VRX_LDS_RW_VARIANT, slab_var, guard,
+                     var_form == 2 ? 2 : 0, 0, s, &var_rows);
     if (rc) return rc;
     VRX_HIP(hipStreamSynchronize(s));
     if (!p->by_cell.tiled.ready || !p->by_var.tiled.ready) {  // rejected by the padding guard
@@ -912,11 +926,12 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
                 if (rc) return rc;
             }
         }
-        if (max_count < 2048 &&
+        const int var_form = env_int("VIREO_VAR_FORM", 2);  // 2: AD / BD phases (any counts)
+        if ((var_form == 2 || max_count < 2048) &&
             (lds == 1 || nnz >= (int64_t)env_int("VIREO_LDS_MIN_NNZ_VAR", 32000000))) {
             rc = build_tiled(p->by_var, rptr.data(), ridx.data(), rval.data(), VRX_LDS_RW_VARIANT,
                              std::min(1024, std::max(16, env_int("VIREO_LDS_SLAB_VAR", 1024))),
-                             lds != 1, 0, 0, p->stream);
+                             lds != 1, var_form == 2 ? 2 : 0, 0, p->stream);
             if (rc) return rc;
         }
     }
@@ -1431,6 +1446,11 @@ static auto lds_kernel(int K, bool strided, int rw, int form) {
         return rw == VRX_LDS_RW_CELL_SHORT ? lds_kernel_form1<VRX_LDS_RW_CELL_SHORT>(pad)
                                            : lds_kernel_form1<VRX_LDS_RW_CELL>(pad);
     }
+    if (MODE == 0 && form == 2) {
+        const bool pad = K != 16 || strided;
+        return pad ? vrx_spmm_lds<VRX_LDS_LPE, 0, VRX_LDS_RW_VARIANT, true, 1, 2>
+                   : vrx_spmm_lds<VRX_LDS_LPE, 0, VRX_LDS_RW_VARIANT, false, 1, 2>;
+    }
     if (MODE == 1 && rw == VRX_LDS_RW_CELL_SHORT)
         return lds_kernel_rw<LPE, MODE, MODE == 1 ? VRX_LDS_RW_CELL_SHORT : VRX_LDS_RW_VARIANT>(K, strided);
     return lds_kernel_rw<LPE, MODE, MODE == 1 ? VRX_LDS_RW_CELL : VRX_LDS_RW_VARIANT>(K, strided);
@@ -1448,7 +1468,8 @@ static int launch_lds_one(const Orient& o, hipStream_t s, const double* X, int K
         const int kb = std::min(16, K - c0);
         const bool f1 = MODE == 1 && t.form == 1;  // planar operand, 256-B LDS rows
         constexpr int CPL = 16 / LPE;  // columns per lane: LDS rows hold whole lanes
-        const size_t lds = (size_t)t.slab_rows * (f1 ? 256 : (kb + CPL - 1) / CPL * CPL * (MODE == 1 ? 16 : 8)) +
+        const bool f2 = MODE == 0 && t.form == 2;  // 128-B LDS rows whatever K
+        const size_t lds = (size_t)t.slab_rows * (f1 ? 256 : f2 ? 128 : (kb + CPL - 1) / CPL * CPL * (MODE == 1 ? 16 : 8)) +
                            16 * VRX_RING * 4;
         auto kern = lds_kernel<LPE, MODE>(kb, K > 16, t.rw, t.form);
         VRX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

@@ -313,6 +313,9 @@ constexpr int VRX_CHUNK = 256;  // entries per refill (64 lanes x 16 B of one LD
 #ifndef VRX_LDS_U_DEF
 #define VRX_LDS_U_DEF 4
 #endif
+#ifndef VRX_F1_FULLTRIPS
+#define VRX_F1_FULLTRIPS 0
+#endif
 #ifndef VRX_LDS_L2PF
 #define VRX_LDS_L2PF 0
 #endif
@@ -354,6 +357,12 @@ constexpr int VRX_LDS_U = VRX_LDS_U_DEF;    // entries per trip and group; rows 
 // one v_and_or_b32.  The two lane groups of a ds_read_b128 service
 // group that share a slice rotation read different halves whenever one walks AD entries and the
 // other BD entries, which the stream builder arranges (AD-first / BD-first segments).
+//
+// FORM 2 (variant pass): the same single-valued words against the 128-B rows of ID_prob, in
+// two PHASES per round -- first the AD entries of the round's rows, accumulated into S1 = AD @ ID,
+// then their BD entries, accumulated into S2 = BD @ ID (SS = S1 + S2 at the store); each phase is
+// padded to its own longest row.  ~22 % more slots than the (ad, dp) pair words, but 7 instead of
+// ~15 vector instructions per slot, no conversions, and counts of any size.
 template <int LPE, int MODE, int RW, bool PADK, int SPLIT, int FORM = 0>
 __global__ __launch_bounds__(1024)
 #if VRX_LDS_L2PF
@@ -375,8 +384,11 @@ __global__ __launch_bounds__(1024)
     constexpr int PF = 8;                  // 16-B prefetch registers per thread: 128 KiB / 1024
     constexpr int NV = MODE == 0 ? 2 : 1;  // accumulated values per column
     constexpr int U = VRX_LDS_U;           // entries per trip and group
-    static_assert(RW % G == 0 && RW / G < 63, "rows per wave");
-    static_assert(FORM == 0 || (MODE == 1 && SPLIT == 1), "AD/BD form");
+    static_assert(RW % G == 0 && 2 * (RW / G) < 63, "rows per wave");
+    static_assert(FORM == 0 || (SPLIT == 1 && ((MODE == 1 && FORM == 1) || (MODE == 0 && FORM == 2))),
+                  "AD/BD forms");
+    constexpr int PH = FORM == 2 ? 2 : 1;  // phases of a round (FORM 2: AD entries, then BD entries)
+    constexpr int NRV = NR * PH;           // (round, phase) pairs per slab
     extern __shared__ __attribute__((aligned(16))) char vrx_smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #if VRX_LDS_PRIO == 1
@@ -397,7 +409,7 @@ __global__ __launch_bounds__(1024)
     }
 #endif
     // LDS rows are padded to a multiple of CP columns (zeros); FORM 1: two halves of 16 columns
-    const int KP = FORM == 1 ? 16 : (K + CP - 1) / CP * CP;  // (whole lanes: CP columns each)
+    const int KP = FORM != 0 ? 16 : (K + CP - 1) / CP * CP;  // (whole lanes: CP columns each)
     const int slab_doubles = slab_rows * KP * XD;
     // LDS = [16 entry rings][slab]: the rings first, so that the LDS-DMA destinations stay
     // below 64 KiB
@@ -414,7 +426,7 @@ __global__ __launch_bounds__(1024)
     const int g = lane / LPE, sub = (lane % LPE) / LPR, kl = lane % LPR;
     const bool kok = kl * CP < K;  // a lane's 4 columns may start (or run) past K
     const int64_t wid = (int64_t)tile * 16 + wave;
-    const int32_t* bw = bnd + wid * ((int64_t)n_slab * NR + 1);
+    const int32_t* bw = bnd + wid * ((int64_t)n_slab * NRV + 1);
     const uint32_t* stream = ent + wave_start[wid];
     // byte offset, inside a dense row, of the q-th 16-B slice this lane reads (rotated by g)
     uint32_t qoff[NQ];
@@ -498,8 +510,8 @@ __global__ __launch_bounds__(1024)
     // of the wave's stream; the ring holds two.  A chunk is issued as soon as the slot it goes
     // to has been vacated, and awaited (vmcnt(0)) when the walk reaches it one chunk later.
     // The compiler does not see these loads: its own vmcnt waits only become stricter.
-    const int stream_lo = __builtin_amdgcn_readfirstlane(bw[(int64_t)s_lo * NR]) & ~(U * G - 1);
-    const int stream_end = __builtin_amdgcn_readfirstlane(bw[(int64_t)s_hi * NR]) & ~(U * G - 1);
+    const int stream_lo = __builtin_amdgcn_readfirstlane(bw[(int64_t)s_lo * NRV]) & ~(U * G - 1);
+    const int stream_end = __builtin_amdgcn_readfirstlane(bw[(int64_t)s_hi * NRV]) & ~(U * G - 1);
     const int base0 = stream_lo & ~(VRX_CHUNK - 1);
     const int clamp_last = max(stream_end - 4, 0);  // lanes past the range re-read its last 16 B
     const uint32_t ring_lds = (uint32_t)(wave * VRX_RING * 4);  // (dynamic LDS starts at 0)
@@ -582,7 +594,7 @@ __global__ __launch_bounds__(1024)
         }
     };
 
-    int bvec = bw[(int64_t)s_lo * NR + min(lane, NR)];
+    int bvec = bw[(int64_t)s_lo * NRV + min(lane, NRV)];
     slab_fetch(s_lo);
     for (int s = s_lo; s < s_hi; ++s) {
         __syncthreads();  // every wave is done reading the previous slab
@@ -594,19 +606,22 @@ __global__ __launch_bounds__(1024)
         if (s + 1 < s_hi) slab_fetch(s + 1);
 #endif
         const int bcur = bvec;
-        if (s + 1 < s_hi) bvec = bw[(int64_t)(s + 1) * NR + min(lane, NR)];
+        if (s + 1 < s_hi) bvec = bw[(int64_t)(s + 1) * NRV + min(lane, NRV)];
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
+        for (int rv = 0; rv < NRV; ++rv) {
+            const int r = rv / PH;
             // the round's entries are stored trip-major: word (base + j*G + g) is the j-th
             // entry of the row owned by group g (zero words where that row is shorter)
             // bnd = stream offset (a multiple of U*G) | entries in the round's last trip
             // (0 = a full trip): the zero words that pad the last trip are not executed
-            const int braw = __builtin_amdgcn_readlane(bcur, r);
+            const int braw = __builtin_amdgcn_readlane(bcur, rv);
             const int base = braw & ~(U * G - 1), tail = braw & (U - 1);
-            const int end = __builtin_amdgcn_readlane(bcur, r + 1) & ~(U * G - 1);
+            const int end = __builtin_amdgcn_readlane(bcur, rv + 1) & ~(U * G - 1);
             const int full_end = tail ? end - U * G : end;
-            if (FORM == 1) {
+            if (FORM != 0) {
+                // FORM 2: the AD entries of the round's rows feed S1 (acc), the BD entries S2 (acc2)
+                double (&ac)[NQ][2] = FORM == 2 && (rv & 1) ? acc2[r] : acc[r];
                 // A trip of NE <= U entries: every slice is requested (ds_read_b128, integer
                 // addresses: word offset bits | lane offset, the slab base is part of the word)
                 // before the first FMA; the FMAs of the first half wait for their four reads
@@ -663,10 +678,10 @@ __global__ __launch_bounds__(1024)
                             // (the accumulators tie this wait behind the first half's FMAs)
                             if (u == H && NE == 4)
                                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[2][0]), "+v"(x[2][1]), "+v"(x[3][0]), "+v"(x[3][1]),
-                                             "+v"(acc[r][0][0]), "+v"(acc[r][0][1]), "+v"(acc[r][1][0]), "+v"(acc[r][1][1]));
+                                             "+v"(ac[0][0]), "+v"(ac[0][1]), "+v"(ac[1][0]), "+v"(ac[1][1]));
                             else if (u == H && NE == 3)
                                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[2][0]), "+v"(x[2][1]),
-                                             "+v"(acc[r][0][0]), "+v"(acc[r][0][1]), "+v"(acc[r][1][0]), "+v"(acc[r][1][1]));
+                                             "+v"(ac[0][0]), "+v"(ac[0][1]), "+v"(ac[1][0]), "+v"(ac[1][1]));
                             else if (u == 0 && NE == 2)
                                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[1][0]), "+v"(x[1][1]));
                             else if (u == 0 && NE == 1)
@@ -678,16 +693,22 @@ __global__ __launch_bounds__(1024)
 #else
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
-                            acc[r][q][0] = fma(v, x[u][q][0], acc[r][q][0]);
-                            acc[r][q][1] = fma(v, x[u][q][1], acc[r][q][1]);
+                            ac[q][0] = fma(v, x[u][q][0], ac[q][0]);
+                            ac[q][1] = fma(v, x[u][q][1], ac[q][1]);
                         }
 #endif
                     }
                 };
+#if VRX_F1_FULLTRIPS
+                // (the words that pad a round's last trip carry the value 0: executing them is
+                //  harmless and saves the three partial-trip variants of the loop body)
+                for (int at = base; at < end; at += U * G) trip(at, std::integral_constant<int, 4>());
+#else
                 for (int at = base; at < full_end; at += U * G) trip(at, std::integral_constant<int, 4>());
                 if (tail == 1) trip(full_end, std::integral_constant<int, 1>());
                 if (tail == 2) trip(full_end, std::integral_constant<int, 2>());
                 if (tail == 3) trip(full_end, std::integral_constant<int, 3>());
+#endif
                 continue;
             }
             for (int at = base; at < full_end; at += U * G) {
@@ -750,6 +771,10 @@ __global__ __launch_bounds__(1024)
                     } else if (MODE == 1) {
                         if (!PADK || slice < K) dst[row * ld + slice] = acc[r][q][0];
                     } else {  // columns 2*slice, 2*slice+1; S[row][k] = (s1, ss)
+                        if (FORM == 2) {  // acc2 holds S2 = BD @ ID_prob: ss = s1 + s2
+                            acc2[r][q][0] += acc[r][q][0];
+                            acc2[r][q][1] += acc[r][q][1];
+                        }
                         double2* o = reinterpret_cast<double2*>(dst) + row * ld + 2 * slice;
                         if (!PADK || 2 * slice < K)
                             o[0] = make_double2(acc[r][q][0], acc2[r][q][0]);
