@@ -39,3 +39,25 @@ for name, args in MODES.items():
             d.write(src.read())
         subprocess.run(["gzip", "-nf", os.path.join(dst, "GT_donors.vireo.vcf")], check=True)
     print(name, sorted(os.listdir(dst)))
+
+# ---- cli_inputs.npz: what the REFERENCE's loaders make of the donor VCF (mode 2 of demo.sh) ----
+# the matched variant count and the genotype-probability tensor that parse_donor_GPb derives from
+# the PL tags; tests/test_cli_io_cpu.py holds vireo_amd's own loaders to them bit for bit
+if True:
+    import io
+    import contextlib
+    import numpy as np
+    sys.path.insert(0, "/root/reference")
+    from vireoSNP.utils.io_utils import match_donor_VCF
+    from vireoSNP.utils.vcf_utils import load_VCF, parse_donor_GPb, read_sparse_GeneINFO
+    with contextlib.redirect_stdout(io.StringIO()):
+        cell_vcf = load_VCF(DATA + "/cells.cellSNP.vcf.gz", biallelic_only=True)
+        cell_dat = read_sparse_GeneINFO(cell_vcf['GenoINFO'], keys=['AD', 'DP'])
+        for _key in ['samples', 'variants', 'FixedINFO', 'contigs', 'comments']:
+            cell_dat[_key] = cell_vcf[_key]
+        donor_vcf = load_VCF(DATA + "/donors.cellSNP.vcf.gz", biallelic_only=True, sparse=False,
+                             format_list=["PL"])
+        cell_dat, donor_vcf = match_donor_VCF(cell_dat, donor_vcf)
+        GPb = parse_donor_GPb(donor_vcf['GenoINFO']["PL"], "PL")
+    np.savez_compressed(os.path.join(HERE, "cli_inputs.npz"), donor_GPb=GPb,
+                        n_matched=np.int64(len(cell_dat['variants'])))

@@ -27,6 +27,10 @@ MODES = {
 }
 
 
+# (rows of donor_ids.tsv, lines of GT_donors.vireo.vcf.gz) whose text differs from the reference's
+OBSERVED_TEXT_DIFFS = {}
+
+
 def _table(path):
     with open(path) as f:
         return [line.rstrip("\n").split("\t") for line in f]
@@ -57,10 +61,12 @@ def test_cli_matches_reference_outputs(mode, tmp_path, capsys):
     # differ in the last printed digit when a value sits on a rounding boundary
     got, want = _table(out + "/donor_ids.tsv"), _table(ref + "/donor_ids.tsv")
     assert len(got) == len(want)
+    n_text_diff = 0
     for g, w in zip(got, want):
         assert [g[i] for i in (0, 1, 4, 5, 6)] == [w[i] for i in (0, 1, 4, 5, 6)]
         assert _num_close(g[2], w[2], 2e-2) and _num_close(g[3], w[3], 2e-2)
         assert abs(float(g[7]) - float(w[7])) <= 2e-3 if g[7] != "doublet_logLikRatio" else True
+        n_text_diff += g != w
 
     # _log.txt: logLik line identical, theta shapes to 1e-6 relative
     glog, wlog = open(out + "/_log.txt").read().split("\n"), open(ref + "/_log.txt").read().split("\n")
@@ -77,7 +83,14 @@ def test_cli_matches_reference_outputs(mode, tmp_path, capsys):
         w = gzip.open(ref_vcf, "rt").read().split("\n")
         assert len(g) == len(w)
         diff = [i for i, (a, b) in enumerate(zip(g, w)) if a != b]
-        # PL / AD / DP are integers rounded from floats: allow a handful of off-by-one cells
-        assert len(diff) <= max(3, len(w) // 1000), diff[:5]
+        n_vcf_diff = len(diff)
+    else:
+        n_vcf_diff = 0
+    # Observed on MI355X: the output TEXT equals the reference's byte for byte in every mode
+    # (3-significant-digit probabilities, integer PL / AD / DP fields: a value would have to sit
+    # within ~1e-10 of a rounding boundary to print differently).  Anything else is a regression.
+    print("%s: donor_ids.tsv rows that differ as text: %d; VCF lines that differ: %d"
+          % (mode, n_text_diff, n_vcf_diff))
+    assert (n_text_diff, n_vcf_diff) == OBSERVED_TEXT_DIFFS.get(mode, (0, 0))
     for name in ("prob_singlet.tsv.gz", "prob_doublet.tsv.gz"):
         assert os.path.exists(out + "/" + name)

@@ -102,6 +102,44 @@ def load_cells(options):
     return dat
 
 
+def _fail(*lines):
+    for line in lines:
+        print(line)
+    sys.exit(1)
+
+
+def resolve_donors(options, cell_dat):
+    """What the donor arguments ask for (the reference decides this inline, vireo.py:149-189):
+    how many donors, whether their genotypes are learned, the genotype prior from the donor
+    VCF (matched to the cell variants) and the donor names.  Returns the (possibly
+    variant-filtered) cell data and a dict(n_donor, learn_GT, GPb, names, vcf)."""
+    n_donor = options.n_donor
+    if options.donor_file is None:
+        return cell_dat, dict(n_donor=n_donor, learn_GT=True, GPb=None, vcf=None,
+                              names=['donor%d' % x for x in range(n_donor)])
+    if "variants" not in cell_dat:
+        _fail("Error: No variants information is loaded, please provide base.vcf.gz")
+    print("[vireo] Loading donor VCF file ...")
+    tag = options.geno_tag
+    vcf = load_VCF(options.donor_file, biallelic_only=True, sparse=False, format_list=[tag])
+    if vcf['n_SNP_tagged'][0] < 0.1 * len(vcf['GenoINFO'][tag]):
+        _fail("Error: No " + tag + " tag in donor genotype; please try another tag for genotype, e.g., GT",
+              "        %s" % options.donor_file)
+    cell_dat, vcf = match_donor_VCF(cell_dat, vcf)
+    if len(vcf['GenoINFO'][tag]) == 0:
+        _fail("Error: No matching variants found between cell data and donor VCF.")
+    GPb = parse_donor_GPb(vcf['GenoINFO'][tag], tag)
+    known = GPb.shape[1]
+    if n_donor is None or n_donor == known:       # every donor genotyped: nothing to learn
+        n_donor, learn_GT, names = known, False, vcf['samples']
+    elif n_donor < known:                          # a subset of the genotyped donors is pooled
+        learn_GT, names = False, ['donor%d' % x for x in range(n_donor)]
+    else:                                          # extra, ungenotyped donors
+        learn_GT = True
+        names = vcf['samples'] + ['donor%d' % x for x in range(known, n_donor)]
+    return cell_dat, dict(n_donor=n_donor, learn_GT=learn_GT, GPb=GPb, names=names, vcf=vcf)
+
+
 def main(argv=None):
     start = time.time()
     parser = build_parser()
@@ -133,40 +171,9 @@ def main(argv=None):
               "vartrix's alt.mtx,ref.mtx,barcodes.tsv does not contain any variants.")
         sys.exit(1)
 
-    n_donor = options.n_donor                                       # vireo.py:149-189
-    donor_vcf = None
-    if options.donor_file is not None:
-        if "variants" not in cell_dat:
-            print("Error: No variants information is loaded, please provide base.vcf.gz")
-            sys.exit(1)
-        print("[vireo] Loading donor VCF file ...")
-        donor_vcf = load_VCF(options.donor_file, biallelic_only=True, sparse=False,
-                             format_list=[options.geno_tag])
-        if donor_vcf['n_SNP_tagged'][0] < 0.1 * len(donor_vcf['GenoINFO'][options.geno_tag]):
-            print("Error: No " + options.geno_tag + " tag in donor genotype; "
-                  "please try another tag for genotype, e.g., GT")
-            print("        %s" % options.donor_file)
-            sys.exit(1)
-        cell_dat, donor_vcf = match_donor_VCF(cell_dat, donor_vcf)
-        if len(donor_vcf['GenoINFO'][options.geno_tag]) == 0:
-            print("Error: No matching variants found between cell data and donor VCF.")
-            sys.exit(1)
-        donor_GPb = parse_donor_GPb(donor_vcf['GenoINFO'][options.geno_tag], options.geno_tag)
-        if n_donor is None or n_donor == donor_GPb.shape[1]:
-            n_donor = donor_GPb.shape[1]
-            donor_names = donor_vcf['samples']
-            learn_GT = False
-        elif n_donor < donor_GPb.shape[1]:
-            learn_GT = False
-            donor_names = ['donor%d' % x for x in range(n_donor)]
-        else:
-            learn_GT = True
-            donor_names = (donor_vcf['samples'] +
-                           ['donor%d' % x for x in range(donor_GPb.shape[1], n_donor)])
-    else:
-        learn_GT = True
-        donor_GPb = None
-        donor_names = ['donor%d' % x for x in range(n_donor)]
+    cell_dat, donors = resolve_donors(options, cell_dat)
+    n_donor, learn_GT, donor_GPb = donors["n_donor"], donors["learn_GT"], donors["GPb"]
+    donor_names, donor_vcf = donors["names"], donors["vcf"]
 
     counts = device_counts(cell_dat['AD'], cell_dat['DP'])         # one upload for everything
     n_vars = counts.n_vars()                                        # vireo.py:191
