@@ -112,6 +112,32 @@ def c4_leg(counts, K, comm, n_init=32):
         LB_list_head=[float(x) for x in rv["LB_list"][:4]], best_restart=stats["best"])
 
 
+def c2_leg(device, steps=200):
+    """BASELINE.json configs[1] (N=10k x M=5k, K=4): a launch-bound problem.  One restart per
+    model against 16 restarts in one model (vrx_model_cfg.n_batch; vireo_wrap packs its
+    restarts like this when n_donor leaves columns of the 16-wide passes idle)."""
+    from vireo_amd import _lib, synth
+    from vireo_amd.counts import DeviceCounts
+    from vireo_amd.engine import DeviceBatch
+    N, M, K, dens = synth.CONFIGS["c2"]
+    w = synth.donor_workload(N, M, K, dens, seed=0)
+    counts = DeviceCounts.from_merged(w["shape"], w["colptr"], w["rowidx"], w["ad"], w["dp"],
+                                      device=device)
+    rng = np.random.default_rng(0)
+    mu, sm = np.linspace(0.01, 0.99, 3)[None, :], np.full((1, 3), 50.0)
+    out = dict(workload="c2: N=%d x M=%d, K=%d, nnz=%d; %d iterations with theta" % (
+        N, M, K, int(w["rowidx"].size), steps), us_per_restart_iteration={})
+    for R in (1, 4, 16):
+        db = DeviceBatch(counts, _lib.KIND_VIREO, K, R)
+        for r in range(R):
+            db.set_restart(r, rng.random((M, K)), rng.random((N, K, 3)), mu, sm, raw=True)
+        db.run_iters(10)
+        _, ms = db.run_iters(steps)
+        out["us_per_restart_iteration"]["n_batch=%d" % R] = round(ms / steps / R * 1e3, 2)
+        db.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -188,9 +214,11 @@ def main():
     kinfo = dm.info()
     dm.close()
 
-    c4 = None
+    c4 = c2 = None
     if not args.no_c4 and args.config == "c3":
         c4 = c4_leg(counts, K, comm)
+        if rank == 0:
+            c2 = c2_leg(local)
 
     # whole-protocol parity + CPU baseline (rank 0): the same fit on the GPU and on the oracle
     parity = None
@@ -300,6 +328,7 @@ def main():
             "cpu_baseline": cpu,
             "parity": parity,
             "c4": c4,
+            "c2": c2,
         }
         if cpu:
             out["speedup_vs_cpu_1core"] = out["value"] / cpu["value"]

@@ -82,7 +82,12 @@ typedef struct {
     int32_t learn_theta;  /* Vireo.learn_theta   (vireo_model.py:67)                     */
     int32_t ase_mode;     /* Vireo.ASE_mode      (vireo_model.py:66): theta per variant  */
     int32_t fix_beta_sum; /* fix_beta_sum        (vireo_model.py:68, bmm_model.py:52)    */
-    int32_t reserved;
+    int32_t n_batch;      /* restarts held by ONE model (0 or 1: a single model; <= 16).  The
+                             random restarts of vireo_wrap (vireo_wrap.py:64-87) fitted side by
+                             side: state arrays gain a restart axis -- ID_prob [n_cell][R][K],
+                             GT_prob [n_var][R][K][T], beta [R][rows][cols], logLik_ID
+                             [n_cell][R][K] -- and fit / run_iters / step(ELBO) / get_elbo_parts
+                             return one trace / value per restart                           */
 } vrx_model_cfg;
 
 int vrx_model_create(vrx_problem* p, const vrx_model_cfg* cfg, vrx_model** out);
@@ -105,6 +110,15 @@ int vrx_model_set_state_raw(vrx_model* m, const double* ID_raw, const double* GT
 int vrx_model_snapshot(vrx_model* m, int32_t restore);
 int vrx_model_get_state(vrx_model* m, double* ID_prob, double* GT_prob, double* beta_mu,
                         double* beta_sum);
+/* Restart batches (vrx_model_cfg.n_batch = R > 1).  vireo_wrap.py:64-87 builds n_init models
+ * and fits them one after the other; here R of them share every sparse pass.
+ * set_restart: slot r <- one restart's state, in the SINGLE-model layouts of
+ * vrx_model_set_state (raw == 0) or vrx_model_set_state_raw (raw != 0: normalised on the
+ * device).  copy_restart: the single model dst <- slot r of src, device to device (the
+ * winner, vireo_wrap.py:90-91).  Prior tables (vrx_model_set_prior) are shared by the batch. */
+int vrx_model_set_restart(vrx_model* m, int32_t r, const double* ID, const double* GT,
+                          const double* beta_mu, const double* beta_sum, int32_t raw);
+int vrx_model_copy_restart(vrx_model* dst, vrx_model* src, int32_t r);
 
 /* Priors (Vireo.set_prior vireo_model.py:107-137; BinomMixtureVB.set_prior
  * bmm_model.py:87-105).  ID_prior: id_rows = 0 -> uniform 1/K (pointer ignored), 1 -> one
@@ -125,10 +139,13 @@ int vrx_model_set_prior(vrx_model* m, const double* ID_prior, int64_t id_rows,
  *   constant), i.e. one more than the reference keeps: the reference returns
  *   ELBO[:it] -- the host mirrors that truncation.
  *   warn_flags: bit0 = "lower bound decreases" seen, bit1 = "did not converge".
- * Continues from the state currently on the device (warm restart, vireo_wrap.py:94). */
+ * Continues from the state currently on the device (warm restart, vireo_wrap.py:94).
+ * A batch model (n_batch = R) runs until its last restart has stopped; a restart that has
+ * stopped is frozen (its kernels return at once).  Outputs are then per restart:
+ * elbo_trace [R][max_iter], it_out [R], warn_flags [R]. */
 int vrx_model_fit(vrx_model* m, int32_t max_iter, int32_t min_iter, double epsilon_conv,
-                  int32_t delay_fit_theta, double* elbo_trace /* max_iter */,
-                  int32_t* it_out, int32_t* warn_flags);
+                  int32_t delay_fit_theta, double* elbo_trace /* [R][max_iter] */,
+                  int32_t* it_out /* [R] */, int32_t* warn_flags /* [R] */);
 
 /* Single coordinate updates, for the public step methods:
  *   VRX_STEP_THETA  Vireo.update_theta_size (vireo_model.py:165) / bmm_model.py:133

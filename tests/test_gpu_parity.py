@@ -610,3 +610,78 @@ def test_device_builder_reports_bad_input(va, monkeypatch):
     with pytest.raises(_lib.VrxError, match="negative count"):
         DeviceCounts.from_merged((4, 2), colptr, np.array([1, 2, 0], dtype=np.int32),
                                  np.array([1, -1, 1], np.int32), np.ones(3, np.int32))
+
+
+# ---------------------------------------------------------------- restart batches
+def _independent_fits(va, counts, N, M, K, n, seed, **fit):
+    np.random.seed(seed)
+    out = []
+    for _ in range(n):
+        m = va.Vireo(n_var=N, n_cell=M, n_donor=K)
+        m.fit(counts, None, verbose=False, **fit)
+        out.append(m)
+    return out
+
+
+@pytest.mark.parametrize("K,R,lds", [(4, 4, True), (4, 3, True), (3, 5, True), (16, 2, True),
+                                     (4, 4, False), (2, 16, False)])
+def test_restart_batch_equals_independent_fits(va, monkeypatch, K, R, lds):
+    """vrx_model_cfg.n_batch: R restarts in one device model (one sparse pass for all of them,
+    per-restart theta / trace / stop rule) == R independent fits from the same draws.  On the
+    LDS-resident passes every column is accumulated in the same order whatever its neighbours
+    are, so the match is bitwise; the gather kernels pick their lane layout from the column
+    count, which changes the order of a row's partial sums (tolerance 1e-9)."""
+    from vireo_amd import _lib
+    from vireo_amd.counts import DeviceCounts
+    from vireo_amd.engine import DeviceBatch, DeviceModel
+    monkeypatch.setenv("VIREO_LDS", "1" if lds else "0")     # read when the problem is built
+    AD, DP = O.synth_donor(1500, 900, K, 0.04, seed=K + R)
+    counts = DeviceCounts(AD, DP)
+    N, M = AD.shape
+    singles = _independent_fits(va, counts, N, M, K, R, seed=4, min_iter=5, max_iter=30,
+                                delay_fit_theta=2)
+    np.random.seed(4)
+    db = DeviceBatch(counts, _lib.KIND_VIREO, K, R)
+    singles[0]._set_device_prior(db)
+    info = db.info()
+    assert info["lds_variant"] == lds and info["lds_cell"] == lds
+    mu, sm = np.linspace(0.01, 0.99, 3)[None, :], np.full((1, 3), 50.0)
+    for r in range(R):
+        db.set_restart(r, np.random.rand(M, K), np.random.rand(N, K, 3), mu, sm, raw=True)
+    traces, its, flags = db.fit(30, 5, 1e-2, 2)
+    one = DeviceModel(counts, _lib.KIND_VIREO, K)
+    assert len({len(m.ELBO_) for m in singles}) > 1 or R < 3     # restarts stop at different times
+    for r, m in enumerate(singles):
+        elbo = traces[r][:its[r]] + counts.binom_const()
+        db.copy_to(one, r)
+        ID, GT, bmu, bsm = one.get_state()
+        if lds:
+            assert np.array_equal(elbo, m.ELBO_), r
+            assert np.array_equal(ID, m.ID_prob) and np.array_equal(GT, m.GT_prob)
+            assert np.array_equal(bmu, m.beta_mu) and np.array_equal(bsm, m.beta_sum)
+        else:
+            assert len(elbo) == len(m.ELBO_)
+            close(elbo, m.ELBO_, rtol=1e-9)
+            close(ID, m.ID_prob, rtol=1e-6, atol=1e-12)
+            close(bmu, m.beta_mu, rtol=1e-9)
+
+
+@pytest.mark.parametrize("batch", [2, 3, 4])
+def test_wrap_with_restart_batches(va, monkeypatch, capsys, batch):
+    """vireo_wrap with its restarts fitted `batch` at a time reproduces the reference's run
+    (golden c1_wrap_seed2_init4) and the one-at-a-time run"""
+    import sys
+    wrap_mod = sys.modules["vireo_amd.vireo_wrap"]       # (the package re-exports the function)
+    AD, DP = gold.c1()
+    g = gold.load("c1_wrap_seed2_init4")
+    res = {}
+    for b in (1, batch):
+        monkeypatch.setenv("VIREO_RESTART_BATCH", str(b))
+        res[b] = va.vireo_wrap(AD, DP, n_donor=4, n_init=4, random_seed=2)
+        assert wrap_mod.LAST_SEARCH["batch"] == b
+    capsys.readouterr()
+    close(res[batch]["LB_list"], g["LB_list"], rtol=1e-9)
+    close(res[batch]["ID_prob"], g["ID_prob"])
+    close(res[batch]["LB_list"], res[1]["LB_list"], rtol=1e-9)
+    close(res[batch]["ID_prob"], res[1]["ID_prob"], rtol=1e-6, atol=1e-12)
+    assert np.array_equal(np.argmax(res[batch]["ID_prob"], 1), np.argmax(res[1]["ID_prob"], 1))

@@ -26,7 +26,7 @@ class ModelCfg(C.Structure):
     _fields_ = [("kind", C.c_int32), ("n_donor", C.c_int32), ("n_gt", C.c_int32),
                 ("learn_gt", C.c_int32), ("learn_theta", C.c_int32),
                 ("ase_mode", C.c_int32), ("fix_beta_sum", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("n_batch", C.c_int32)]
 
 
 _P = C.c_void_p
@@ -51,6 +51,8 @@ SIGNATURES = {
     "vrx_model_get_state": (C.c_int, [_P, _D, _D, _D, _D]),
     "vrx_model_set_state_raw": (C.c_int, [_P, _D, _D, _D, _D]),
     "vrx_model_snapshot": (C.c_int, [_P, C.c_int32]),
+    "vrx_model_set_restart": (C.c_int, [_P, C.c_int32, _D, _D, _D, _D, C.c_int32]),
+    "vrx_model_copy_restart": (C.c_int, [_P, _P, C.c_int32]),
     "vrx_model_set_prior": (C.c_int, [_P, _D, C.c_int64, _D, C.c_int64, _D, _D, C.c_int64]),
     "vrx_model_fit": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_double, C.c_int32, _D, _I32, _I32]),
     "vrx_model_step": (C.c_int, [_P, C.c_int32, _D]),

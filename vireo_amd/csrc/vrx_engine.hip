@@ -1031,7 +1031,9 @@ struct vrx_model {
     vrx_problem* p = nullptr;
     vrx_model_cfg cfg{};
     int K = 0, T = 0, KP = 0;
-    int64_t N = 0, M = 0, NK = 0;
+    int R = 1, Kt = 0;  // restarts in the batch; R * K columns of the dense operands
+    int64_t N = 0, M = 0, NK = 0, NKt = 0;
+    VrxBatch batch() const { return VrxBatch{R, K, Kt}; }
     int64_t th_rows = 1, th_cols = 0;  // shape of beta_mu / beta_sum
     // variational state
     DevBuf<double> ID, GT, mu, sm;
@@ -1043,7 +1045,7 @@ struct vrx_model {
     DevBuf<double> PV, PC;  // split-row partial slots
     DevBuf<double> RV, RC;  // per-range partials of the LDS-resident passes
     // priors
-    DevBuf<double> logq_id, logq_gt, prior1, prior2, tmp;
+    DevBuf<double> logq_id, logq_gt, prior1, prior2, tmp, tmp2;
     int id_mode = 0, gt_mode = 0;
     int64_t prior_rows = 1;
     // reductions
@@ -1133,6 +1135,10 @@ extern "C" int vrx_model_create(vrx_problem* p, const vrx_model_cfg* cfg, vrx_mo
     m->N = p->n_var;
     m->M = p->n_cell;
     m->NK = m->N * m->K;
+    m->R = std::max(1, (int)cfg->n_batch);
+    VRX_REQUIRE(m->R <= 16, "vrx_model_create: at most 16 restarts per batch");
+    m->Kt = m->R * m->K;
+    m->NKt = m->NK * m->R;
     VRX_REQUIRE(m->NK < INT32_MAX * (int64_t)VRX_BLOCK, "vrx_model_create: n_var*n_donor too large");
     if (cfg->kind == VRX_KIND_VIREO) {
         m->th_rows = cfg->ase_mode ? m->N : 1;
@@ -1142,50 +1148,50 @@ extern "C" int vrx_model_create(vrx_problem* p, const vrx_model_cfg* cfg, vrx_mo
         m->th_cols = m->K;
     }
     hipStream_t s = p->stream;
-    const size_t th = (size_t)(m->th_rows * m->th_cols);
-    VRX_HIP(m->ID.alloc((size_t)(m->M * m->K)));
-    VRX_HIP(m->LID.alloc((size_t)(m->M * m->K)));
-    VRX_HIP(m->mu.alloc(th));
-    VRX_HIP(m->sm.alloc(th));
+    const size_t th = (size_t)(m->R * m->th_rows * m->th_cols);
+    VRX_HIP(m->ID.alloc((size_t)(m->M * m->Kt)));
+    VRX_HIP(m->LID.alloc((size_t)(m->M * m->Kt)));
+    VRX_HIP(m->mu.alloc(th * m->R));
+    VRX_HIP(m->sm.alloc(th * m->R));
     VRX_HIP(m->prior1.alloc(th));
     VRX_HIP(m->prior2.alloc(th));
-    VRX_HIP(m->S.alloc((size_t)m->NK * 2));
-    VRX_HIP(m->W.alloc((size_t)m->NK * 2));
-    VRX_HIP(m->PV.alloc((size_t)(p->by_var.n_slots * m->K * 2)));
-    VRX_HIP(m->PC.alloc((size_t)(p->by_cell.n_slots * m->K)));
+    VRX_HIP(m->S.alloc((size_t)m->NKt * 2));
+    VRX_HIP(m->W.alloc((size_t)m->NKt * 2));
+    VRX_HIP(m->PV.alloc((size_t)(p->by_var.n_slots * m->Kt * 2)));
+    VRX_HIP(m->PC.alloc((size_t)(p->by_cell.n_slots * m->Kt)));
     {
         const TiledStream &tv = p->by_var.tiled, &tc = p->by_cell.tiled;
-        if (lds_eligible<0>(p->by_var, m->K) && (tv.n_range > 1 || tv.split))
-            VRX_HIP(m->RV.alloc((size_t)(tv.n_range * tv.n_vrows * m->K * 2)));
-        if (lds_eligible<1>(p->by_cell, m->K) && (tc.n_range > 1 || tc.split))
-            VRX_HIP(m->RC.alloc((size_t)(tc.n_range * tc.n_vrows * m->K)));
+        if (lds_eligible<0>(p->by_var, m->Kt) && (tv.n_range > 1 || tv.split))
+            VRX_HIP(m->RV.alloc((size_t)(tv.n_range * tv.n_vrows * m->Kt * 2)));
+        if (lds_eligible<1>(p->by_cell, m->Kt) && (tc.n_range > 1 || tc.split))
+            VRX_HIP(m->RC.alloc((size_t)(tc.n_range * tc.n_vrows * m->Kt)));
     }
-    m->wform = lds_eligible<1>(p->by_cell, m->K) && p->by_cell.tiled.form == 1 ? 1 : 0;
+    m->wform = lds_eligible<1>(p->by_cell, m->Kt) && p->by_cell.tiled.form == 1 ? 1 : 0;
     // rows without entries are never written by the passes: zero once
-    VRX_HIP(hipMemsetAsync(m->S.p, 0, (size_t)m->NK * 2 * sizeof(double), s));
-    VRX_HIP(hipMemsetAsync(m->LID.p, 0, (size_t)(m->M * m->K) * sizeof(double), s));
-    VRX_HIP(hipMemsetAsync(m->ID.p, 0, (size_t)(m->M * m->K) * sizeof(double), s));
+    VRX_HIP(hipMemsetAsync(m->S.p, 0, (size_t)m->NKt * 2 * sizeof(double), s));
+    VRX_HIP(hipMemsetAsync(m->LID.p, 0, (size_t)(m->M * m->Kt) * sizeof(double), s));
+    VRX_HIP(hipMemsetAsync(m->ID.p, 0, (size_t)(m->M * m->Kt) * sizeof(double), s));
     m->nb_nk = (int)((m->NK + VRX_BLOCK - 1) / VRX_BLOCK);
     m->nb_cell = (int)((m->M * m->KP + VRX_BLOCK - 1) / VRX_BLOCK);
     m->nb_throws = (int)((m->N + VRX_BLOCK - 1) / VRX_BLOCK);
     m->nb_theta = std::min(m->nb_nk, p->n_cu * 4);
-    VRX_HIP(m->part_cell.alloc((size_t)m->nb_cell * 2));
-    VRX_HIP(m->part_gt.alloc((size_t)m->nb_nk));
-    VRX_HIP(hipMemsetAsync(m->part_gt.p, 0, (size_t)m->nb_nk * sizeof(double), s));
+    VRX_HIP(m->part_cell.alloc((size_t)m->R * m->nb_cell * 2));
+    VRX_HIP(m->part_gt.alloc((size_t)m->R * m->nb_nk));
+    VRX_HIP(hipMemsetAsync(m->part_gt.p, 0, (size_t)m->R * m->nb_nk * sizeof(double), s));
     if (cfg->kind == VRX_KIND_VIREO) {
-        VRX_HIP(m->GT.alloc((size_t)m->NK * m->T));
-        VRX_HIP(m->psi.alloc(3 * th));
-        VRX_HIP(m->part_theta.alloc((size_t)m->nb_theta * 2 * VRX_MAXT));
+        VRX_HIP(m->GT.alloc((size_t)m->NKt * m->T));
+        VRX_HIP(m->psi.alloc(3 * th * m->R));
+        VRX_HIP(m->part_theta.alloc((size_t)m->R * m->nb_theta * 2 * VRX_MAXT));
         m->n_th_part = cfg->ase_mode ? m->nb_throws : 1;
     } else {
         m->n_th_part = m->nb_nk;
     }
-    VRX_HIP(m->part_th.alloc((size_t)m->n_th_part));
-    VRX_HIP(hipMemsetAsync(m->part_th.p, 0, (size_t)m->n_th_part * sizeof(double), s));
-    VRX_HIP(m->d_elbo.alloc(kMaxTrace));
-    VRX_HIP(m->ctl.alloc(VRX_CTL_WORDS));
-    VRX_HIP(hipMemsetAsync(m->ctl.p, 0, VRX_CTL_WORDS * sizeof(int32_t), s));
-    VRX_HIP(m->d_parts.alloc(4));
+    VRX_HIP(m->part_th.alloc((size_t)m->R * m->n_th_part));
+    VRX_HIP(hipMemsetAsync(m->part_th.p, 0, (size_t)m->R * m->n_th_part * sizeof(double), s));
+    VRX_HIP(m->d_elbo.alloc((size_t)m->R * kMaxTrace));
+    VRX_HIP(m->ctl.alloc((size_t)m->R * VRX_CTL_WORDS));
+    VRX_HIP(hipMemsetAsync(m->ctl.p, 0, (size_t)m->R * VRX_CTL_WORDS * sizeof(int32_t), s));
+    VRX_HIP(m->d_parts.alloc((size_t)m->R * 4));
     VRX_HIP(hipHostMalloc(reinterpret_cast<void**>(&m->h_pin), 64 * sizeof(double), hipHostMallocDefault));
     VRX_HIP(hipEventCreate(&m->t0));
     VRX_HIP(hipEventCreate(&m->t1));
@@ -1219,11 +1225,11 @@ extern "C" int vrx_model_set_state(vrx_model* m, const double* ID_prob, const do
     VRX_REQUIRE(m, "vrx_model_set_state: null model");
     VRX_HIP(hipSetDevice(m->p->device));
     int rc;
-    if ((rc = h2d(m, m->ID, ID_prob, (size_t)(m->M * m->K)))) return rc;
+    if ((rc = h2d(m, m->ID, ID_prob, (size_t)(m->M * m->Kt)))) return rc;
     if (m->cfg.kind == VRX_KIND_VIREO)
-        if ((rc = h2d(m, m->GT, GT_prob, (size_t)m->NK * m->T))) return rc;
-    if ((rc = h2d(m, m->mu, beta_mu, (size_t)(m->th_rows * m->th_cols)))) return rc;
-    if ((rc = h2d(m, m->sm, beta_sum, (size_t)(m->th_rows * m->th_cols)))) return rc;
+        if ((rc = h2d(m, m->GT, GT_prob, (size_t)m->NKt * m->T))) return rc;
+    if ((rc = h2d(m, m->mu, beta_mu, (size_t)(m->R * m->th_rows * m->th_cols)))) return rc;
+    if ((rc = h2d(m, m->sm, beta_sum, (size_t)(m->R * m->th_rows * m->th_cols)))) return rc;
     VRX_HIP(hipStreamSynchronize(m->p->stream));
     m->w_valid = false;
     return VRX_OK;
@@ -1239,20 +1245,21 @@ extern "C" int vrx_model_set_state_raw(vrx_model* m, const double* ID_raw, const
     VRX_HIP(hipSetDevice(m->p->device));
     hipStream_t s = m->p->stream;
     int rc;
-    if ((rc = h2d(m, m->ID, ID_raw, (size_t)(m->M * m->K)))) return rc;
+    if ((rc = h2d(m, m->ID, ID_raw, (size_t)(m->M * m->Kt)))) return rc;
     if (ID_raw) {
-        vrx_normalize_rows<<<(unsigned)((m->M + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
-            m->M, m->K, m->ID.p);
+        const int64_t rows = m->M * m->R;  // [M][R][K]: one row per (cell, restart)
+        vrx_normalize_rows<<<(unsigned)((rows + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
+            rows, m->K, m->ID.p);
         VRX_HIP(hipGetLastError());
     }
     if (m->cfg.kind == VRX_KIND_VIREO && GT_raw) {
-        if ((rc = h2d(m, m->GT, GT_raw, (size_t)m->NK * m->T))) return rc;
-        vrx_normalize_rows<<<(unsigned)((m->NK + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
-            m->NK, m->T, m->GT.p);
+        if ((rc = h2d(m, m->GT, GT_raw, (size_t)m->NKt * m->T))) return rc;
+        vrx_normalize_rows<<<(unsigned)((m->NKt + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
+            m->NKt, m->T, m->GT.p);
         VRX_HIP(hipGetLastError());
     }
-    if ((rc = h2d(m, m->mu, beta_mu, (size_t)(m->th_rows * m->th_cols)))) return rc;
-    if ((rc = h2d(m, m->sm, beta_sum, (size_t)(m->th_rows * m->th_cols)))) return rc;
+    if ((rc = h2d(m, m->mu, beta_mu, (size_t)(m->R * m->th_rows * m->th_cols)))) return rc;
+    if ((rc = h2d(m, m->sm, beta_sum, (size_t)(m->R * m->th_rows * m->th_cols)))) return rc;
     VRX_HIP(hipStreamSynchronize(s));
     m->w_valid = false;
     return VRX_OK;
@@ -1264,20 +1271,20 @@ extern "C" int vrx_model_snapshot(vrx_model* m, int32_t restore) {
     VRX_REQUIRE(m, "vrx_model_snapshot: null model");
     VRX_HIP(hipSetDevice(m->p->device));
     hipStream_t s = m->p->stream;
-    const size_t th = (size_t)(m->th_rows * m->th_cols);
+    const size_t th = (size_t)(m->R * m->th_rows * m->th_cols);
     if (restore) {
         VRX_REQUIRE(m->snap_valid, "vrx_model_snapshot: nothing saved");
     } else if (!m->snapID.p) {
-        VRX_HIP(m->snapID.alloc((size_t)(m->M * m->K)));
-        if (m->cfg.kind == VRX_KIND_VIREO) VRX_HIP(m->snapGT.alloc((size_t)m->NK * m->T));
+        VRX_HIP(m->snapID.alloc((size_t)(m->M * m->Kt)));
+        if (m->cfg.kind == VRX_KIND_VIREO) VRX_HIP(m->snapGT.alloc((size_t)m->NKt * m->T));
         VRX_HIP(m->snapTh.alloc(2 * th));
     }
     auto cp = [&](double* live, double* saved, size_t n) {
         return restore ? hipMemcpyAsync(live, saved, n * sizeof(double), hipMemcpyDeviceToDevice, s)
                        : hipMemcpyAsync(saved, live, n * sizeof(double), hipMemcpyDeviceToDevice, s);
     };
-    VRX_HIP(cp(m->ID.p, m->snapID.p, (size_t)(m->M * m->K)));
-    if (m->cfg.kind == VRX_KIND_VIREO) VRX_HIP(cp(m->GT.p, m->snapGT.p, (size_t)m->NK * m->T));
+    VRX_HIP(cp(m->ID.p, m->snapID.p, (size_t)(m->M * m->Kt)));
+    if (m->cfg.kind == VRX_KIND_VIREO) VRX_HIP(cp(m->GT.p, m->snapGT.p, (size_t)m->NKt * m->T));
     VRX_HIP(cp(m->mu.p, m->snapTh.p, th));
     VRX_HIP(cp(m->sm.p, m->snapTh.p + th, th));
     VRX_HIP(hipStreamSynchronize(s));
@@ -1288,16 +1295,109 @@ extern "C" int vrx_model_snapshot(vrx_model* m, int32_t restore) {
     return VRX_OK;
 }
 
+// ---- restart batches -------------------------------------------------------------------
+// rows x cols block between two row-major arrays with their own row strides and column offsets
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_copy_block(int64_t rows, int cols,
+                                                            const double* __restrict__ src,
+                                                            int64_t src_ld, int64_t src_off,
+                                                            double* __restrict__ dst, int64_t dst_ld,
+                                                            int64_t dst_off) {
+    const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int64_t r = i / cols, c = i - r * cols;
+    dst[r * dst_ld + dst_off + c] = src[r * src_ld + src_off + c];
+}
+
+static int copy_block(hipStream_t s, int64_t rows, int64_t cols, const double* src, int64_t src_ld,
+                      int64_t src_off, double* dst, int64_t dst_ld, int64_t dst_off) {
+    const int64_t n = rows * cols;
+    if (n == 0) return VRX_OK;
+    vrx_copy_block<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
+        rows, (int)cols, src, src_ld, src_off, dst, dst_ld, dst_off);
+    VRX_HIP(hipGetLastError());
+    return VRX_OK;
+}
+
+// Slot r of a batch model <- one restart's state, given exactly as vrx_model_set_state[_raw]
+// takes it for a single model (ID [M][K], GT [N][K][T], beta [rows][cols]).  raw: the draws are
+// row-normalised on the device first, in NumPy's order (vireo_model.py:99,104).
+extern "C" int vrx_model_set_restart(vrx_model* m, int32_t r, const double* ID, const double* GT,
+                                     const double* beta_mu, const double* beta_sum, int32_t raw) {
+    VRX_REQUIRE(m, "vrx_model_set_restart: null model");
+    VRX_REQUIRE(r >= 0 && r < m->R, "vrx_model_set_restart: slot %d outside the batch of %d", r, m->R);
+    if (raw && (m->K > 128 || m->T > 128)) {
+        vrx_set_error("vrx_model_set_restart: more than 128 columns (normalise on the host)");
+        return VRX_ERR_UNSUPPORTED;
+    }
+    VRX_HIP(hipSetDevice(m->p->device));
+    hipStream_t s = m->p->stream;
+    int rc;
+    const size_t n_id = (size_t)(m->M * m->K), n_gt = (size_t)m->NK * m->T;
+    const size_t th = (size_t)(m->th_rows * m->th_cols);
+    if (ID) {
+        if (m->tmp.n != n_id) VRX_HIP(m->tmp.alloc(n_id));
+        VRX_HIP(hipMemcpyAsync(m->tmp.p, ID, n_id * sizeof(double), hipMemcpyHostToDevice, s));
+        if (raw)
+            vrx_normalize_rows<<<(unsigned)((m->M + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
+                m->M, m->K, m->tmp.p);
+        if ((rc = copy_block(s, m->M, m->K, m->tmp.p, m->K, 0, m->ID.p, m->Kt, (int64_t)r * m->K)))
+            return rc;
+    }
+    if (GT && m->cfg.kind == VRX_KIND_VIREO) {
+        if (m->tmp2.n != n_gt) VRX_HIP(m->tmp2.alloc(n_gt));
+        VRX_HIP(hipMemcpyAsync(m->tmp2.p, GT, n_gt * sizeof(double), hipMemcpyHostToDevice, s));
+        if (raw)
+            vrx_normalize_rows<<<(unsigned)((m->NK + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
+                m->NK, m->T, m->tmp2.p);
+        const int64_t kt = (int64_t)m->K * m->T;
+        if ((rc = copy_block(s, m->N, kt, m->tmp2.p, kt, 0, m->GT.p, (int64_t)m->Kt * m->T, r * kt)))
+            return rc;
+    }
+    if (beta_mu)
+        VRX_HIP(hipMemcpyAsync(m->mu.p + r * th, beta_mu, th * sizeof(double), hipMemcpyHostToDevice, s));
+    if (beta_sum)
+        VRX_HIP(hipMemcpyAsync(m->sm.p + r * th, beta_sum, th * sizeof(double), hipMemcpyHostToDevice, s));
+    VRX_HIP(hipStreamSynchronize(s));  // (the host arrays may be reused by the caller)
+    m->w_valid = false;
+    return VRX_OK;
+}
+
+// dst (a single model of the same problem and shape) <- the state of slot r of `src`, on the
+// device: the winner of a batch moves on without a host round trip (vireo_wrap.py:90-91)
+extern "C" int vrx_model_copy_restart(vrx_model* dst, vrx_model* src, int32_t r) {
+    VRX_REQUIRE(dst && src, "vrx_model_copy_restart: null model");
+    VRX_REQUIRE(r >= 0 && r < src->R, "vrx_model_copy_restart: slot %d outside the batch of %d", r, src->R);
+    VRX_REQUIRE(dst->R == 1 && dst->p == src->p && dst->K == src->K && dst->T == src->T &&
+                    dst->cfg.kind == src->cfg.kind && dst->th_rows == src->th_rows,
+                "vrx_model_copy_restart: models differ in problem or shape");
+    VRX_HIP(hipSetDevice(src->p->device));
+    hipStream_t s = src->p->stream;
+    int rc;
+    if ((rc = copy_block(s, src->M, src->K, src->ID.p, src->Kt, (int64_t)r * src->K, dst->ID.p, src->K, 0)))
+        return rc;
+    if (src->cfg.kind == VRX_KIND_VIREO) {
+        const int64_t kt = (int64_t)src->K * src->T;
+        if ((rc = copy_block(s, src->N, kt, src->GT.p, (int64_t)src->Kt * src->T, r * kt, dst->GT.p, kt, 0)))
+            return rc;
+    }
+    const size_t th = (size_t)(src->th_rows * src->th_cols);
+    VRX_HIP(hipMemcpyAsync(dst->mu.p, src->mu.p + r * th, th * sizeof(double), hipMemcpyDeviceToDevice, s));
+    VRX_HIP(hipMemcpyAsync(dst->sm.p, src->sm.p + r * th, th * sizeof(double), hipMemcpyDeviceToDevice, s));
+    VRX_HIP(hipStreamSynchronize(s));
+    dst->w_valid = false;
+    return VRX_OK;
+}
+
 extern "C" int vrx_model_get_state(vrx_model* m, double* ID_prob, double* GT_prob, double* beta_mu,
                                    double* beta_sum) {
     VRX_REQUIRE(m, "vrx_model_get_state: null model");
     VRX_HIP(hipSetDevice(m->p->device));
     int rc;
-    if ((rc = d2h(m, ID_prob, m->ID, (size_t)(m->M * m->K)))) return rc;
+    if ((rc = d2h(m, ID_prob, m->ID, (size_t)(m->M * m->Kt)))) return rc;
     if (m->cfg.kind == VRX_KIND_VIREO)
-        if ((rc = d2h(m, GT_prob, m->GT, (size_t)m->NK * m->T))) return rc;
-    if ((rc = d2h(m, beta_mu, m->mu, (size_t)(m->th_rows * m->th_cols)))) return rc;
-    if ((rc = d2h(m, beta_sum, m->sm, (size_t)(m->th_rows * m->th_cols)))) return rc;
+        if ((rc = d2h(m, GT_prob, m->GT, (size_t)m->NKt * m->T))) return rc;
+    if ((rc = d2h(m, beta_mu, m->mu, (size_t)(m->R * m->th_rows * m->th_cols)))) return rc;
+    if ((rc = d2h(m, beta_sum, m->sm, (size_t)(m->R * m->th_rows * m->th_cols)))) return rc;
     VRX_HIP(hipStreamSynchronize(m->p->stream));
     return VRX_OK;
 }
@@ -1305,7 +1405,7 @@ extern "C" int vrx_model_get_state(vrx_model* m, double* ID_prob, double* GT_pro
 extern "C" int vrx_model_get_loglik(vrx_model* m, double* out) {
     VRX_REQUIRE(m && out, "vrx_model_get_loglik: null argument");
     VRX_HIP(hipSetDevice(m->p->device));
-    int rc = d2h(m, out, m->LID, (size_t)(m->M * m->K));
+    int rc = d2h(m, out, m->LID, (size_t)(m->M * m->Kt));
     if (rc) return rc;
     VRX_HIP(hipStreamSynchronize(m->p->stream));
     return VRX_OK;
@@ -1314,7 +1414,7 @@ extern "C" int vrx_model_get_loglik(vrx_model* m, double* out) {
 extern "C" int vrx_model_set_loglik(vrx_model* m, const double* in) {
     VRX_REQUIRE(m && in, "vrx_model_set_loglik: null argument");
     VRX_HIP(hipSetDevice(m->p->device));
-    int rc = h2d(m, m->LID, in, (size_t)(m->M * m->K));
+    int rc = h2d(m, m->LID, in, (size_t)(m->M * m->Kt));
     if (rc) return rc;
     VRX_HIP(hipStreamSynchronize(m->p->stream));
     return VRX_OK;
@@ -1323,7 +1423,7 @@ extern "C" int vrx_model_set_loglik(vrx_model* m, const double* in) {
 extern "C" int vrx_model_get_elbo_parts(vrx_model* m, double* parts4) {
     VRX_REQUIRE(m && parts4, "vrx_model_get_elbo_parts: null argument");
     VRX_HIP(hipSetDevice(m->p->device));
-    VRX_HIP(hipMemcpyAsync(parts4, m->d_parts.p, 4 * sizeof(double), hipMemcpyDeviceToHost,
+    VRX_HIP(hipMemcpyAsync(parts4, m->d_parts.p, (size_t)m->R * 4 * sizeof(double), hipMemcpyDeviceToHost,
                            m->p->stream));
     VRX_HIP(hipStreamSynchronize(m->p->stream));
     return VRX_OK;
@@ -1390,11 +1490,11 @@ extern "C" int vrx_model_set_prior(vrx_model* m, const double* ID_prior, int64_t
 // ------------------------------------------------------------------------------------
 template <int LPE, int CPL, int MODE>
 static void launch_spmm_fmt(const Orient& o, dim3 grid, hipStream_t s, const double* X, int K,
-                            double* out, double* partial, const int32_t* ctl) {
+                            double* out, double* partial, const int32_t* ctl, int R) {
 #define VRX_GO(F)                                                                              \
     vrx_spmm<LPE, CPL, MODE, F><<<grid, VRX_BLOCK, 0, s>>>(o.n_seg, o.seg_begin.p, o.seg_len.p, \
                                                            o.seg_dst.p, o.ent.p, X, K, out,    \
-                                                           partial, ctl)
+                                                           partial, ctl, R)
     if (o.fmt == VRX_FMT_P32)
         VRX_GO(VRX_FMT_P32);
     else if (o.fmt == VRX_FMT_P64)
@@ -1458,7 +1558,7 @@ static auto lds_kernel(int K, bool strided, int rw, int form) {
 
 template <int LPE, int MODE>
 static int launch_lds_one(const Orient& o, hipStream_t s, const double* X, int K, double* dst,
-                          const int32_t* ctl) {
+                          const int32_t* ctl, int R) {
     const TiledStream& t = o.tiled;
     constexpr int XD = MODE == 1 ? 2 : 1, NV = MODE == 0 ? 2 : 1;
     dim3 grid((unsigned)t.n_tile, (unsigned)t.n_range);
@@ -1476,7 +1576,7 @@ static int launch_lds_one(const Orient& o, hipStream_t s, const double* X, int K
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         kern<<<grid, 1024, lds, s>>>(t.ent.p, t.wave_start.p, t.bnd.p, t.rowmap.p, t.n_slab,
                                      t.slab_rows, o.n_contract, t.n_vrows,
-                                     X + (size_t)c0 * (f1 ? 1 : XD), kb, K, dst + (size_t)c0 * NV, ctl);
+                                     X + (size_t)c0 * (f1 ? 1 : XD), kb, K, dst + (size_t)c0 * NV, ctl, R);
         VRX_HIP(hipGetLastError());
     }
     return VRX_OK;
@@ -1490,21 +1590,21 @@ static int launch_spmm_lds(vrx_model* m, const Orient& o, const double* X, int K
     constexpr int NV = MODE == 0 ? 2 : 1;
     double* dst = t.n_range == 1 && !t.split ? out : range_partial;
     int rc;
-    rc = launch_lds_one<VRX_LDS_LPE, MODE>(o, s, X, K, dst, m->ctl.p);  // K < 16 leaves lanes idle
+    rc = launch_lds_one<VRX_LDS_LPE, MODE>(o, s, X, K, dst, m->ctl.p, m->R);  // K < 16 leaves lanes idle
     if (rc) return rc;
     if (t.split) {  // rows cut into pieces: sum pieces and ranges in one fixed order
         const int64_t n = o.n_rows * K * NV;
         if ((int64_t)t.n_range * t.n_vrows >= 64 * o.n_rows)  // >= 64 terms per row on average
             vrx_sum_pieces_wave<<<(unsigned)((n * 64 + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
-                o.n_rows, K * NV, t.n_range, t.n_vrows, t.vptr.p, range_partial, out, m->ctl.p);
+                o.n_rows, K * NV, t.n_range, t.n_vrows, t.vptr.p, range_partial, out, m->ctl.p, m->R);
         else
             vrx_sum_pieces<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
-                o.n_rows, K * NV, t.n_range, t.n_vrows, t.vptr.p, range_partial, out, m->ctl.p);
+                o.n_rows, K * NV, t.n_range, t.n_vrows, t.vptr.p, range_partial, out, m->ctl.p, m->R);
         VRX_HIP(hipGetLastError());
     } else if (t.n_range > 1 && !defer_sum) {
         const int64_t n = o.n_rows * K * NV;
         vrx_sum_ranges<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
-            n, t.n_range, range_partial, out, m->ctl.p);
+            n, t.n_range, range_partial, out, m->ctl.p, m->R);
         VRX_HIP(hipGetLastError());
     }
     return VRX_OK;
@@ -1523,19 +1623,19 @@ static int launch_spmm(vrx_model* m, const Orient& o, const double* X, int K, do
     if (cpl == 2) {
         if (MODE == 0) {  // (guard keeps the CPL=2 cell-pass templates from being instantiated)
             switch (lpe) {
-                case 1: launch_spmm_fmt<1, 2, 0>(o, grid, s, X, K, out, partial, m->ctl.p); break;
-                case 2: launch_spmm_fmt<2, 2, 0>(o, grid, s, X, K, out, partial, m->ctl.p); break;
-                case 4: launch_spmm_fmt<4, 2, 0>(o, grid, s, X, K, out, partial, m->ctl.p); break;
-                default: launch_spmm_fmt<8, 2, 0>(o, grid, s, X, K, out, partial, m->ctl.p); break;
+                case 1: launch_spmm_fmt<1, 2, 0>(o, grid, s, X, K, out, partial, m->ctl.p, m->R); break;
+                case 2: launch_spmm_fmt<2, 2, 0>(o, grid, s, X, K, out, partial, m->ctl.p, m->R); break;
+                case 4: launch_spmm_fmt<4, 2, 0>(o, grid, s, X, K, out, partial, m->ctl.p, m->R); break;
+                default: launch_spmm_fmt<8, 2, 0>(o, grid, s, X, K, out, partial, m->ctl.p, m->R); break;
             }
         }
     } else {
         switch (lpe) {
-            case 1: launch_spmm_fmt<1, 1, MODE>(o, grid, s, X, K, out, partial, m->ctl.p); break;
-            case 2: launch_spmm_fmt<2, 1, MODE>(o, grid, s, X, K, out, partial, m->ctl.p); break;
-            case 4: launch_spmm_fmt<4, 1, MODE>(o, grid, s, X, K, out, partial, m->ctl.p); break;
-            case 8: launch_spmm_fmt<8, 1, MODE>(o, grid, s, X, K, out, partial, m->ctl.p); break;
-            default: launch_spmm_fmt<16, 1, MODE>(o, grid, s, X, K, out, partial, m->ctl.p); break;
+            case 1: launch_spmm_fmt<1, 1, MODE>(o, grid, s, X, K, out, partial, m->ctl.p, m->R); break;
+            case 2: launch_spmm_fmt<2, 1, MODE>(o, grid, s, X, K, out, partial, m->ctl.p, m->R); break;
+            case 4: launch_spmm_fmt<4, 1, MODE>(o, grid, s, X, K, out, partial, m->ctl.p, m->R); break;
+            case 8: launch_spmm_fmt<8, 1, MODE>(o, grid, s, X, K, out, partial, m->ctl.p, m->R); break;
+            default: launch_spmm_fmt<16, 1, MODE>(o, grid, s, X, K, out, partial, m->ctl.p, m->R); break;
         }
     }
     VRX_HIP(hipGetLastError());
@@ -1543,7 +1643,7 @@ static int launch_spmm(vrx_model* m, const Orient& o, const double* X, int K, do
         constexpr int VPE = MODE == 0 ? 2 : 1;
         const int64_t tot = o.n_multi * K * VPE;
         vrx_sum_slots<VPE><<<(unsigned)((tot + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
-            o.n_multi, K, o.multi_row.p, o.multi_ptr.p, partial, out, m->ctl.p);
+            o.n_multi, K, o.multi_row.p, o.multi_ptr.p, partial, out, m->ctl.p, m->R);
         VRX_HIP(hipGetLastError());
     }
     return VRX_OK;
@@ -1552,29 +1652,29 @@ static int launch_spmm(vrx_model* m, const Orient& o, const double* X, int K, do
 // S <- (AD @ ID_prob, DP @ ID_prob)        vireo_model.py:169-170,207-208; bmm_model.py:137-138
 static int variant_pass(vrx_model* m, bool defer_sum = false) {
     ProfScope ps(m, VRX_KERN_VARIANT_PASS);
-    if (lds_eligible<0>(m->p->by_var, m->K)) {
+    if (lds_eligible<0>(m->p->by_var, m->Kt)) {
         m->s_pending = defer_sum && m->p->by_var.tiled.n_range > 1 && !m->p->by_var.tiled.split;
-        return launch_spmm_lds<0>(m, m->p->by_var, m->ID.p, m->K, m->S.p, m->RV.p, defer_sum);
+        return launch_spmm_lds<0>(m, m->p->by_var, m->ID.p, m->Kt, m->S.p, m->RV.p, defer_sum);
     }
-    return launch_spmm<0>(m, m->p->by_var, m->ID.p, m->K, m->S.p, m->PV.p);
+    return launch_spmm<0>(m, m->p->by_var, m->ID.p, m->Kt, m->S.p, m->PV.p);
 }
 
 // LID <- AD^T W1 + DP^T W2                 vireo_model.py:190-196; bmm_model.py:125-129
 static int cell_pass(vrx_model* m, bool defer_sum = false) {
     ProfScope ps(m, VRX_KERN_CELL_PASS);
-    if (lds_eligible<1>(m->p->by_cell, m->K)) {
+    if (lds_eligible<1>(m->p->by_cell, m->Kt)) {
         m->l_pending = defer_sum && m->p->by_cell.tiled.n_range > 1 && !m->p->by_cell.tiled.split;
-        return launch_spmm_lds<1>(m, m->p->by_cell, m->W.p, m->K, m->LID.p, m->RC.p, defer_sum);
+        return launch_spmm_lds<1>(m, m->p->by_cell, m->W.p, m->Kt, m->LID.p, m->RC.p, defer_sum);
     }
-    return launch_spmm<1>(m, m->p->by_cell, m->W.p, m->K, m->LID.p, m->PC.p);
+    return launch_spmm<1>(m, m->p->by_cell, m->W.p, m->Kt, m->LID.p, m->PC.p);
 }
 
 // a consumer that cannot fuse the range sum forms S / logLik_ID explicitly
 static int resolve_S(vrx_model* m) {
     if (!m->s_pending) return VRX_OK;
-    const int64_t n = m->NK * 2;
+    const int64_t n = m->NKt * 2;
     vrx_sum_ranges<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, m->p->stream>>>(
-        n, m->p->by_var.tiled.n_range, m->RV.p, m->S.p, m->ctl.p);
+        n, m->p->by_var.tiled.n_range, m->RV.p, m->S.p, m->ctl.p, m->R);
     VRX_HIP(hipGetLastError());
     m->s_pending = false;
     return VRX_OK;
@@ -1582,9 +1682,9 @@ static int resolve_S(vrx_model* m) {
 
 static int resolve_LID(vrx_model* m) {
     if (!m->l_pending) return VRX_OK;
-    const int64_t n = m->M * m->K;
+    const int64_t n = m->M * m->Kt;
     vrx_sum_ranges<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, m->p->stream>>>(
-        n, m->p->by_cell.tiled.n_range, m->RC.p, m->LID.p, m->ctl.p);
+        n, m->p->by_cell.tiled.n_range, m->RC.p, m->LID.p, m->ctl.p, m->R);
     VRX_HIP(hipGetLastError());
     m->l_pending = false;
     return VRX_OK;
@@ -1600,27 +1700,28 @@ static int theta_step(vrx_model* m, int update) {
         if (rc) return rc;
     }
     if (c.kind == VRX_KIND_BMM) {
-        vrx_bmm_theta<<<m->nb_nk, VRX_BLOCK, 0, s>>>(
+        vrx_bmm_theta<<<dim3(m->nb_nk, m->R), VRX_BLOCK, 0, s>>>(
             m->NK, update, c.fix_beta_sum, reinterpret_cast<const double2*>(m->S.p), m->prior1.p,
             m->prior2.p, m->prior_rows == 1 ? 0 : 1, m->mu.p, m->sm.p, m->W.p, m->K, m->wform,
-            m->part_th.p, m->ctl.p);
+            m->part_th.p, m->batch(), m->ctl.p);
         m->w_valid = true;
     } else if (c.ase_mode) {
-        vrx_theta_ase<<<m->nb_throws, VRX_BLOCK, 0, s>>>(
+        vrx_theta_ase<<<dim3(m->nb_throws, m->R), VRX_BLOCK, 0, s>>>(
             m->N, m->K, m->T, update, c.fix_beta_sum, reinterpret_cast<const double2*>(m->S.p),
             m->GT.p, m->prior1.p, m->prior2.p, (int)m->prior_rows, m->mu.p, m->sm.p, m->psi.p,
-            m->part_th.p, m->ctl.p);
+            m->part_th.p, m->batch(), m->ctl.p);
         m->w_valid = false;
     } else {
         if (update) {
             const int nr = m->s_pending ? m->p->by_var.tiled.n_range : 0;
-            vrx_theta_partial<<<m->nb_theta, VRX_BLOCK, 0, s>>>(
+            vrx_theta_partial<<<dim3(m->nb_theta, m->R), VRX_BLOCK, 0, s>>>(
                 m->NK, m->T, reinterpret_cast<double2*>(m->S.p), nr,
-                reinterpret_cast<const double2*>(m->RV.p), m->GT.p, m->part_theta.p, m->ctl.p);
+                reinterpret_cast<const double2*>(m->RV.p), m->GT.p, m->part_theta.p, m->batch(),
+                m->ctl.p);
             VRX_HIP(hipGetLastError());
             m->s_pending = false;
         }
-        vrx_theta_final<<<1, VRX_BLOCK, 0, s>>>(m->nb_theta, m->T, update, c.fix_beta_sum,
+        vrx_theta_final<<<m->R, VRX_BLOCK, 0, s>>>(m->nb_theta, m->T, update, c.fix_beta_sum,
                                                  m->part_theta.p, m->prior1.p, m->prior2.p, m->mu.p,
                                                  m->sm.p, m->psi.p, m->part_th.p, m->ctl.p);
         m->w_valid = false;
@@ -1636,10 +1737,10 @@ static int gt_step(vrx_model* m, int learn) {
         int rc = resolve_S(m);
         if (rc) return rc;
     }
-    vrx_gt_update<<<m->nb_nk, VRX_BLOCK, 0, m->p->stream>>>(
+    vrx_gt_update<<<dim3(m->nb_nk, m->R), VRX_BLOCK, 0, m->p->stream>>>(
         m->NK, m->K, m->T, learn, m->cfg.ase_mode, m->N, reinterpret_cast<const double2*>(m->S.p),
         m->psi.p, m->logq_gt.p, m->gt_mode, -std::log((double)m->T), m->GT.p, m->W.p, m->wform,
-        m->part_gt.p, m->ctl.p);
+        m->part_gt.p, m->batch(), m->ctl.p);
     VRX_HIP(hipGetLastError());
     m->w_valid = true;
     return VRX_OK;
@@ -1655,6 +1756,7 @@ static VrxElboIn elbo_inputs(vrx_model* m) {
     e.n_th_part = m->n_th_part;
     e.elbo = m->d_elbo.p;
     e.parts = m->d_parts.p;
+    e.trace_stride = kMaxTrace;
     return e;
 }
 
@@ -1674,9 +1776,9 @@ static int softmax_step(vrx_model* m, int update) {
     m->l_pending = false;
 #define VRX_SM_CASE(KPV)                                                                        \
     case KPV:                                                                                   \
-        vrx_cell_softmax<KPV><<<m->nb_cell, VRX_BLOCK, 0, s>>>(                                 \
+        vrx_cell_softmax<KPV><<<dim3(m->nb_cell, m->R), VRX_BLOCK, 0, s>>>(                     \
             m->M, m->K, update, m->LID.p, nr, m->RC.p, m->logq_id.p, m->id_mode, lu, m->ID.p,   \
-            m->part_cell.p, m->ctl.p);                                                          \
+            m->part_cell.p, m->batch(), m->ctl.p);                                              \
         break;
     switch (m->KP) {
         VRX_SM_CASE(1)
@@ -1695,7 +1797,7 @@ static int softmax_step(vrx_model* m, int update) {
 // ELBO of iteration rule.it into the trace; evaluates the stop rule when it is active
 static int elbo_step(vrx_model* m, const VrxStopRule& rule) {
     ProfScope ps(m, VRX_KERN_DENSE);
-    vrx_elbo_final<<<1, VRX_BLOCK, 0, m->p->stream>>>(elbo_inputs(m), rule, m->ctl.p);
+    vrx_elbo_final<<<m->R, VRX_BLOCK, 0, m->p->stream>>>(elbo_inputs(m), rule, m->ctl.p);
     VRX_HIP(hipGetLastError());
     return VRX_OK;
 }
@@ -1731,7 +1833,7 @@ static int enqueue_iteration(vrx_model* m, bool do_theta, const VrxStopRule& rul
 }
 
 static int reset_ctl(vrx_model* m) {  // stop flag, stop iteration, warn flags (tickets stay 0)
-    VRX_HIP(hipMemsetAsync(m->ctl.p, 0, 3 * sizeof(int32_t), m->p->stream));
+    VRX_HIP(hipMemsetAsync(m->ctl.p, 0, (size_t)m->R * VRX_CTL_WORDS * sizeof(int32_t), m->p->stream));
     return VRX_OK;
 }
 
@@ -1761,7 +1863,8 @@ extern "C" int vrx_model_fit(vrx_model* m, int32_t max_iter, int32_t min_iter, d
     // an overshoot costs launches, not work.
     static const int batch = std::max(1, env_int("VIREO_FIT_BATCH", 4));
     int32_t* hctl = reinterpret_cast<int32_t*>(m->h_pin);
-    int it = 0, flags = 0, next = 0;
+    const int R = m->R;  // elbo_trace [R][max_iter], it_out [R], warn_flags [R]
+    int it = 0, next = 0;
     bool stopped = false;
     while (next < max_iter && !stopped) {
         const int upto = std::min(max_iter, next == 0 ? std::max(min_iter + 2, batch) : next + batch);
@@ -1777,22 +1880,28 @@ extern "C" int vrx_model_fit(vrx_model* m, int32_t max_iter, int32_t min_iter, d
             if ((rc = enqueue_iteration(m, do_theta, rule))) return rc;
         }
         next = upto;
-        VRX_HIP(hipMemcpyAsync(hctl, m->ctl.p, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        VRX_HIP(hipMemcpyAsync(hctl, m->ctl.p, (size_t)R * VRX_CTL_WORDS * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, s));
         VRX_HIP(hipStreamSynchronize(s));
-        stopped = hctl[VRX_CTL_STOP] != 0;
-        flags = hctl[VRX_CTL_WARN];
+        stopped = true;  // the batch runs until its last restart has stopped
+        for (int r = 0; r < R; ++r) stopped = stopped && hctl[r * VRX_CTL_WORDS + VRX_CTL_STOP] != 0;
     }
-    it = stopped ? hctl[VRX_CTL_IT] : max_iter - 1;  // Python leaves `it` at the last executed index
-    VRX_HIP(hipMemcpyAsync(elbo_trace, m->d_elbo.p, (size_t)(it + 1) * sizeof(double),
-                           hipMemcpyDeviceToHost, s));
+    bool any_stop = false;
+    for (int r = 0; r < R; ++r) {
+        const int32_t* c = hctl + r * VRX_CTL_WORDS;
+        any_stop = any_stop || c[VRX_CTL_STOP] != 0;
+        // Python leaves `it` at the last executed index
+        it = c[VRX_CTL_STOP] ? c[VRX_CTL_IT] : max_iter - 1;
+        it_out[r] = it;
+        if (warn_flags) warn_flags[r] = c[VRX_CTL_WARN];
+        VRX_HIP(hipMemcpyAsync(elbo_trace + (size_t)r * max_iter, m->d_elbo.p + (size_t)r * kMaxTrace,
+                               (size_t)(it + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
     VRX_HIP(hipStreamSynchronize(s));
-    if (stopped) {  // the launches behind the stop did nothing; the next call starts clean
+    if (any_stop) {  // the launches behind a stop did nothing; the next call starts clean
         if ((rc = reset_ctl(m))) return rc;
     }
-    if ((rc = prof_drain(m))) return rc;
-    *it_out = it;
-    if (warn_flags) *warn_flags = flags;
-    return VRX_OK;
+    return prof_drain(m);
 }
 
 extern "C" int vrx_model_run_iters(vrx_model* m, int32_t n_iter, int32_t theta_from_iter,
@@ -1814,10 +1923,10 @@ extern "C" int vrx_model_run_iters(vrx_model* m, int32_t n_iter, int32_t theta_f
     float ms = 0.f;
     VRX_HIP(hipEventElapsedTime(&ms, m->t0, m->t1));
     if (ms_out) *ms_out = ms;
-    if (elbo_trace) {
-        VRX_HIP(hipMemcpy(elbo_trace, m->d_elbo.p, (size_t)n_iter * sizeof(double),
-                          hipMemcpyDeviceToHost));
-    }
+    if (elbo_trace)  // [R][n_iter]
+        for (int r = 0; r < m->R; ++r)
+            VRX_HIP(hipMemcpy(elbo_trace + (size_t)r * n_iter, m->d_elbo.p + (size_t)r * kMaxTrace,
+                              (size_t)n_iter * sizeof(double), hipMemcpyDeviceToHost));
     return prof_drain(m);
 }
 
@@ -1858,9 +1967,11 @@ extern "C" int vrx_model_step(vrx_model* m, int32_t which, double* elbo_out) {
                 if ((rc = gt_step(m, 0))) return rc;
             if ((rc = softmax_step(m, 0))) return rc;
             if ((rc = elbo_step(m, no_rule(0)))) return rc;
-            VRX_HIP(hipMemcpyAsync(m->h_pin, m->d_elbo.p, sizeof(double), hipMemcpyDeviceToHost, s));
+            for (int r = 0; r < m->R; ++r)  // elbo_out [R]
+                VRX_HIP(hipMemcpyAsync(m->h_pin + r, m->d_elbo.p + (size_t)r * kMaxTrace, sizeof(double),
+                                       hipMemcpyDeviceToHost, s));
             VRX_HIP(hipStreamSynchronize(s));
-            *elbo_out = m->h_pin[0];
+            for (int r = 0; r < m->R; ++r) elbo_out[r] = m->h_pin[r];
             break;
         default:
             vrx_set_error("vrx_model_step: unknown step %d", which);
@@ -1873,8 +1984,8 @@ extern "C" int vrx_model_step(vrx_model* m, int32_t which, double* elbo_out) {
 extern "C" int vrx_model_info(vrx_model* m, int32_t* info) {
     VRX_REQUIRE(m && info, "vrx_model_info: null argument");
     const Orient &v = m->p->by_var, &c = m->p->by_cell;
-    info[0] = lds_eligible<0>(v, m->K);
-    info[1] = lds_eligible<1>(c, m->K);
+    info[0] = lds_eligible<0>(v, m->Kt);
+    info[1] = lds_eligible<1>(c, m->Kt);
     info[2] = v.fmt;
     info[3] = c.fmt;
     info[4] = v.n_tiles;

@@ -37,7 +37,27 @@ constexpr int VRX_MAXT = 8;  // max genotype classes handled by the dense kernel
 //  more than the two small launches it saves: dense kernels 0.136 -> 0.223 ms per iteration at
 //  c3, 41 -> 49 us per iteration at c2.)
 // ------------------------------------------------------------------------------------
-enum { VRX_CTL_STOP = 0, VRX_CTL_IT = 1, VRX_CTL_WARN = 2, VRX_CTL_WORDS = 4 };
+enum { VRX_CTL_STOP = 0, VRX_CTL_IT = 1, VRX_CTL_WARN = 2, VRX_CTL_WORDS = 4 };  // per restart
+__device__ __forceinline__ bool vrx_all_stopped(const int32_t* ctl, int R) {
+    for (int r = 0; r < R; ++r)
+        if (!ctl[r * VRX_CTL_WORDS + VRX_CTL_STOP]) return false;
+    return true;
+}
+// Restart batches.  A model may hold R restarts of the same problem (vireo_wrap.py:64-87 runs
+// them one after the other): the dense operands then carry R * K columns -- ID_prob [M][R][K],
+// GT_prob [N][R][K][T], S / W [N][R * K] -- so ONE sparse pass serves every restart of the batch
+// (the entry stream is read once for R * K columns), and every dense kernel runs once with
+// blockIdx.y = restart.  Each restart has its own control words, theta, partial sums and trace.
+struct VrxBatch {  // by value
+    int R, K, Kt;  // restarts, donors per restart, R * K
+};
+// position of (variant or cell n, restart r, donor k) given i = n * K + k
+__device__ __forceinline__ int64_t vrx_col(const VrxBatch& b, int64_t i, int r) {
+    if (b.R == 1) return i;
+    const int64_t n = i / b.K;
+    return n * b.Kt + (int64_t)r * b.K + (i - n * b.K);
+}
+
 struct VrxStopRule {  // by value to the ELBO kernel
     int it, min_iter, max_iter, active;
     double eps;
@@ -231,9 +251,9 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_spmm(
     int64_t n_seg, const int64_t* __restrict__ seg_begin, const int32_t* __restrict__ seg_len,
     const int32_t* __restrict__ seg_dst, const uint32_t* __restrict__ ent,
     const double* __restrict__ X, int K, double* __restrict__ out, double* __restrict__ partial,
-    const int32_t* __restrict__ ctl) {
+    const int32_t* __restrict__ ctl, int n_batch) {
     static_assert(LPE * CPL <= 16 && (MODE == 0 || CPL == 1), "layout");
-    if (ctl[VRX_CTL_STOP]) return;
+    if (vrx_all_stopped(ctl, n_batch)) return;
     const int lane = threadIdx.x & 63;
     const int64_t seg = (int64_t)blockIdx.x * VRX_WAVES + (threadIdx.x >> 6);
     if (seg >= n_seg) return;
@@ -372,8 +392,8 @@ __global__ __launch_bounds__(1024)
     const uint32_t* __restrict__ ent, const int64_t* __restrict__ wave_start,
     const int32_t* __restrict__ bnd, const int32_t* __restrict__ rowmap, int n_slab,
     int slab_rows, int64_t n_contract, int64_t n_rows, const double* __restrict__ X, int K,
-    int ld, double* __restrict__ out, const int32_t* __restrict__ ctl) {
-    if (ctl[VRX_CTL_STOP]) return;
+    int ld, double* __restrict__ out, const int32_t* __restrict__ ctl, int n_batch) {
+    if (vrx_all_stopped(ctl, n_batch)) return;
     // K <= 16 columns of this launch; ld = columns per row of X and out (ld > K: one block of a
     // wider operand, always with PADK = true: the flat slab copy needs contiguous rows)
     constexpr int G = 64 / LPE;            // rows per round
@@ -790,8 +810,8 @@ __global__ __launch_bounds__(1024)
 // out[row][c] = sum over ranges (outer) and the row's pieces (inner), fixed order
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_pieces(
     int64_t n_rows, int width, int n_range, int64_t n_vrows, const int32_t* __restrict__ vptr,
-    const double* __restrict__ partial, double* __restrict__ out, const int32_t* __restrict__ ctl) {
-    if (ctl[VRX_CTL_STOP]) return;
+    const double* __restrict__ partial, double* __restrict__ out, const int32_t* __restrict__ ctl, int n_batch) {
+    if (vrx_all_stopped(ctl, n_batch)) return;
     const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
     if (i >= n_rows * width) return;
     const int64_t row = i / width;
@@ -819,8 +839,8 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_pieces(
 // butterfly of wave_sum
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_pieces_wave(
     int64_t n_rows, int width, int n_range, int64_t n_vrows, const int32_t* __restrict__ vptr,
-    const double* __restrict__ partial, double* __restrict__ out, const int32_t* __restrict__ ctl) {
-    if (ctl[VRX_CTL_STOP]) return;
+    const double* __restrict__ partial, double* __restrict__ out, const int32_t* __restrict__ ctl, int n_batch) {
+    if (vrx_all_stopped(ctl, n_batch)) return;
     const int64_t i = ((int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (i >= n_rows * width) return;
@@ -840,8 +860,8 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_pieces_wave(
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_ranges(int64_t n, int n_range,
                                                             const double* __restrict__ partial,
                                                             double* __restrict__ out,
-                                                            const int32_t* __restrict__ ctl) {
-    if (ctl[VRX_CTL_STOP]) return;
+                                                            const int32_t* __restrict__ ctl, int n_batch) {
+    if (vrx_all_stopped(ctl, n_batch)) return;
     const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
     if (i >= n) return;
     double s = 0.0;
@@ -863,8 +883,8 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_slots(int64_t n_multi, int 
                                                            const int32_t* __restrict__ multi_ptr,
                                                            const double* __restrict__ partial,
                                                            double* __restrict__ out,
-                                                           const int32_t* __restrict__ ctl) {
-    if (ctl[VRX_CTL_STOP]) return;
+                                                           const int32_t* __restrict__ ctl, int n_batch) {
+    if (vrx_all_stopped(ctl, n_batch)) return;
     const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
     const int64_t per = (int64_t)K * VPE;
     if (i >= n_multi * per) return;
@@ -985,8 +1005,10 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_final(int n_part, int T, 
                                                              double* sm, double* psi,
                                                              double* kl_out,
                                                              const int32_t* __restrict__ ctl) {
-    if (ctl[VRX_CTL_STOP]) return;
-    vrx_theta_final_block(n_part, T, update, fix_sum, part, prior1, prior2, mu, sm, psi, kl_out);
+    const int r = blockIdx.x;  // one block per restart of the batch
+    if (ctl[r * VRX_CTL_WORDS + VRX_CTL_STOP]) return;
+    vrx_theta_final_block(n_part, T, update, fix_sum, part + (int64_t)r * n_part * 2 * VRX_MAXT, prior1,
+                          prior2, mu + r * T, sm + r * T, psi + r * 3 * T, kl_out + r);
 }
 
 // stage 1 (shared theta): per-block partial sums of S1*GT_t and S2*GT_t over all (n,k).
@@ -994,35 +1016,39 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_final(int n_part, int T, 
 // arrays the LDS-resident variant pass left in `ranges` (fused here to save a launch).
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_partial(
     int64_t NK, int T, double2* S, int n_range, const double2* __restrict__ ranges,
-    const double* __restrict__ GT, double* __restrict__ part, const int32_t* __restrict__ ctl) {
-    if (ctl[VRX_CTL_STOP]) return;
+    const double* __restrict__ GT, double* __restrict__ part, VrxBatch B,
+    const int32_t* __restrict__ ctl) {
+    const int rb = blockIdx.y;
+    if (ctl[rb * VRX_CTL_WORDS + VRX_CTL_STOP]) return;
+    const int64_t NKt = NK * B.R;
     double acc[2 * VRX_MAXT];
 #pragma unroll
     for (int t = 0; t < 2 * VRX_MAXT; ++t) acc[t] = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x; i < NK;
          i += (int64_t)gridDim.x * VRX_BLOCK) {
+        const int64_t j = vrx_col(B, i, rb);
         double2 s;
         if (n_range > 0) {
             s = make_double2(0.0, 0.0);
             for (int r = 0; r < n_range; ++r) {
-                const double2 v = ranges[(int64_t)r * NK + i];
+                const double2 v = ranges[(int64_t)r * NKt + j];
                 s.x += v.x;
                 s.y += v.y;
             }
-            S[i] = s;
+            S[j] = s;
         } else {
-            s = S[i];
+            s = S[j];
         }
         const double s1 = s.x, s2 = s.y - s.x;
 #pragma unroll
         for (int t = 0; t < VRX_MAXT; ++t)
             if (t < T) {
-                const double g = GT[i * T + t];
+                const double g = GT[j * T + t];
                 acc[t] += s1 * g;
                 acc[VRX_MAXT + t] += s2 * g;
             }
     }
-    block_sum_store<2 * VRX_MAXT>(acc, part + (int64_t)blockIdx.x * 2 * VRX_MAXT);
+    block_sum_store<2 * VRX_MAXT>(acc, part + ((int64_t)rb * gridDim.x + blockIdx.x) * 2 * VRX_MAXT);
 }
 
 // ASE mode: one theta row per variant (vireo_model.py:82,:177 axis=1).  Thread per variant.
@@ -1033,9 +1059,13 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_ase(int64_t N, int K, int
                                                            const double* __restrict__ prior1,
                                                            const double* __restrict__ prior2,
                                                            int prior_rows, double* mu, double* sm,
-                                                           double* psi, double* kl_part,
+                                                           double* psi, double* kl_part, VrxBatch B,
                                                            const int32_t* __restrict__ ctl) {
-    if (ctl[VRX_CTL_STOP]) return;
+    const int rb = blockIdx.y;
+    if (ctl[rb * VRX_CTL_WORDS + VRX_CTL_STOP]) return;
+    mu += (int64_t)rb * N * T;
+    sm += (int64_t)rb * N * T;
+    psi += (int64_t)rb * 3 * N * T;
     const int64_t n = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
     double kl[1] = {0.0};
     if (n < N) {
@@ -1044,12 +1074,13 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_ase(int64_t N, int K, int
         for (int t = 0; t < VRX_MAXT; ++t) a1[t] = a2[t] = 0.0;
         if (update)
             for (int k = 0; k < K; ++k) {
-                const double2 s = S[n * K + k];
+                const int64_t j = n * B.Kt + (int64_t)rb * K + k;
+                const double2 s = S[j];
                 const double s1 = s.x, s2 = s.y - s.x;
 #pragma unroll
                 for (int t = 0; t < VRX_MAXT; ++t)
                     if (t < T) {
-                        const double g = GT[(n * K + k) * T + t];
+                        const double g = GT[j * T + t];
                         a1[t] += s1 * g;
                         a2[t] += s2 * g;
                     }
@@ -1059,7 +1090,7 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_ase(int64_t N, int K, int
                               mu + n * T, sm + n * T, psi + n * T, psi + (N + n) * T,
                               psi + (2 * N + n) * T);
     }
-    block_sum_store<1>(kl, kl_part + blockIdx.x);
+    block_sum_store<1>(kl, kl_part + (int64_t)rb * gridDim.x + blockIdx.x);
 }
 
 // One entry of the cell pass's dense operand.  wform 0: W[n][k] = (W1, W2) interleaved, used
@@ -1085,18 +1116,21 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_gt_update(
     int64_t NK, int K, int T, int learn, int ase, int64_t N, const double2* __restrict__ S,
     const double* __restrict__ psi, const double* __restrict__ logq, int gt_mode, double logq_uni,
     double* __restrict__ GT, double* __restrict__ W, int wform, double* __restrict__ kl_part,
-    const int32_t* __restrict__ ctl) {
+    VrxBatch B, const int32_t* __restrict__ ctl) {
 #pragma clang fp contract(off)
-    if (ctl[VRX_CTL_STOP]) return;
+    const int rb = blockIdx.y;
+    if (ctl[rb * VRX_CTL_WORDS + VRX_CTL_STOP]) return;
     const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
     double kl[1] = {0.0};
     if (i < NK) {
         const int64_t n = i / K;
         const int k = (int)(i - n * K);
+        const int64_t j = n * B.Kt + (int64_t)rb * K + k;  // this restart's column of S / GT / W
         const int64_t rows = ase ? N : 1, pr = ase ? n : 0;
-        const double* p1 = psi + pr * T;
-        const double* p2 = psi + (rows + pr) * T;
-        const double* ps = psi + (2 * rows + pr) * T;
+        const double* pb = psi + (int64_t)rb * 3 * rows * T;
+        const double* p1 = pb + pr * T;
+        const double* p2 = pb + (rows + pr) * T;
+        const double* ps = pb + (2 * rows + pr) * T;
         double g[VRX_MAXT], lq[VRX_MAXT];
 #pragma unroll
         for (int t = 0; t < VRX_MAXT; ++t)
@@ -1104,7 +1138,7 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_gt_update(
                 lq[t] = gt_mode == 0 ? logq_uni
                                      : (gt_mode == 1 ? logq[k * T + t] : logq[i * T + t]);
         if (learn) {
-            const double2 s = S[i];
+            const double2 s = S[j];
             const double s1 = s.x, ss = s.y, s2 = ss - s1;
             double L[VRX_MAXT];
             double mx = -__builtin_inf();
@@ -1127,14 +1161,14 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_gt_update(
             for (int t = 0; t < VRX_MAXT; ++t)
                 if (t < T) {
                     g[t] = g[t] / sum;
-                    GT[i * T + t] = g[t];
+                    GT[j * T + t] = g[t];
                     if (g[t] > 0.0) kl[0] += g[t] * ((L[t] - lsum) - lq[t]);
                 }
         } else {
 #pragma unroll
             for (int t = 0; t < VRX_MAXT; ++t)
                 if (t < T) {
-                    g[t] = GT[i * T + t];
+                    g[t] = GT[j * T + t];
                     if (g[t] > 0.0) kl[0] += g[t] * (log(g[t]) - lq[t]);
                 }
         }
@@ -1146,9 +1180,9 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_gt_update(
                 w2 += g[t] * (p2[t] - ps[t]);
                 wa += g[t] * (p1[t] - ps[t]);
             }
-        vrx_store_w(W, wform, n, k, K, w1, w2, wa);
+        vrx_store_w(W, wform, n, rb * K + k, B.Kt, w1, w2, wa);
     }
-    block_sum_store<1>(kl, kl_part + blockIdx.x);
+    block_sum_store<1>(kl, kl_part + (int64_t)rb * gridDim.x + blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1220,17 +1254,20 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_bmm_theta(int64_t NK, int updat
                                                            const double* __restrict__ prior2,
                                                            int prior_full, double* mu, double* sm,
                                                            double* __restrict__ W, int K, int wform,
-                                                           double* __restrict__ kl_part,
+                                                           double* __restrict__ kl_part, VrxBatch B,
                                                            const int32_t* __restrict__ ctl) {
 #pragma clang fp contract(off)
-    if (ctl[VRX_CTL_STOP]) return;
+    const int rb = blockIdx.y;
+    if (ctl[rb * VRX_CTL_WORDS + VRX_CTL_STOP]) return;
+    mu += (int64_t)rb * NK;
+    sm += (int64_t)rb * NK;
     const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
     double kl[1] = {0.0};
     if (i < NK) {
         const double q1 = prior1[prior_full ? i : 0], q2 = prior2[prior_full ? i : 0];
         double m = mu[i], s = sm[i];
         if (update) {
-            const double2 a = S[i];
+            const double2 a = S[vrx_col(B, i, rb)];
             const double t1 = a.x + q1;
             const double t2 = (a.y - a.x) + q2;
             m = t1 / (t1 + t2);
@@ -1240,20 +1277,21 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_bmm_theta(int64_t NK, int updat
         }
         const double s1 = m * s, s2 = (1.0 - m) * s;
         const double d1 = vrx_digamma(s1), d2 = vrx_digamma(s2), ds = vrx_digamma(s1 + s2);
-        vrx_store_w(W, wform, i / K, (int)(i % K), K, d1 - d2, d2 - ds, d1 - ds);
+        vrx_store_w(W, wform, i / K, rb * K + (int)(i % K), B.Kt, d1 - d2, d2 - ds, d1 - ds);
         kl[0] = vrx_beta_kl(s1, s2, q1, q2, d1, d2, ds);
     }
-    block_sum_store<1>(kl, kl_part + blockIdx.x);
+    block_sum_store<1>(kl, kl_part + (int64_t)rb * gridDim.x + blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------
 // ELBO  = LB_p - KL_ID - KL_GT - KL_theta  (vireo_model.py:247-248, bmm_model.py:175)
 // One block; each term is the fixed-order sum of a partial array.
 // ------------------------------------------------------------------------------------
-struct VrxElboIn {  // by value
+struct VrxElboIn {  // by value; per restart r: partial arrays r * n_*_part on, trace r * trace_stride on
     const double *cell_part, *gt_part, *th_part;
     int n_cell_part, n_gt_part, n_th_part;
     double *elbo, *parts;  // elbo: the trace (slot rule.it is written)
+    int64_t trace_stride;
 };
 
 __device__ __forceinline__ void vrx_elbo_final_block(const double* cell_part, int n_cell_part,
@@ -1318,9 +1356,13 @@ __device__ __forceinline__ void vrx_elbo_final_block(const double* cell_part, in
 }
 
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_elbo_final(VrxElboIn e, VrxStopRule rule, int32_t* ctl) {
+    const int r = blockIdx.x;  // one block per restart of the batch
+    ctl += r * VRX_CTL_WORDS;
     if (ctl[VRX_CTL_STOP]) return;
-    vrx_elbo_final_block(e.cell_part, e.n_cell_part, e.gt_part, e.n_gt_part, e.th_part, e.n_th_part,
-                         e.elbo, e.parts, rule, ctl);
+    vrx_elbo_final_block(e.cell_part + (int64_t)r * e.n_cell_part * 2, e.n_cell_part,
+                         e.gt_part + (int64_t)r * e.n_gt_part, e.n_gt_part,
+                         e.th_part + (int64_t)r * e.n_th_part, e.n_th_part,
+                         e.elbo + r * e.trace_stride, e.parts + r * 4, rule, ctl);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1337,17 +1379,19 @@ template <int KP>
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_cell_softmax(
     int64_t M, int K, int update, double* LID, int n_range, const double* __restrict__ ranges,
     const double* __restrict__ logq, int id_mode, double logq_uni, double* __restrict__ ID,
-    double* __restrict__ part, const int32_t* __restrict__ ctl) {
-    if (ctl[VRX_CTL_STOP]) return;
+    double* __restrict__ part, VrxBatch B, const int32_t* __restrict__ ctl) {
+    const int rb = blockIdx.y;
+    if (ctl[rb * VRX_CTL_WORDS + VRX_CTL_STOP]) return;
     const int64_t cell = ((int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x) / KP;
     const int kl = threadIdx.x % KP;
     double acc[2] = {0.0, 0.0};
     const bool live = cell < M;
-    double* Lr = LID + (live ? cell : 0) * (int64_t)K;
+    const int64_t row0 = (live ? cell : 0) * (int64_t)B.Kt + (int64_t)rb * K;  // this restart's K columns
+    double* Lr = LID + row0;
     if (live && n_range > 0)
         for (int k = kl; k < K; k += KP) {
             double t = 0.0;
-            for (int r = 0; r < n_range; ++r) t += ranges[((int64_t)r * M + cell) * K + k];
+            for (int r = 0; r < n_range; ++r) t += ranges[(int64_t)r * M * B.Kt + row0 + k];
             Lr[k] = t;
         }
     const double* qr = id_mode == 2 ? logq + (live ? cell : 0) * (int64_t)K : logq;
@@ -1363,7 +1407,7 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_cell_softmax(
     for (int s = 1; s < KP; s <<= 1) sum += __shfl_xor(sum, s, 64);
     if (live) {
         const double lsum = update ? log(sum) : 0.0;
-        double* Ir = ID + cell * (int64_t)K;
+        double* Ir = ID + row0;
         for (int k = kl; k < K; k += KP) {
             const double L = Lr[k];
             const double lq = id_mode ? qr[k] : logq_uni;
@@ -1381,7 +1425,7 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_cell_softmax(
             if (p > 0.0) acc[1] += p * (lp - lq);
         }
     }
-    block_sum_store<2>(acc, part + (int64_t)blockIdx.x * 2);
+    block_sum_store<2>(acc, part + ((int64_t)rb * gridDim.x + blockIdx.x) * 2);
 }
 
 // ------------------------------------------------------------------------------------

@@ -27,8 +27,9 @@ def _prior_rows(P, full_rows):
 
 class DeviceModel:
     def __init__(self, counts, kind, n_donor, n_gt=3, learn_gt=True, learn_theta=True,
-                 ase_mode=False, fix_beta_sum=False):
+                 ase_mode=False, fix_beta_sum=False, n_batch=1):
         self.counts = counts            # keeps the vrx_problem alive
+        self.R = int(n_batch)
         self.kind = kind
         self.K, self.T = int(n_donor), int(n_gt)
         self.N, self.M = counts.n_var, counts.n_cell
@@ -38,7 +39,7 @@ class DeviceModel:
             self.theta_shape = (self.N, self.K)
         cfg = _lib.ModelCfg(kind=kind, n_donor=self.K, n_gt=self.T, learn_gt=int(bool(learn_gt)),
                             learn_theta=int(bool(learn_theta)), ase_mode=int(bool(ase_mode)),
-                            fix_beta_sum=int(bool(fix_beta_sum)), reserved=0)
+                            fix_beta_sum=int(bool(fix_beta_sum)), n_batch=self.R)
         self._h = C.c_void_p()
         _lib.check(_lib.lib().vrx_model_create(counts.handle, C.byref(cfg), C.byref(self._h)))
         self._fin = weakref.finalize(self, _lib.lib().vrx_model_destroy, self._h)
@@ -170,6 +171,66 @@ class DeviceModel:
     def run_iters(self, n_iter, theta_from_iter=0):
         """n_iter iterations back to back, no convergence test -> (elbo trace, wall ms)"""
         trace = np.zeros(n_iter)
+        ms = C.c_double(0.0)
+        _lib.check(_lib.lib().vrx_model_run_iters(self._h, int(n_iter), int(theta_from_iter),
+                                                  dptr(trace), C.byref(ms)))
+        return trace, ms.value
+
+
+class DeviceBatch(DeviceModel):
+    """``n_batch`` restarts of one model shape in ONE device model (vrx_model_cfg.n_batch):
+    every sparse pass serves all of them, each keeps its own theta, ELBO trace and stop rule.
+    Slots are filled one restart at a time in the single-model layouts; the winner moves to a
+    single ``DeviceModel`` on the device."""
+
+    def __init__(self, counts, kind, n_donor, n_batch, **kw):
+        if not 1 <= int(n_batch) <= 16:
+            raise ValueError("n_batch must be in 1..16")
+        super().__init__(counts, kind, n_donor, n_batch=n_batch, **kw)
+
+    def _single_only(self, *a, **k):
+        raise TypeError("not available on a restart batch; use set_restart / copy_to")
+
+    set_state = set_state_raw = get_state = snapshot = restore = _single_only
+    get_loglik = set_loglik = _single_only
+
+    def set_restart(self, r, ID=None, GT=None, beta_mu=None, beta_sum=None, raw=False):
+        ID = self._check(ID, (self.M, self.K), "ID")
+        GT = (self._check(GT, (self.N, self.K, self.T), "GT")
+              if self.kind == _lib.KIND_VIREO else None)
+        beta_mu = self._check(beta_mu, self.theta_shape, "beta_mu")
+        beta_sum = self._check(beta_sum, self.theta_shape, "beta_sum")
+        _lib.check(_lib.lib().vrx_model_set_restart(self._h, int(r), dptr(ID), dptr(GT),
+                                                    dptr(beta_mu), dptr(beta_sum), int(bool(raw))))
+
+    def copy_to(self, single, r):
+        """``single`` (a DeviceModel of the same problem and shape) <- slot r, on the device"""
+        _lib.check(_lib.lib().vrx_model_copy_restart(single._h, self._h, int(r)))
+
+    def fit(self, max_iter, min_iter, epsilon_conv, delay_fit_theta=0):
+        """-> per restart: (list of traces [it_r + 1 values each], it [R], warn_flags [R])"""
+        trace = np.zeros((self.R, max_iter))
+        it = np.zeros(self.R, dtype=np.int32)
+        flags = np.zeros(self.R, dtype=np.int32)
+        i32 = C.POINTER(C.c_int32)
+        _lib.check(_lib.lib().vrx_model_fit(self._h, int(max_iter), int(min_iter),
+                                            float(epsilon_conv), int(delay_fit_theta),
+                                            dptr(trace), it.ctypes.data_as(i32),
+                                            flags.ctypes.data_as(i32)))
+        return [trace[r, :it[r] + 1] for r in range(self.R)], it, flags
+
+    def step(self, which):
+        out = np.zeros(self.R)
+        _lib.check(_lib.lib().vrx_model_step(self._h, which, dptr(out)))
+        return out
+
+    def elbo_parts(self):
+        p = np.zeros((self.R, 4))
+        _lib.check(_lib.lib().vrx_model_get_elbo_parts(self._h, dptr(p)))
+        return p
+
+    def run_iters(self, n_iter, theta_from_iter=0):
+        trace = np.zeros((self.R, n_iter))
         ms = C.c_double(0.0)
         _lib.check(_lib.lib().vrx_model_run_iters(self._h, int(n_iter), int(theta_from_iter),
                                                   dptr(trace), C.byref(ms)))

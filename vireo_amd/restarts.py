@@ -16,8 +16,10 @@ import time
 
 import numpy as np
 
+import os
+
 from . import _lib
-from .engine import DeviceModel
+from .engine import DeviceBatch, DeviceModel
 
 
 # Optional phase timers (bench.py's c4 leg): set to a dict and the restart loop adds the
@@ -67,36 +69,112 @@ class LegacyStream:
             self._advance(None, n)
 
 
-class DeviceRestarts:
-    """This rank's restarts on one ``DeviceModel``; the best fitted state is snapshotted
-    device-side.  ``template`` is a host ``Vireo`` carrying shapes, flags and priors (its own
-    ID_prob / GT_prob are ignored unless passed as fixed initial values)."""
+def restart_batch(n_donor, n_owned, nnz):
+    """How many restarts share one device model.  The LDS-resident passes compute 16 columns per
+    sweep of the entry stream whatever n_donor is, so restarts are packed until the 16 columns
+    are full; a problem small enough to be bound by kernel launches rather than by the stream
+    takes a full batch of 16.  VIREO_RESTART_BATCH overrides (1 = one restart at a time)."""
+    forced = int(os.environ.get("VIREO_RESTART_BATCH", "0"))
+    if forced > 0:
+        return max(1, min(forced, 16, n_owned))
+    fill = max(1, 16 // n_donor)
+    if nnz * n_donor < (1 << 24):
+        fill = 16
+    return max(1, min(fill, n_owned))
 
-    def __init__(self, counts, template):
+
+class DeviceRestarts:
+    """This rank's restarts on the device; the best fitted state is snapshotted device-side.
+    ``template`` is a host ``Vireo`` carrying shapes, flags and priors (its own ID_prob /
+    GT_prob are ignored unless passed as fixed initial values).  With ``batch`` > 1 the
+    restarts are collected with ``submit`` and fitted ``batch`` at a time by one
+    ``DeviceBatch`` (every sparse pass serves all of them); ``flush`` returns their ELBOs."""
+
+    def __init__(self, counts, template, batch=1):
         self.counts = counts
         self.t = template
-        self.dm = DeviceModel(counts, _lib.KIND_VIREO, template.n_donor, n_gt=template.n_GT,
-                              learn_gt=template.learn_GT, learn_theta=template.learn_theta,
-                              ase_mode=template.ASE_mode, fix_beta_sum=template.fix_beta_sum)
+        shape = dict(n_gt=template.n_GT, learn_gt=template.learn_GT,
+                     learn_theta=template.learn_theta, ase_mode=template.ASE_mode,
+                     fix_beta_sum=template.fix_beta_sum)
+        self.dm = DeviceModel(counts, _lib.KIND_VIREO, template.n_donor, **shape)
         template._set_device_prior(self.dm)
+        self.batch = int(batch)
+        self.db = None
+        if self.batch > 1:
+            self.db = DeviceBatch(counts, _lib.KIND_VIREO, template.n_donor, self.batch, **shape)
+            template._set_device_prior(self.db)
+        self.pending, self.done = [], {}
         self.const = counts.binom_const()
         self.best = None            # (elbo, restart index, trace)
+        self.iterations = 0
+
+    def _theta0(self):
+        t = self.t
+        rows = t.n_var if t.ASE_mode else 1
+        return (np.broadcast_to(t.beta_mu, (rows, t.n_GT)),
+                np.broadcast_to(t.beta_sum, (rows, t.n_GT)))
+
+    def submit(self, im, ID_raw, GT_raw, ID_fixed, GT_fixed, max_iter, delay_fit_theta):
+        """Place restart ``im`` in the next slot of the batch; a full batch is fitted."""
+        mu, sm = self._theta0()
+        slot = len(self.pending)
+        with _phase("upload+normalise"):
+            if ID_fixed is not None or GT_fixed is not None:
+                self.db.set_restart(slot, ID_fixed, GT_fixed, None, None, raw=False)
+            self.db.set_restart(slot, ID_raw, GT_raw, mu, sm, raw=True)
+            if slot == 0:
+                # slots the last batch does not fill repeat its first restart (they must hold
+                # a valid state; their results are dropped)
+                self._fill = (ID_raw, GT_raw, ID_fixed, GT_fixed)
+        self.pending.append(im)
+        self._fit_args = (max_iter, delay_fit_theta)
+        if len(self.pending) == self.batch:
+            self._fit_pending()
+
+    def _fit_pending(self):
+        if not self.pending:
+            return
+        mu, sm = self._theta0()
+        ID_raw, GT_raw, ID_fixed, GT_fixed = self._fill
+        with _phase("upload+normalise"):
+            for slot in range(len(self.pending), self.batch):
+                if ID_fixed is not None or GT_fixed is not None:
+                    self.db.set_restart(slot, ID_fixed, GT_fixed, None, None, raw=False)
+                self.db.set_restart(slot, ID_raw, GT_raw, mu, sm, raw=True)
+        max_iter, delay = self._fit_args
+        with _phase("fit"):
+            traces, its, _ = self.db.fit(max_iter, 5, 1e-2, delay)
+        for slot, im in enumerate(self.pending):
+            it = int(its[slot])
+            self.iterations += it + 1
+            elbo = traces[slot][:it] + self.const
+            self.done[im] = elbo[-1]
+            if self.best is None or elbo[-1] > self.best[0]:     # first max wins
+                with _phase("snapshot"):
+                    self.db.copy_to(self.dm, slot)
+                    self.dm.snapshot()
+                self.best = (elbo[-1], im, elbo)
+        self.pending = []
+        self._fill = None
+
+    def flush(self):
+        """fit what is still pending -> {restart index: ELBO_[-1]} of everything submitted"""
+        self._fit_pending()
+        done, self.done = self.done, {}
+        return done
 
     def run(self, im, ID_raw, GT_raw, ID_fixed, GT_fixed, max_iter, delay_fit_theta):
         """Fit restart ``im`` from raw draws (normalised on the device) or, where the caller
         supplied initial values, from those (already normalised on the host).  Returns
         ``ELBO_[-1]`` as ``Vireo.fit`` would leave it."""
-        t = self.t
-        rows = t.n_var if t.ASE_mode else 1
-        mu = np.broadcast_to(t.beta_mu, (rows, t.n_GT))
-        sm = np.broadcast_to(t.beta_sum, (rows, t.n_GT))
+        mu, sm = self._theta0()
         with _phase("upload+normalise"):
             if ID_fixed is not None or GT_fixed is not None:
                 self.dm.set_state(ID_fixed, GT_fixed, None, None)
             self.dm.set_state_raw(ID_raw, GT_raw, mu, sm)
         with _phase("fit"):
             trace, it, _ = self.dm.fit(max_iter, 5, 1e-2, delay_fit_theta)
-        self.iterations = getattr(self, "iterations", 0) + it + 1
+        self.iterations += it + 1
         elbo = trace[:it] + self.const
         if self.best is None or elbo[-1] > self.best[0]:     # first max wins
             with _phase("snapshot"):
@@ -122,3 +200,5 @@ class DeviceRestarts:
 
     def close(self):
         self.dm.close()
+        if self.db is not None:
+            self.db.close()

@@ -17,7 +17,7 @@ import numpy as np
 
 from .counts import device_counts
 from .dist import LocalComm, gather_restart_elbos, my_restarts
-from .restarts import DeviceRestarts, LegacyStream, _phase
+from .restarts import DeviceRestarts, LegacyStream, _phase, restart_batch
 from .vireo_base import donor_select, normalize, optimal_match
 from .vireo_doublet import predict_doublet
 from .vireo_model import Vireo
@@ -96,16 +96,23 @@ def _search(counts, plan, comm, max_iter_init, delay_fit_theta, kwargs, restarts
         GT0_first, GT0 = tmpl.GT_prob.copy(), normalize(plan.search_prior)
     stream = LegacyStream()
     mine = set(my_restarts(plan.n_init, comm.rank, comm.world))
-    runner = restarts_cls(counts, tmpl)
+    batch = restart_batch(K, len(mine), counts.nnz) if hasattr(restarts_cls, "submit") else 1
+    runner = restarts_cls(counts, tmpl, batch) if batch > 1 else restarts_cls(counts, tmpl)
     local = {}
     for im in range(plan.n_init):
         if im in mine:
             ID_raw = stream.rand(n_cell, K) if ID0 is None else None
             GT_raw = stream.rand(n_var, K, T) if GT0 is None else None
-            local[im] = runner.run(im, ID_raw, GT_raw, ID0, GT0_first if im == 0 else GT0,
-                                   max_iter_init, delay_fit_theta)
+            args = (im, ID_raw, GT_raw, ID0, GT0_first if im == 0 else GT0, max_iter_init,
+                    delay_fit_theta)
+            if batch > 1:
+                runner.submit(*args)         # fitted `batch` at a time
+            else:
+                local[im] = runner.run(*args)
         else:
             stream.skip((n_cell * K if ID0 is None else 0) + (n_var * K * T if GT0 is None else 0))
+    if batch > 1:
+        local.update(runner.flush())
     with _phase("gather"):
         elbo_all = gather_restart_elbos(comm, plan.n_init, local)
     best = int(np.argmax(elbo_all))              # first max wins, vireo_wrap.py:90-91
@@ -114,7 +121,7 @@ def _search(counts, plan, comm, max_iter_init, delay_fit_theta, kwargs, restarts
     LAST_SEARCH.clear()
     LAST_SEARCH.update(restarts=len(local), restart_iterations=getattr(runner, "iterations", 0),
                        final_iterations=getattr(runner, "final_iterations", 0), best=best,
-                       owner=owner)
+                       owner=owner, batch=batch)
     runner.close()
     with _phase("broadcast"):
         _bcast_model(comm, model, owner)
