@@ -253,8 +253,8 @@ def main():
                       elbo_trace_rel_err_per_iteration=None if rel_it is None else
                       [float("%.3g" % x) for x in rel_it],
                       elbo_final_rel_err=None if rel_it is None else float(rel_it[-1]),
-                      gpu_self_sensitivity_1e-13_per_iteration=None if self_rel is None else
-                      [float("%.3g" % x) for x in self_rel],
+                      gpu_self_sensitivity_per_iteration=None if self_rel is None else
+                      [float("%.3g" % x) for x in self_rel],   # (to a 1e-13 perturbation)
                       elbo_final_gpu=float(gtrace[-1]), elbo_final_cpu=float(ctrace[-1]),
                       id_prob_max_abs_err=float(np.max(np.abs(dev.ID_prob - st.ID_prob))),
                       assignment_mismatches=int(differ.sum()),
