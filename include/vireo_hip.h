@@ -215,7 +215,10 @@ int vrx_problem_cell_loglik(vrx_problem* p, int64_t n_col, int64_t n_class,
  * LDS-resident variant/cell pass; info[8]/[9] = its stream words (padding included) per 1000
  * non-zeros; info[10]/[11] = extra row pieces (long rows are cut into interleaved pieces);
  * info[12] = form of the LDS-resident cell stream (0: (ad, dp) pairs, 1: single-valued AD / BD
- * entries); info[13..15] reserved (0). */
+ * entries); info[13] = form of the variant stream (0: pairs, 2: AD entries then BD entries per
+ * round); info[14] = restarts in the model (n_batch); info[15] reserved (0).  The forms follow
+ * the depth of the data: AD/BD words unless a count needs so many of them (> 1.56 words per
+ * entry, estimated at vrx_problem_create) that one pair word per entry is cheaper. */
 int vrx_model_info(vrx_model* m, int32_t* info16);
 int vrx_model_profile(vrx_model* m, int32_t enable);
 int vrx_model_profile_read(vrx_model* m, double* ms_total /* VRX_KERN_COUNT */,

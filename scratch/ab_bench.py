@@ -34,7 +34,20 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     dm.run_iters(10, theta_from_iter=0)
     pm, n = dm.profile_read()
     info = dm.info()
-    print(json.dumps(dict(ms_iter=round(ms / 20, 4), variant=round(pm[0] / max(n[0], 1), 4),
+    timing = None
+    if hasattr(_lib.lib(), "vrx_debug_timing"):     # scratch builds with -DVRX_TIMING
+        import ctypes
+        buf = (ctypes.c_ulonglong * 16)()
+        _lib.lib().vrx_debug_timing(buf)
+        dm.run_iters(10, theta_from_iter=0)
+        _lib.lib().vrx_debug_timing(buf)
+        timing = {}
+        for mode, name in ((0, "variant"), (1, "cell")):
+            tot, b1, b2, st, nw = [buf[mode * 8 + i] for i in range(5)]
+            if nw:
+                timing[name] = dict(cycles_per_wave=tot // nw, barrier1=round(b1 / tot, 3),
+                                    barrier2=round(b2 / tot, 3), stage=round(st / tot, 3))
+    print(json.dumps(dict(timing=timing, ms_iter=round(ms / 20, 4), variant=round(pm[0] / max(n[0], 1), 4),
                           cell=round(pm[1] / max(n[1], 1), 4), dense=round(pm[2] / 10, 4),
                           elbo=float(tr[-1]), pad_v=info["pad_variant"], pad_c=info["pad_cell"],
                           form=info["cell_form"])))

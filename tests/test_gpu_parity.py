@@ -397,6 +397,7 @@ def test_lds_count_limit_and_tiny_shapes(va, monkeypatch, top, var_form):
     from vireo_amd.engine import DeviceModel
     monkeypatch.setenv("VIREO_LDS", "1")
     monkeypatch.setenv("VIREO_VAR_FORM", str(var_form))
+    monkeypatch.setenv("VIREO_CELL_FORM", "1")     # (counts this deep would pick pair words)
     expect_lds = var_form == 2 or top < 2048
     rng = np.random.default_rng(5)
     dp = (rng.random((70, 40)) < 0.3) * rng.integers(1, 60, (70, 40))
@@ -685,3 +686,31 @@ def test_wrap_with_restart_batches(va, monkeypatch, capsys, batch):
     close(res[batch]["LB_list"], res[1]["LB_list"], rtol=1e-9)
     close(res[batch]["ID_prob"], res[1]["ID_prob"], rtol=1e-6, atol=1e-12)
     assert np.array_equal(np.argmax(res[batch]["ID_prob"], 1), np.argmax(res[1]["ID_prob"], 1))
+
+
+@pytest.mark.parametrize("depth,want", [(1.0, (1, 2)), (50.0, (0, 0)), (3000.0, (1, 2))])
+def test_stream_form_follows_count_depth(va, monkeypatch, depth, want):
+    """AD/BD words (cell form 1, variant form 2) on shallow data, one (ad, dp) pair word per
+    entry where the counts are deep enough to need several AD/BD words each (clone mode) but
+    still fit 11 bits, AD/BD words again beyond that; every choice matches the oracle"""
+    from vireo_amd import _lib
+    from vireo_amd.counts import DeviceCounts
+    from vireo_amd.engine import DeviceModel
+    monkeypatch.setenv("VIREO_LDS", "1")
+    rng = np.random.default_rng(int(depth))
+    N, M, K = 600, 900, 5
+    mask = rng.random((N, M)) < 0.05
+    DPd = (1 + rng.poisson(depth, (N, M))) * mask
+    ADd = rng.binomial(DPd, 0.3)
+    AD, DP = csc_matrix(ADd), csc_matrix(DPd)
+    counts = DeviceCounts(AD, DP)
+    dm = DeviceModel(counts, _lib.KIND_VIREO, K)
+    info = dm.info()
+    assert (info["cell_form"], info["var_form"]) == want and info["lds_cell"] and info["lds_variant"]
+    np.random.seed(3)
+    m = va.Vireo(n_var=N, n_cell=M, n_donor=K)
+    st = O.vireo_new(M, N, K, ID_prob_init=m.ID_prob.copy(), GT_prob_init=m.GT_prob.copy())
+    m.fit(counts, None, min_iter=3, max_iter=8, verbose=False)
+    O.vireo_fit(st, AD, DP, max_iter=8, min_iter=3)
+    close(m.ELBO_, st.ELBO_, rtol=1e-9)
+    close(m.ID_prob, st.ID_prob, rtol=1e-6, atol=1e-12)

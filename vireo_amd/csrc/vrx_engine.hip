@@ -621,12 +621,49 @@ static int pick_rw_cell(int64_t n_var, int64_t n_cell) {
                : VRX_LDS_RW_CELL;
 }
 
+// Which stream words the LDS-resident passes use.  Single-valued AD / BD words (cell form 1,
+// variant form 2) cost ~1.56x less per word than (ad, dp) pair words (c3: 0.39 vs 0.51 ms at
+// 1.2 words per entry) and hold any count, but a count with more than three significant bits
+// takes several words (45 = 40 + 5): deep data -- clone mode, DP ~ Poisson(50), 2.65 words per
+// entry -- is better served by one pair word per entry as long as the counts fit its 11 bits.
+// The words per entry are estimated from every 61st entry.  VIREO_CELL_FORM / VIREO_VAR_FORM
+// force a form.
+struct StreamForms {
+    int cell, var;   // cell pass: 1 AD/BD, 0 pairs; variant pass: 2 AD/BD phases, 0 pairs
+    bool auto_pair;  // pairs chosen by the estimate: fall back to AD/BD when a count is >= 2048
+};
+static StreamForms pick_forms(int64_t nnz, const int32_t* ad, const int32_t* dp) {
+    auto chunks = [](int64_t v) {
+        int n = 0;
+        while (v > 0) {
+            const int len = 64 - __builtin_clzll((uint64_t)v), sh = std::max(0, len - 3);
+            v -= (v >> sh) << sh;
+            ++n;
+        }
+        return n;
+    };
+    int64_t words = 0, seen = 0;
+    for (int64_t e = 0; e < nnz; e += 61) {
+        const int64_t a = ad[e], d = dp[e];
+        if (a < 0 || d < a) continue;  // (rejected by the validation that follows)
+        words += chunks(a) + chunks(d - a);
+        ++seen;
+    }
+    const double wpe = seen ? (double)words / (double)seen : 1.0;
+    const bool pairs = wpe > (double)env_int("VIREO_PAIR_WORDS_X100", 156) / 100.0;
+    StreamForms f;
+    f.cell = env_int("VIREO_CELL_FORM", pairs ? 0 : 1);
+    f.var = env_int("VIREO_VAR_FORM", pairs ? 0 : 2);
+    f.auto_pair = pairs && !getenv("VIREO_CELL_FORM") && !getenv("VIREO_VAR_FORM");
+    return f;
+}
+
 // Large problems: everything from the merged CSC arrays onwards happens on the device
 // (vrx_build.h).  *built = false means "not applicable here" (small problem, counts the pair
 // words cannot hold, a stream the padding guard rejects): the caller then runs the host builder.
 static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* rowidx,
                         const int32_t* ad, const int32_t* dp, int rw_cell, int slab_cell, int slab_var,
-                        int cell_form, bool guard, bool* built) {
+                        StreamForms forms, bool guard, bool* built) {
     *built = false;
     const int64_t nnz = p->nnz, n_var = p->n_var, n_cell = p->n_cell;
     hipStream_t s = p->stream;
@@ -668,8 +705,10 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
         return VRX_ERR_ARG;
     }
     const int32_t max_count = st[2];
-    const int var_form = env_int("VIREO_VAR_FORM", 2);
-    if (var_form != 2 && max_count >= 2048) return VRX_OK;  // (pair words hold 11-bit counts)
+    if (max_count >= 2048 && forms.auto_pair) forms = StreamForms{1, 2, false};
+    const int var_form = forms.var, cell_form = forms.cell;
+    // (pair words hold 11-bit counts; a forced pair form leaves such data to the host builder)
+    if ((var_form != 2 || cell_form != 1) && max_count >= 2048) return VRX_OK;
     // ---- transposition: stable sort of (variant, entry) ---------------------------------------
     VRX_HIP(keys_in.alloc((size_t)nnz));
     VRX_HIP(keys_out.alloc((size_t)nnz));
@@ -790,17 +829,18 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
     // on the device; VIREO_BUILD=host keeps the host builder (the specification the device
     // build is tested against), VIREO_BUILD=device takes the device path whenever VIREO_LDS
     // allows the streams.
+    StreamForms forms = pick_forms(nnz, ad, dp);
     {
         const int lds0 = env_int("VIREO_LDS", -1);
         const char* bm = getenv("VIREO_BUILD");
         const bool force_dev = bm && !strcmp(bm, "device"), force_host = bm && !strcmp(bm, "host");
         const bool big = nnz >= (int64_t)env_int("VIREO_LDS_MIN_NNZ", 4000000) &&
                          nnz >= (int64_t)env_int("VIREO_LDS_MIN_NNZ_VAR", 32000000);
-        if (!force_host && lds0 != 0 && env_int("VIREO_CELL_FORM", 1) == 1 && (force_dev || big)) {
+        if (!force_host && lds0 != 0 && (force_dev || big)) {
             bool built = false;
             int rc = device_build(p.get(), colptr, rowidx, ad, dp, pick_rw_cell(n_var, n_cell),
                                   std::min(512, std::max(16, env_int("VIREO_LDS_SLAB_CELL", 512))),
-                                  std::min(1024, std::max(16, env_int("VIREO_LDS_SLAB_VAR", 1024))), 1,
+                                  std::min(1024, std::max(16, env_int("VIREO_LDS_SLAB_VAR", 1024))), forms,
                                   lds0 != 1, &built);
             if (rc) return rc;
             if (built) {
@@ -914,7 +954,8 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
     // variant pass (whose per-range partials also cost the theta kernel a wider read) only
     // ties at 8-16 M and wins clearly at 100 M.
     const int lds = env_int("VIREO_LDS", -1);
-    const int cell_form = env_int("VIREO_CELL_FORM", 1);  // 1: AD/BD stream (any counts)
+    if (max_count >= 2048 && forms.auto_pair) forms = StreamForms{1, 2, false};
+    const int cell_form = forms.cell;  // 1: AD/BD stream (any counts)
     if ((max_count < 2048 || cell_form == 1) && lds != 0) {
         // cell pass: slabs of 512 W rows (128 KiB at K = 16); variant pass: 1024 ID rows
         if (lds == 1 || nnz >= (int64_t)env_int("VIREO_LDS_MIN_NNZ", 4000000)) {
@@ -926,7 +967,7 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
                 if (rc) return rc;
             }
         }
-        const int var_form = env_int("VIREO_VAR_FORM", 2);  // 2: AD / BD phases (any counts)
+        const int var_form = forms.var;  // 2: AD / BD phases (any counts)
         if ((var_form == 2 || max_count < 2048) &&
             (lds == 1 || nnz >= (int64_t)env_int("VIREO_LDS_MIN_NNZ_VAR", 32000000))) {
             rc = build_tiled(p->by_var, rptr.data(), ridx.data(), rval.data(), VRX_LDS_RW_VARIANT,
@@ -1981,6 +2022,17 @@ extern "C" int vrx_model_step(vrx_model* m, int32_t which, double* elbo_out) {
     return prof_drain(m);
 }
 
+#ifdef VRX_TIMING
+// scratch builds only: read and clear the per-pass cycle counters of vrx_spmm_lds
+extern "C" int vrx_debug_timing(unsigned long long* out16) {
+    VRX_HIP(hipDeviceSynchronize());
+    VRX_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(vrx_timing), 16 * sizeof(unsigned long long)));
+    unsigned long long z[16] = {};
+    VRX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(vrx_timing), z, sizeof z));
+    return VRX_OK;
+}
+#endif
+
 extern "C" int vrx_model_info(vrx_model* m, int32_t* info) {
     VRX_REQUIRE(m && info, "vrx_model_info: null argument");
     const Orient &v = m->p->by_var, &c = m->p->by_cell;
@@ -1997,7 +2049,9 @@ extern "C" int vrx_model_info(vrx_model* m, int32_t* info) {
     info[10] = v.tiled.ready ? (int32_t)(v.tiled.n_vrows - v.n_rows) : 0;
     info[11] = c.tiled.ready ? (int32_t)(c.tiled.n_vrows - c.n_rows) : 0;
     info[12] = c.tiled.ready ? c.tiled.form : 0;
-    info[13] = info[14] = info[15] = 0;
+    info[13] = v.tiled.ready ? v.tiled.form : 0;
+    info[14] = m->R;
+    info[15] = 0;
     return VRX_OK;
 }
 

@@ -342,6 +342,12 @@ constexpr int VRX_CHUNK = 256;  // entries per refill (64 lanes x 16 B of one LD
 #ifndef VRX_L2PF_AHEAD
 #define VRX_L2PF_AHEAD 2
 #endif
+// FORM 1 / 2: the ring words of a trip are read one trip ahead (a wave's stream is contiguous
+// across rounds and slabs, so the next trip is always U*G words further): the trip's critical
+// path has ONE LDS round trip (the slices) instead of two.
+#ifndef VRX_F1_PREFETCH
+#define VRX_F1_PREFETCH 0  // measured: 0.403 vs 0.391 ms (the four extra registers spill)
+#endif
 #ifndef VRX_LDS_PRIO
 #define VRX_LDS_PRIO 0
 #endif
@@ -383,6 +389,9 @@ constexpr int VRX_LDS_U = VRX_LDS_U_DEF;    // entries per trip and group; rows 
 // then their BD entries, accumulated into S2 = BD @ ID (SS = S1 + S2 at the store); each phase is
 // padded to its own longest row.  ~22 % more slots than the (ad, dp) pair words, but 7 instead of
 // ~15 vector instructions per slot, no conversions, and counts of any size.
+#ifdef VRX_TIMING
+__device__ unsigned long long vrx_timing[16];  // per pass: total, barrier 1, barrier 2, stage, waves
+#endif
 template <int LPE, int MODE, int RW, bool PADK, int SPLIT, int FORM = 0>
 __global__ __launch_bounds__(1024)
 #if VRX_LDS_L2PF
@@ -614,20 +623,47 @@ __global__ __launch_bounds__(1024)
         }
     };
 
+    uint32_t wn[U];  // (VRX_F1_PREFETCH) the words of the next trip
+    if (FORM != 0 && VRX_F1_PREFETCH) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) wn[u] = 0u;
+        if (stream_lo < stream_end) {
+            ring_need(stream_lo);
+            const uint32_t* rp = ring_g + (stream_lo & (VRX_RING - 1));
+#pragma unroll
+            for (int u = 0; u < U; ++u) wn[u] = rp[u * G];
+        }
+    }
     int bvec = bw[(int64_t)s_lo * NRV + min(lane, NRV)];
     slab_fetch(s_lo);
+#ifdef VRX_TIMING
+    unsigned long long tm_bar1 = 0, tm_bar2 = 0, tm_stage = 0;
+    const unsigned long long tm_start = __builtin_amdgcn_s_memtime();
+#define VRX_TM(var, stmt)                                            \
+    {                                                                \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        stmt;                                                        \
+        var += __builtin_amdgcn_s_memtime() - t_;                   \
+    }
+#else
+#define VRX_TM(var, stmt) stmt;
+#endif
     for (int s = s_lo; s < s_hi; ++s) {
-        __syncthreads();  // every wave is done reading the previous slab
+#ifndef VRX_X_NOBAR1
+        VRX_TM(tm_bar1, __syncthreads())  // every wave is done reading the previous slab
+#endif
 #ifdef VRX_X_NOSTAGE
         if (s == s_lo)
 #endif
-        slab_store();
+        VRX_TM(tm_stage, slab_store())
 #ifndef VRX_X_NOSTAGE
         if (s + 1 < s_hi) slab_fetch(s + 1);
 #endif
         const int bcur = bvec;
         if (s + 1 < s_hi) bvec = bw[(int64_t)(s + 1) * NRV + min(lane, NRV)];
-        __syncthreads();
+#ifndef VRX_X_NOBAR2
+        VRX_TM(tm_bar2, __syncthreads())
+#endif
 #pragma unroll
         for (int rv = 0; rv < NRV; ++rv) {
             const int r = rv / PH;
@@ -649,12 +685,27 @@ __global__ __launch_bounds__(1024)
                 // is no conversion: 3 VALU instructions of overhead per entry.
                 auto trip = [&](int at, auto ne_tag) {
                     constexpr int NE = decltype(ne_tag)::value;
+                    uint32_t w[NE];
+#if VRX_F1_PREFETCH
+#pragma unroll
+                    for (int u = 0; u < NE; ++u) w[u] = wn[u];
+                    {
+                        const int nx = at + U * G;  // (the slot of the chunk this trip ends may
+                        if (nx < stream_end) {      //  be refilled: its words are in registers)
+                            ring_need(nx);
+                            const uint32_t* rn = ring_g + (nx & (VRX_RING - 1));
+#pragma unroll
+                            for (int u = 0; u < U; ++u) wn[u] = rn[u * G];
+                        }
+                    }
+#else
 #ifndef VRX_X_NODMA
                     ring_need(at);
 #endif
                     const uint32_t* rp = ring_g + (at & (VRX_RING - 1));
-                    uint32_t w[NE];
-#ifdef VRX_X_NORING
+#endif
+#if VRX_F1_PREFETCH
+#elif defined(VRX_X_NORING)
 #pragma unroll
                     for (int u = 0; u < NE; ++u) w[u] = 0x3ff00000u | 32768u | (uint32_t)((at + u * 64 + g * 8) & 0xff80);
                     (void)rp;
@@ -673,18 +724,59 @@ __global__ __launch_bounds__(1024)
                     if (NE == 4) asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[NE - 1]));
                     if (NE == 3) asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[NE - 1]));
                     if (NE == 2) asm volatile("" : "+v"(w[0]), "+v"(w[NE - 1]));
+#ifdef VRX_X_NOREAD
 #pragma unroll
                     for (int u = 0; u < NE; ++u)
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
                             uint32_t a;
                             asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(a) : "v"(w[u]), "s"(0x3ff80u), "v"(qoff[q]));
-#ifdef VRX_X_NOREAD
                             x[u][q] = vrx_d2{(double)__uint_as_float(a), 1.0};
-#else
-                            asm volatile("ds_read_b128 %0, %1" : "=v"(x[u][q]) : "v"(a) : "memory");
-#endif
                         }
+#else
+                    // ONE statement per trip: between separate asm statements the compiler pads
+                    // with an s_nop.  Address = word offset bits | lane offset; two address
+                    // registers alternate (an LDS instruction reads its address when it issues).
+                    {
+                        uint32_t a0, a1;
+#define VRX_RD(X0, X1, W)                                    \
+    "v_and_or_b32 %[a0], " W ", %[msk], %[q0]\n\t"            \
+    "ds_read_b128 " X0 ", %[a0]\n\t"                         \
+    "v_and_or_b32 %[a1], " W ", %[msk], %[q1]\n\t"            \
+    "ds_read_b128 " X1 ", %[a1]\n\t"
+                        if constexpr (NE == 4)
+                            asm volatile(VRX_RD("%[x00]", "%[x01]", "%[w0]") VRX_RD("%[x10]", "%[x11]", "%[w1]")
+                                         VRX_RD("%[x20]", "%[x21]", "%[w2]") VRX_RD("%[x30]", "%[x31]", "%[w3]")
+                                         : [x00] "=&v"(x[0][0]), [x01] "=&v"(x[0][1]), [x10] "=&v"(x[1][0]),
+                                           [x11] "=&v"(x[1][1]), [x20] "=&v"(x[2][0]), [x21] "=&v"(x[2][1]),
+                                           [x30] "=&v"(x[NE - 1][0]), [x31] "=&v"(x[NE - 1][1]), [a0] "=&v"(a0), [a1] "=&v"(a1)
+                                         : [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[NE - 1]),
+                                           [msk] "s"(0x3ff80u), [q0] "v"(qoff[0]), [q1] "v"(qoff[1])
+                                         : "memory");
+                        else if constexpr (NE == 3)
+                            asm volatile(VRX_RD("%[x00]", "%[x01]", "%[w0]") VRX_RD("%[x10]", "%[x11]", "%[w1]")
+                                         VRX_RD("%[x20]", "%[x21]", "%[w2]")
+                                         : [x00] "=&v"(x[0][0]), [x01] "=&v"(x[0][1]), [x10] "=&v"(x[1][0]),
+                                           [x11] "=&v"(x[1][1]), [x20] "=&v"(x[NE - 1][0]), [x21] "=&v"(x[NE - 1][1]),
+                                           [a0] "=&v"(a0), [a1] "=&v"(a1)
+                                         : [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[NE - 1]),
+                                           [msk] "s"(0x3ff80u), [q0] "v"(qoff[0]), [q1] "v"(qoff[1])
+                                         : "memory");
+                        else if constexpr (NE == 2)
+                            asm volatile(VRX_RD("%[x00]", "%[x01]", "%[w0]") VRX_RD("%[x10]", "%[x11]", "%[w1]")
+                                         : [x00] "=&v"(x[0][0]), [x01] "=&v"(x[0][1]), [x10] "=&v"(x[NE - 1][0]),
+                                           [x11] "=&v"(x[NE - 1][1]), [a0] "=&v"(a0), [a1] "=&v"(a1)
+                                         : [w0] "v"(w[0]), [w1] "v"(w[NE - 1]),
+                                           [msk] "s"(0x3ff80u), [q0] "v"(qoff[0]), [q1] "v"(qoff[1])
+                                         : "memory");
+                        else
+                            asm volatile(VRX_RD("%[x00]", "%[x01]", "%[w0]")
+                                         : [x00] "=&v"(x[0][0]), [x01] "=&v"(x[0][1]), [a0] "=&v"(a0), [a1] "=&v"(a1)
+                                         : [w0] "v"(w[0]), [msk] "s"(0x3ff80u), [q0] "v"(qoff[0]), [q1] "v"(qoff[1])
+                                         : "memory");
+#undef VRX_RD
+                    }
+#endif
                     constexpr int H = NE > 2 ? 2 : NE;  // entries of the first half
                     if (NE > 2) {
                         if (NE == 4)
@@ -757,6 +849,15 @@ __global__ __launch_bounds__(1024)
     // (every issued chunk has been awaited by the walk; this only guards the invariant that no
     //  LDS-DMA write is in flight when the workgroup's LDS is released)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef VRX_TIMING
+    if (lane == 0) {
+        atomicAdd(&vrx_timing[MODE * 8 + 0], __builtin_amdgcn_s_memtime() - tm_start);
+        atomicAdd(&vrx_timing[MODE * 8 + 1], tm_bar1);
+        atomicAdd(&vrx_timing[MODE * 8 + 2], tm_bar2);
+        atomicAdd(&vrx_timing[MODE * 8 + 3], tm_stage);
+        atomicAdd(&vrx_timing[MODE * 8 + 4], 1ull);
+    }
+#endif
     // ---- every group holds the complete sums of its rows: store them ------------------------
     if (SPLIT > 1) {  // partial sums of the SPLIT entry streams: butterfly over the lanes
 #pragma unroll

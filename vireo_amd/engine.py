@@ -155,7 +155,7 @@ class DeviceModel:
                     ranges_variant=int(a[6]), ranges_cell=int(a[7]),
                     pad_variant=a[8] / 1000.0, pad_cell=a[9] / 1000.0,
                     extra_pieces_variant=int(a[10]), extra_pieces_cell=int(a[11]),
-                    cell_form=int(a[12]))
+                    cell_form=int(a[12]), var_form=int(a[13]), n_batch=int(a[14]))
 
     # ---- timing -----------------------------------------------------------------------
     def profile(self, enable=True):
