@@ -90,16 +90,18 @@ def c4_leg(counts, K, comm, n_init=32):
     phases, restarts.PHASES = restarts.PHASES, None
     stats = dict(W.LAST_SEARCH)
     # per-rank numbers -> rank-major arrays on every rank
-    keys = ["draw", "skip", "upload+normalise", "fit", "snapshot", "gather", "final_fit",
-            "download", "broadcast"]
+    keys = ["search_wall", "draw", "skip", "upload+normalise", "fit", "snapshot", "gather",
+            "final_fit", "download", "broadcast"]
     mine = np.array([wall, stats["restart_iterations"], stats["final_iterations"]] +
                     [phases.get(k, 0.0) for k in keys])
     allr = np.asarray(comm.allgather(mine)).reshape(comm.world, -1)
     wall_max = float(allr[:, 0].max())
     restart_its = int(allr[:, 1].sum())
     final_its = int(allr[:, 2].sum())
-    # the restart-shard phase ends when the slowest rank has fitted its share
-    shard = allr[:, 3:3 + 5].sum(axis=1)          # draw + skip + upload + fit + snapshot
+    # the restart-shard phase ends when the slowest rank has fitted its share (wall clock of
+    # the restart loop: the random draws run one restart ahead on a helper thread, so the
+    # draw / skip and the upload / fit phases below overlap)
+    shard = allr[:, 3]
     return dict(
         workload="c4: vireo_wrap(n_init=%d, max_iter_init=20, random_seed=1, no doublets) on the "
                  "c3 data, restart i on rank i %% %d" % (n_init, comm.world),

@@ -15,8 +15,10 @@ from ._lib import dptr, f64
 def _prior_rows(P, full_rows):
     """(array-or-None, rows) for a prior table: 0 = uniform (constant table), 1 = one
     broadcast row, full_rows = per-row table."""
+    if P is None:
+        return None, 0
     P = np.asarray(P, dtype=np.float64)
-    if P.size and np.all(P == P.flat[0]):
+    if P.size and P.min() == P.max():   # constant = uniform after normalisation
         return None, 0
     if P.shape[0] == 1:
         return f64(P), 1

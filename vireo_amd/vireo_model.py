@@ -79,18 +79,42 @@ class Vireo():
         self.theta_s2_prior = (1 - beta_mu_prior) * beta_sum_prior
 
         if ID_prior is None:
-            self.ID_prior = normalize(np.ones(self.ID_prob.shape))
+            self.ID_prior = None          # uniform; the array is formed when somebody reads it
         else:
             self.ID_prior = ID_prior[None, :] if len(ID_prior.shape) == 1 else ID_prior
 
         if GT_prior is None:
-            self.GT_prior = normalize(np.ones(self.GT_prob.shape))
+            self.GT_prior = None          # uniform, likewise
         else:
             if len(GT_prior.shape) == 2:
                 GT_prior = GT_prior[None, :, :]
             GT_prior[GT_prior < min_GP] = min_GP
             GT_prior[GT_prior > 1 - min_GP] = 1 - min_GP
             self.GT_prior = normalize(GT_prior)
+
+    # The default priors are uniform (vireo_model.py:120,127: normalize(np.ones(shape))).  The
+    # reference materialises them for every model -- 38 MB at c3 -- and the device would then
+    # read a log-prior table on every iteration; here "uniform" is kept as None until host code
+    # reads the attribute, and the device uses its scalar-prior kernels.
+    @property
+    def ID_prior(self):
+        if self._ID_prior is None:
+            self._ID_prior = normalize(np.ones((self.n_cell, self.n_donor)))
+        return self._ID_prior
+
+    @ID_prior.setter
+    def ID_prior(self, value):
+        self._ID_prior = value
+
+    @property
+    def GT_prior(self):
+        if self._GT_prior is None:
+            self._GT_prior = normalize(np.ones((self.n_var, self.n_donor, self.n_GT)))
+        return self._GT_prior
+
+    @GT_prior.setter
+    def GT_prior(self, value):
+        self._GT_prior = value
 
     def __getstate__(self):
         """plain NumPy state only (the reference ships models through multiprocessing.Pool,
@@ -132,11 +156,11 @@ class Vireo():
         return dm, counts
 
     def _set_device_prior(self, dm):
-        GT_prior = self.GT_prior
+        GT_prior = self._GT_prior         # None: uniform (never materialised)
         full = (self.n_var, self.n_donor, self.n_GT)
-        if GT_prior.shape[0] != 1 and GT_prior.shape != full:
+        if GT_prior is not None and GT_prior.shape[0] != 1 and GT_prior.shape != full:
             GT_prior = np.broadcast_to(GT_prior, full)
-        dm.set_prior(self.ID_prior, GT_prior, self.theta_s1_prior, self.theta_s2_prior)
+        dm.set_prior(self._ID_prior, GT_prior, self.theta_s1_prior, self.theta_s2_prior)
 
     def _pull(self, dm, want_GT=True):
         ID, GT, mu, sm = dm.get_state(want_GT=want_GT)

@@ -11,12 +11,16 @@ restarts (vireo_amd/restarts.py) and returns the winning model, ``_keep_n_donors
 ``_match_prior_subset`` / ``_match_prior_superset`` are the three optional re-fits, and
 ``_report`` / ``_result`` produce the reference's prints and its result dict.
 """
+import queue
 import sys
+import threading
+import time
 
 import numpy as np
 
 from .counts import device_counts
 from .dist import LocalComm, gather_restart_elbos, my_restarts
+from . import restarts as restarts_mod
 from .restarts import DeviceRestarts, LegacyStream, _phase, restart_batch
 from .vireo_base import donor_select, normalize, optimal_match
 from .vireo_doublet import predict_doublet
@@ -79,6 +83,44 @@ def _bcast_model(comm, model, root):
     model.ELBO_ = comm.bcast(trace, root)
 
 
+def _one_ahead(gen):
+    """Iterate ``gen`` with its next item being produced on a helper thread while the caller
+    works on the current one (the library calls on both sides release the GIL).  The helper has
+    finished -- or failed, and the error is re-raised here -- when the iteration ends."""
+    box = queue.Queue(maxsize=1)
+    stop = threading.Event()
+    done = object()
+
+    def produce():
+        try:
+            for item in gen:
+                while not stop.is_set():
+                    try:
+                        box.put(item, timeout=0.1)
+                        break
+                    except queue.Full:
+                        pass
+                if stop.is_set():
+                    return
+            box.put(done)
+        except BaseException as e:      # noqa: BLE001 -- handed to the consumer
+            box.put(e)
+
+    th = threading.Thread(target=produce, name="vireo-restart-draws", daemon=True)
+    th.start()
+    try:
+        while True:
+            item = box.get()
+            if item is done:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+    finally:
+        stop.set()
+        th.join()
+
+
 def _search(counts, plan, comm, max_iter_init, delay_fit_theta, kwargs, restarts_cls):
     """The n_init restarts (vireo_wrap.py:64-94): every rank walks the random stream of all of
     them, fits its own share, the ELBOs are all-gathered, the first maximum wins and its owner
@@ -98,21 +140,32 @@ def _search(counts, plan, comm, max_iter_init, delay_fit_theta, kwargs, restarts
     mine = set(my_restarts(plan.n_init, comm.rank, comm.world))
     batch = restart_batch(K, len(mine), counts.nnz) if hasattr(restarts_cls, "submit") else 1
     runner = restarts_cls(counts, tmpl, batch) if batch > 1 else restarts_cls(counts, tmpl)
-    local = {}
-    for im in range(plan.n_init):
-        if im in mine:
-            ID_raw = stream.rand(n_cell, K) if ID0 is None else None
-            GT_raw = stream.rand(n_var, K, T) if GT0 is None else None
-            args = (im, ID_raw, GT_raw, ID0, GT0_first if im == 0 else GT0, max_iter_init,
-                    delay_fit_theta)
-            if batch > 1:
-                runner.submit(*args)         # fitted `batch` at a time
+
+    def draws():
+        """this rank's restarts in order, each with what its constructor draws; the draws of
+        the other ranks' restarts are consumed without being formed"""
+        for im in range(plan.n_init):
+            if im in mine:
+                yield (im, stream.rand(n_cell, K) if ID0 is None else None,
+                       stream.rand(n_var, K, T) if GT0 is None else None)
             else:
-                local[im] = runner.run(*args)
+                stream.skip((n_cell * K if ID0 is None else 0) + (n_var * K * T if GT0 is None else 0))
+
+    local = {}
+    t_search = time.perf_counter()
+    # the generator runs one restart ahead on a helper thread: the Mersenne Twister (host, serial)
+    # and the fit (device) overlap; the helper is the only user of the stream meanwhile
+    for im, ID_raw, GT_raw in _one_ahead(draws()):
+        args = (im, ID_raw, GT_raw, ID0, GT0_first if im == 0 else GT0, max_iter_init,
+                delay_fit_theta)
+        if batch > 1:
+            runner.submit(*args)         # fitted `batch` at a time
         else:
-            stream.skip((n_cell * K if ID0 is None else 0) + (n_var * K * T if GT0 is None else 0))
+            local[im] = runner.run(*args)
     if batch > 1:
         local.update(runner.flush())
+    if restarts_mod.PHASES is not None:
+        restarts_mod.PHASES["search_wall"] = time.perf_counter() - t_search
     with _phase("gather"):
         elbo_all = gather_restart_elbos(comm, plan.n_init, local)
     best = int(np.argmax(elbo_all))              # first max wins, vireo_wrap.py:90-91
