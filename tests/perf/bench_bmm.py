@@ -26,3 +26,11 @@ print(json.dumps(dict(workload="c5 BinomMixtureVB N=200 x M=200000 K=8 nnz=%d" %
       ms_per_iteration=wall / steps * 1e3, passes_ms=dict(variant=pm[0] / max(pn[0], 1), cell=pm[1] / max(pn[1], 1), dense=pm[2] / steps),
       info=dm.info(), cpu_oracle_s_per_iteration=tc, speedup=steps / wall * tc,
       elbo_rel_err_first_iteration=abs(tr1[0] - e) / abs(e), host_s=dict(generate=tg, upload=tu))))
+# the whole BinomMixtureVB.fit (10 initialisations of up to 100 iterations + the final fit), one
+# initialisation at a time against the packed batches
+for batch in ("1", "0"):
+    os.environ["VIREO_RESTART_BATCH"] = batch
+    b = BinomMixtureVB(n_var=N, n_cell=M, n_donor=K)
+    t0 = time.perf_counter(); b.fit(counts, None, n_init=10, random_seed=1, verbose=False); dt = time.perf_counter() - t0
+    print(json.dumps(dict(fit="BinomMixtureVB.fit(n_init=10)", restart_batch="auto" if batch == "0" else 1,
+                          wall_s=round(dt, 3), ELBO_final=float(b.ELBO_iters[-1]), iterations_final_fit=len(b.ELBO_iters))))

@@ -714,3 +714,32 @@ def test_stream_form_follows_count_depth(va, monkeypatch, depth, want):
     O.vireo_fit(st, AD, DP, max_iter=8, min_iter=3)
     close(m.ELBO_, st.ELBO_, rtol=1e-9)
     close(m.ID_prob, st.ID_prob, rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("data", ["mito", "clone"])
+def test_bmm_fit_with_batched_initialisations(va, monkeypatch, capsys, data):
+    """BinomMixtureVB.fit runs its n_init short fits side by side in one device model
+    (bmm_model.py:241-252 runs them one after the other): same draws, same ELBO_inits, same
+    winner and final fit as one at a time"""
+    from vireo_amd import restarts
+    if data == "mito":
+        AD, DP = gold.mito()
+        K, kw = 3, dict(n_init=7, min_iter=10, max_iter_pre=40, random_seed=3)
+    else:
+        AD, DP = O.synth_clone(60, 3000, 5, seed=2)
+        K, kw = 5, dict(n_init=6, min_iter=5, max_iter_pre=30, random_seed=4)
+    fits = {}
+    for batch in ("1", "0"):                   # one at a time; automatic packing
+        monkeypatch.setenv("VIREO_RESTART_BATCH", batch)
+        b = va.BinomMixtureVB(n_var=AD.shape[0], n_cell=AD.shape[1], n_donor=K)
+        b.fit(AD, DP, **kw)
+        fits[batch] = (b, capsys.readouterr().out)
+    assert restarts.restart_batch(K, kw["n_init"], 10 ** 5) > 1
+    one, packed = fits["1"][0], fits["0"][0]
+    assert fits["1"][1] == fits["0"][1]        # the reference's warnings, in the same order
+    close(packed.ELBO_inits, one.ELBO_inits, rtol=1e-9)
+    assert np.argmax(packed.ELBO_inits) == np.argmax(one.ELBO_inits)
+    assert len(packed.ELBO_iters) == len(one.ELBO_iters)
+    close(packed.ELBO_iters, one.ELBO_iters, rtol=1e-9)
+    close(packed.ID_prob, one.ID_prob, rtol=1e-6, atol=1e-12)
+    close(packed.beta_mu, one.beta_mu, rtol=1e-8)

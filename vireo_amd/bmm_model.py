@@ -6,7 +6,8 @@ import numpy as np
 
 from . import _lib
 from .counts import device_counts
-from .engine import DeviceModel
+from .engine import DeviceBatch, DeviceModel
+from .restarts import restart_batch
 from .vireo_base import normalize
 
 
@@ -74,6 +75,9 @@ class BinomMixtureVB():
         shape = (self.n_var, self.n_donor)
         dm.set_state(self.ID_prob, None, np.broadcast_to(self.beta_mu, shape),
                      np.broadcast_to(self.beta_sum, shape))
+        self._push_prior(dm)
+
+    def _push_prior(self, dm):
         # a constant theta prior travels as one broadcast row
         s1, s2 = self.theta_s1_prior, self.theta_s2_prior
         if np.all(s1 == s1.flat[0]) and np.all(s2 == s2.flat[0]):
@@ -141,12 +145,53 @@ class BinomMixtureVB():
         if _dm is None:
             dm.close()
         if verbose:
-            for i in range(min_iter + 1, it + 1):
-                if trace[i] - trace[i - 1] < -1e-6:
-                    print("Warning: ELBO decreases %.8f to %.8f!\n" % (trace[i - 1], trace[i]))
-                elif i == max_iter - 1:
-                    print("Warning: VB did not converge!\n")
+            self._warn(trace, it, min_iter, max_iter)
         self.ELBO_iters = np.append(self.ELBO_iters, trace[:it])
+
+    @staticmethod
+    def _warn(trace, it, min_iter, max_iter):
+        """the reference's prints (bmm_model.py:192-197)"""
+        for i in range(min_iter + 1, it + 1):
+            if trace[i] - trace[i - 1] < -1e-6:
+                print("Warning: ELBO decreases %.8f to %.8f!\n" % (trace[i - 1], trace[i]))
+            elif i == max_iter - 1:
+                print("Warning: VB did not converge!\n")
+
+    def _fit_inits_batched(self, counts, dm, n_init, R, max_iter_pre, min_iter=20,
+                           epsilon_conv=1e-2, verbose=True):
+        """The n_init short fits of ``fit`` (bmm_model.py:241-252), R at a time in one device
+        model (vrx_model_cfg.n_batch): same draws in the same order, same prints, the best
+        state moves to ``dm`` on the device.  -> best (ID_prob, beta_mu, beta_sum, ELBO_iters)"""
+        db = DeviceBatch(counts, _lib.KIND_BMM, self.n_donor, R, fix_beta_sum=self.fix_beta_sum)
+        self._push_prior(db)
+        shape = (self.n_var, self.n_donor)
+        best_trace = None
+        for base in range(0, n_init, R):
+            ids = list(range(base, min(base + R, n_init)))
+            first = None
+            for slot in range(R):
+                if slot < len(ids):
+                    self.set_initial(self.beta_mu_init, self.beta_sum_init, self.ID_prob_init)
+                    state = (self.ID_prob, np.broadcast_to(self.beta_mu, shape),
+                             np.broadcast_to(self.beta_sum, shape))
+                    first = first or state
+                else:
+                    state = first          # idle slots repeat the batch's first restart
+                db.set_restart(slot, state[0], None, state[1], state[2])
+            traces, its, _ = db.fit(max_iter_pre, min_iter, epsilon_conv)
+            for slot, i in enumerate(ids):
+                trace, it = traces[slot], int(its[slot])
+                if verbose:
+                    self._warn(trace, it, min_iter, max_iter_pre)
+                self.ELBO_inits.append(trace[:it][-1])
+                if i == 0 or self.ELBO_inits[-1] > np.max(self.ELBO_inits[:-1]):
+                    db.copy_to(dm, slot)
+                    dm.snapshot()
+                    best_trace = trace[:it] + 0
+        db.close()
+        dm.restore()
+        self._pull(dm)
+        return (self.ID_prob, self.beta_mu, self.beta_sum, best_trace)
 
     def fit(self, AD, DP, n_init=10, max_iter=200, max_iter_pre=100,
             random_seed=None, **kwargs):
@@ -160,7 +205,10 @@ class BinomMixtureVB():
         const = counts.binom_const()
         dm = self._device_model(counts, None)
         self.ELBO_inits = []
-        for i in range(n_init):
+        R = restart_batch(self.n_donor, n_init, counts.nnz)
+        if R > 1:
+            best = self._fit_inits_batched(counts, dm, n_init, R, max_iter_pre, **kwargs)
+        for i in range(n_init if R == 1 else 0):
             self.set_initial(self.beta_mu_init, self.beta_sum_init, self.ID_prob_init)
             self._fit_BV(counts, None, max_iter=max_iter_pre, _dm=dm, **kwargs)
             self.ELBO_inits.append(self.ELBO_iters[-1])
