@@ -113,7 +113,9 @@ static int env_int(const char* name, int dflt) {
 // contracted index (nominal K = 16): 1, 2, 4, 8 or a multiple of 8
 static int pick_tiles(int64_t n_contract, double row_bytes, const char* env) {
     int t = env_int(env, 0);
-    if (t <= 0) t = (int)std::lround(n_contract * row_bytes / kSlabBytes);
+    // (an operand of up to two slabs still sits in one XCD's 4 MiB L2: one tile, and no rows
+    //  split over tiles whose slots need a second kernel to sum -- c2: 45.1 -> 42.7 us)
+    if (t <= 0) t = n_contract * row_bytes <= 2.0 * kSlabBytes ? 1 : (int)std::lround(n_contract * row_bytes / kSlabBytes);
     if (t <= 1) return 1;
     if (t <= kXcd) {
         int p = 1;
@@ -307,14 +309,14 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
     std::vector<int32_t> vrow_row((size_t)n_vrows);
     for (int64_t r = 0; r < o.n_rows; ++r)
         for (int32_t v = vptr[(size_t)r]; v < vptr[(size_t)r + 1]; ++v) vrow_row[(size_t)v] = (int32_t)r;
-    const int64_t tile_rows = 16 * (int64_t)RW;
+    const int64_t tile_rows = VRX_LDS_WAVES * (int64_t)RW;
     t.n_tile = (int)((n_vrows + tile_rows - 1) / tile_rows);
     // one workgroup per CU at a time (LDS), so the grid should fill whole rounds of CUs:
     // the largest n_range with n_tile * n_range <= target (4 rounds of 256 CUs by default)
     const int want = env_int(mode == 1 ? "VIREO_LDS_BLOCKS_CELL" : "VIREO_LDS_BLOCKS_VAR",
                              env_int("VIREO_LDS_BLOCKS", 1024));
     t.n_range = std::max(1, std::min(t.n_slab, want / std::max(1, t.n_tile)));
-    const int64_t n_wave = (int64_t)t.n_tile * 16;
+    const int64_t n_wave = (int64_t)t.n_tile * VRX_LDS_WAVES;
     const int PH = form == 2 ? 2 : 1;  // phases of a round (form 2: AD entries, then BD entries)
     const int64_t per_wave = (int64_t)t.n_slab * NR * PH + 1;
     std::vector<int64_t> wave_start((size_t)n_wave), wave_len((size_t)n_wave, 0);
@@ -348,7 +350,7 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
     // of the slab-local index (variant pass); none for the 256-B rows of the (ad, dp) cell pass
     const int bit_shift = form != 0 ? 7 : (mode == 0 ? 22 : -1);
     // form 1 words carry the LDS address of their half row: the slab starts behind the rings
-    const uint32_t f1_base = 16u * VRX_RING * 4u, pad_word = form != 0 ? f1_base : 0u;
+    const uint32_t f1_base = (uint32_t)VRX_LDS_WAVES * VRX_RING * 4u, pad_word = form != 0 ? f1_base : 0u;
     // FORM 1 value field: the top 14 bits of the IEEE double (sign, exponent, 2 mantissa bits).
     // A value with more than three significant bits becomes several entries (9 = 8 + 1, ...).
     auto push_value = [](std::vector<uint32_t>& out, int64_t v, uint32_t off) {
@@ -1611,11 +1613,11 @@ static int launch_lds_one(const Orient& o, hipStream_t s, const double* X, int K
         constexpr int CPL = 16 / LPE;  // columns per lane: LDS rows hold whole lanes
         const bool f2 = MODE == 0 && t.form == 2;  // 128-B LDS rows whatever K
         const size_t lds = (size_t)t.slab_rows * (f1 ? 256 : f2 ? 128 : (kb + CPL - 1) / CPL * CPL * (MODE == 1 ? 16 : 8)) +
-                           16 * VRX_RING * 4;
+                           VRX_LDS_WAVES * VRX_RING * 4;
         auto kern = lds_kernel<LPE, MODE>(kb, K > 16, t.rw, t.form);
         VRX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        kern<<<grid, 1024, lds, s>>>(t.ent.p, t.wave_start.p, t.bnd.p, t.rowmap.p, t.n_slab,
+        kern<<<grid, VRX_LDS_WAVES * 64, lds, s>>>(t.ent.p, t.wave_start.p, t.bnd.p, t.rowmap.p, t.n_slab,
                                      t.slab_rows, o.n_contract, t.n_vrows,
                                      X + (size_t)c0 * (f1 ? 1 : XD), kb, K, dst + (size_t)c0 * NV, ctl, R);
         VRX_HIP(hipGetLastError());

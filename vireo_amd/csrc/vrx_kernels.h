@@ -345,6 +345,11 @@ constexpr int VRX_CHUNK = 256;  // entries per refill (64 lanes x 16 B of one LD
 // FORM 1 / 2: the ring words of a trip are read one trip ahead (a wave's stream is contiguous
 // across rounds and slabs, so the next trip is always U*G words further): the trip's critical
 // path has ONE LDS round trip (the slices) instead of two.
+// waves per workgroup of the LDS-resident passes (16: one 160-KiB workgroup per CU; 8: two
+// 80-KiB workgroups per CU whose barrier / staging phases overlap -- experimental builds)
+#ifndef VRX_LDS_WAVES
+#define VRX_LDS_WAVES 16
+#endif
 #ifndef VRX_F1_PREFETCH
 #define VRX_F1_PREFETCH 0  // measured: 0.403 vs 0.391 ms (the four extra registers spill)
 #endif
@@ -393,7 +398,7 @@ constexpr int VRX_LDS_U = VRX_LDS_U_DEF;    // entries per trip and group; rows 
 __device__ unsigned long long vrx_timing[16];  // per pass: total, barrier 1, barrier 2, stage, waves
 #endif
 template <int LPE, int MODE, int RW, bool PADK, int SPLIT, int FORM = 0>
-__global__ __launch_bounds__(1024)
+__global__ __launch_bounds__(VRX_LDS_WAVES * 64)
 #if VRX_LDS_L2PF
     __attribute__((amdgpu_num_vgpr(120)))
 #endif
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(1024)
     const int slab_doubles = slab_rows * KP * XD;
     // LDS = [16 entry rings][slab]: the rings first, so that the LDS-DMA destinations stay
     // below 64 KiB
-    double* slab = reinterpret_cast<double*>(vrx_smem + 16 * VRX_RING * 4);
+    double* slab = reinterpret_cast<double*>(vrx_smem + VRX_LDS_WAVES * VRX_RING * 4);
     uint32_t* ring = reinterpret_cast<uint32_t*>(vrx_smem) + wave * VRX_RING;
     const int tile = blockIdx.x;
     // contracted range of this workgroup: slabs split as evenly as possible over gridDim.y
@@ -454,7 +459,7 @@ __global__ __launch_bounds__(1024)
     static_assert(LPE % SPLIT == 0 && U % SPLIT == 0, "split");
     const int g = lane / LPE, sub = (lane % LPE) / LPR, kl = lane % LPR;
     const bool kok = kl * CP < K;  // a lane's 4 columns may start (or run) past K
-    const int64_t wid = (int64_t)tile * 16 + wave;
+    const int64_t wid = (int64_t)tile * VRX_LDS_WAVES + wave;
     const int32_t* bw = bnd + wid * ((int64_t)n_slab * NRV + 1);
     const uint32_t* stream = ent + wave_start[wid];
     // byte offset, inside a dense row, of the q-th 16-B slice this lane reads (rotated by g)
@@ -479,7 +484,8 @@ __global__ __launch_bounds__(1024)
     // unit's column never changes and nothing is divided inside the loop.
     double2 pf[PF];
     const int upr = KP * XD / 2;  // 16-B units per LDS row
-    const int padT = 1024 / upr * upr, j0 = threadIdx.x % upr, r0 = threadIdx.x / upr;
+    constexpr int NT = VRX_LDS_WAVES * 64;  // threads of the workgroup
+    const int padT = NT / upr * upr, j0 = threadIdx.x % upr, r0 = threadIdx.x / upr;
     const int rstep = padT / upr;
     const bool pad_act = (int)threadIdx.x < padT;
     auto slab_fetch = [&](int s) {
@@ -490,7 +496,7 @@ __global__ __launch_bounds__(1024)
             const double2* src = reinterpret_cast<const double2*>(X + row0 * K * XD);
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
-                const int at = threadIdx.x + i * 1024;
+                const int at = threadIdx.x + i * NT;
                 pf[i] = at < n16 ? src[at] : make_double2(0.0, 0.0);
             }
         } else {
@@ -522,7 +528,7 @@ __global__ __launch_bounds__(1024)
             const int n16 = slab_doubles / 2;
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
-                const int at = threadIdx.x + i * 1024;
+                const int at = threadIdx.x + i * NT;
                 if (at < n16) dst[at] = pf[i];
             }
         } else {
@@ -876,7 +882,7 @@ __global__ __launch_bounds__(1024)
     if (kok && sub == 0) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            const int64_t row = rowmap[((int64_t)tile * 16 + wave) * RW + r * G + g];
+            const int64_t row = rowmap[((int64_t)tile * VRX_LDS_WAVES + wave) * RW + r * G + g];
             if (row >= 0) {  // tile position -> row (rows are dealt to rounds by length)
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
