@@ -1093,6 +1093,8 @@ struct vrx_model {
     int64_t prior_rows = 1;
     // reductions
     int nb_theta = 0, nb_nk = 0, nb_cell = 0, nb_throws = 0, n_th_part = 1;
+    int nb_gt = 0;               // blocks (= KL_GT partials) of the grid-stride vrx_gt_update
+    bool theta_pending = false;  // stage-1 partials wait for the finalisation inside vrx_gt_update
     DevBuf<double> part_theta, part_gt, part_cell, part_th;
     DevBuf<double> d_elbo, d_parts;
     DevBuf<int32_t> ctl;  // device-side loop control (VRX_CTL_*)
@@ -1218,6 +1220,7 @@ extern "C" int vrx_model_create(vrx_problem* p, const vrx_model_cfg* cfg, vrx_mo
     m->nb_cell = (int)((m->M * m->KP + VRX_BLOCK - 1) / VRX_BLOCK);
     m->nb_throws = (int)((m->N + VRX_BLOCK - 1) / VRX_BLOCK);
     m->nb_theta = std::min(m->nb_nk, p->n_cu * 4);
+    m->nb_gt = std::min(m->nb_nk, p->n_cu * 8);
     VRX_HIP(m->part_cell.alloc((size_t)m->R * m->nb_cell * 2));
     VRX_HIP(m->part_gt.alloc((size_t)m->R * m->nb_nk));
     VRX_HIP(hipMemsetAsync(m->part_gt.p, 0, (size_t)m->R * m->nb_nk * sizeof(double), s));
@@ -1733,8 +1736,9 @@ static int resolve_LID(vrx_model* m) {
     return VRX_OK;
 }
 
-// theta update (update=1) or just psi/KL from the current beta (update=0)
-static int theta_step(vrx_model* m, int update) {
+// theta update (update=1) or just psi/KL from the current beta (update=0).  defer_final: the
+// caller runs gt_step next, whose kernel finalises the shared theta itself (VrxThetaFuse).
+static int theta_step(vrx_model* m, int update, bool defer_final = false) {
     ProfScope ps(m, VRX_KERN_DENSE);
     hipStream_t s = m->p->stream;
     const auto& c = m->cfg;
@@ -1764,9 +1768,17 @@ static int theta_step(vrx_model* m, int update) {
             VRX_HIP(hipGetLastError());
             m->s_pending = false;
         }
-        vrx_theta_final<<<m->R, VRX_BLOCK, 0, s>>>(m->nb_theta, m->T, update, c.fix_beta_sum,
-                                                 m->part_theta.p, m->prior1.p, m->prior2.p, m->mu.p,
-                                                 m->sm.p, m->psi.p, m->part_th.p, m->ctl.p);
+        // Worth it only while the partials are few: every block of vrx_gt_update re-reads them
+        // (c2, 157 partials: 43.4 -> 41.9 us per iteration; c3, 1024 partials = 128 KB per
+        // block: 0.994 -> 1.012 ms, so large problems keep the separate one-block kernel).
+        static const int fuse_max = env_int("VIREO_FUSE_THETA_MAX_PARTS", 256);
+        if (update && defer_final && m->nb_theta <= fuse_max) {
+            m->theta_pending = true;
+        } else {
+            vrx_theta_final<<<m->R, VRX_BLOCK, 0, s>>>(m->nb_theta, m->T, update, c.fix_beta_sum,
+                                                     m->part_theta.p, m->prior1.p, m->prior2.p,
+                                                     m->mu.p, m->sm.p, m->psi.p, m->part_th.p, m->ctl.p);
+        }
         m->w_valid = false;
     }
     VRX_HIP(hipGetLastError());
@@ -1780,10 +1792,24 @@ static int gt_step(vrx_model* m, int learn) {
         int rc = resolve_S(m);
         if (rc) return rc;
     }
-    vrx_gt_update<<<dim3(m->nb_nk, m->R), VRX_BLOCK, 0, m->p->stream>>>(
+    VrxThetaFuse F{};
+    if (m->theta_pending) {
+        F.on = 1;
+        F.n_part = m->nb_theta;
+        F.fix_sum = m->cfg.fix_beta_sum;
+        F.part = m->part_theta.p;
+        F.prior1 = m->prior1.p;
+        F.prior2 = m->prior2.p;
+        F.mu = m->mu.p;
+        F.sm = m->sm.p;
+        F.psi = m->psi.p;
+        F.kl_out = m->part_th.p;
+        m->theta_pending = false;
+    }
+    vrx_gt_update<<<dim3(m->nb_gt, m->R), VRX_BLOCK, 0, m->p->stream>>>(
         m->NK, m->K, m->T, learn, m->cfg.ase_mode, m->N, reinterpret_cast<const double2*>(m->S.p),
         m->psi.p, m->logq_gt.p, m->gt_mode, -std::log((double)m->T), m->GT.p, m->W.p, m->wform,
-        m->part_gt.p, m->batch(), m->ctl.p);
+        m->part_gt.p, F, m->batch(), m->ctl.p);
     VRX_HIP(hipGetLastError());
     m->w_valid = true;
     return VRX_OK;
@@ -1795,7 +1821,7 @@ static VrxElboIn elbo_inputs(vrx_model* m) {
     e.gt_part = m->part_gt.p;
     e.th_part = m->part_th.p;
     e.n_cell_part = m->nb_cell;
-    e.n_gt_part = m->cfg.kind == VRX_KIND_VIREO ? m->nb_nk : 0;
+    e.n_gt_part = m->cfg.kind == VRX_KIND_VIREO ? m->nb_gt : 0;
     e.n_th_part = m->n_th_part;
     e.elbo = m->d_elbo.p;
     e.parts = m->d_parts.p;
@@ -1858,7 +1884,7 @@ static int enqueue_iteration(vrx_model* m, bool do_theta, const VrxStopRule& rul
         if (do_theta) {
             if ((rc = variant_pass(m, true))) return rc;  // range sum fused into the theta kernel
             have_s = true;
-            if ((rc = theta_step(m, 1))) return rc;
+            if ((rc = theta_step(m, 1, true))) return rc;  // (a gt_step always follows)
         }
         if (c.learn_gt) {
             // the reference recomputes AD@ID_prob, DP@ID_prob here (vireo_model.py:207-208);

@@ -1137,10 +1137,17 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_partial(
         double2 s;
         if (n_range > 0) {
             s = make_double2(0.0, 0.0);
-            for (int r = 0; r < n_range; ++r) {
-                const double2 v = ranges[(int64_t)r * NKt + j];
-                s.x += v.x;
-                s.y += v.y;
+            for (int r0 = 0; r0 < n_range; r0 += 8) {  // (loads of 8 ranges in flight together)
+                double2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v[u] = r0 + u < n_range ? ranges[(int64_t)(r0 + u) * NKt + j] : make_double2(0.0, 0.0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (r0 + u < n_range) {
+                        s.x += v[u].x;
+                        s.y += v[u].y;
+                    }
             }
             S[j] = s;
         } else {
@@ -1219,22 +1226,55 @@ __device__ __forceinline__ void vrx_store_w(double* W, int wform, int64_t n, int
 // Thread per (variant, donor).  learn == 0: GT is fixed, only W (and the KL) are derived.
 // gt_mode: 0 uniform prior (scalar log 1/T), 1 one (K,T) slab, 2 full (N,K,T).
 // ------------------------------------------------------------------------------------
+// The shared-theta finalisation folded into this kernel (on != 0; never in ASE mode): every block
+// sums the stage-1 partials of vrx_theta_partial in the same fixed order -- identical values in
+// every block -- and takes psi from its own shared memory; block 0 also writes beta_mu,
+// beta_sum, psi and KL_theta to global memory.  One launch (vrx_theta_final: one block of pure
+// latency) and one kernel boundary less per iteration.
+struct VrxThetaFuse {  // by value
+    int on, n_part, fix_sum;
+    const double *part, *prior1, *prior2;
+    double *mu, *sm, *psi, *kl_out;
+};
+
+// Grid-stride over the (variant, donor) pairs: gridDim.x blocks, gridDim.x KL partials.
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_gt_update(
     int64_t NK, int K, int T, int learn, int ase, int64_t N, const double2* __restrict__ S,
-    const double* __restrict__ psi, const double* __restrict__ logq, int gt_mode, double logq_uni,
+    const double* psi, const double* __restrict__ logq, int gt_mode, double logq_uni,
     double* __restrict__ GT, double* __restrict__ W, int wform, double* __restrict__ kl_part,
-    VrxBatch B, const int32_t* __restrict__ ctl) {
+    VrxThetaFuse F, VrxBatch B, const int32_t* __restrict__ ctl) {
 #pragma clang fp contract(off)
     const int rb = blockIdx.y;
     if (ctl[rb * VRX_CTL_WORDS + VRX_CTL_STOP]) return;
-    const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    __shared__ double th_ms[2 * VRX_MAXT], th_psi[3 * VRX_MAXT], th_kl[1];
+    const double* psi_r = psi + (int64_t)rb * 3 * (ase ? N : 1) * T;
+    if (F.on) {
+        if ((int)threadIdx.x < T) {
+            th_ms[threadIdx.x] = F.mu[rb * T + threadIdx.x];
+            th_ms[VRX_MAXT + threadIdx.x] = F.sm[rb * T + threadIdx.x];
+        }
+        __syncthreads();
+        vrx_theta_final_block(F.n_part, T, 1, F.fix_sum, F.part + (int64_t)rb * F.n_part * 2 * VRX_MAXT,
+                              F.prior1, F.prior2, th_ms, th_ms + VRX_MAXT, th_psi, th_kl);
+        __syncthreads();
+        if (blockIdx.x == 0) {  // the one writer of the new state
+            if ((int)threadIdx.x < T) {
+                F.mu[rb * T + threadIdx.x] = th_ms[threadIdx.x];
+                F.sm[rb * T + threadIdx.x] = th_ms[VRX_MAXT + threadIdx.x];
+            }
+            if ((int)threadIdx.x < 3 * T) F.psi[rb * 3 * T + threadIdx.x] = th_psi[threadIdx.x];
+            if (threadIdx.x == 0) F.kl_out[rb] = th_kl[0];
+        }
+        psi_r = th_psi;
+    }
     double kl[1] = {0.0};
-    if (i < NK) {
+    for (int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x; i < NK;
+         i += (int64_t)gridDim.x * VRX_BLOCK) {
         const int64_t n = i / K;
         const int k = (int)(i - n * K);
         const int64_t j = n * B.Kt + (int64_t)rb * K + k;  // this restart's column of S / GT / W
         const int64_t rows = ase ? N : 1, pr = ase ? n : 0;
-        const double* pb = psi + (int64_t)rb * 3 * rows * T;
+        const double* pb = psi_r;
         const double* p1 = pb + pr * T;
         const double* p2 = pb + (rows + pr) * T;
         const double* ps = pb + (2 * rows + pr) * T;
@@ -1497,8 +1537,19 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_cell_softmax(
     double* Lr = LID + row0;
     if (live && n_range > 0)
         for (int k = kl; k < K; k += KP) {
+            // the loads of 8 ranges are issued together (one memory round trip instead of 8);
+            // the additions keep the range order
             double t = 0.0;
-            for (int r = 0; r < n_range; ++r) t += ranges[(int64_t)r * M * B.Kt + row0 + k];
+            const double* src = ranges + row0 + k;
+            const int64_t stride = M * B.Kt;
+            for (int r0 = 0; r0 < n_range; r0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = r0 + u < n_range ? src[(int64_t)(r0 + u) * stride] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (r0 + u < n_range) t += v[u];
+            }
             Lr[k] = t;
         }
     const double* qr = id_mode == 2 ? logq + (live ? cell : 0) * (int64_t)K : logq;
