@@ -219,13 +219,13 @@ def main():
     c4 = c2 = None
     if not args.no_c4 and args.config == "c3":
         c4 = c4_leg(counts, K, comm)
-        if rank == 0:
+        if rank == 0 and world == 1:
             c2 = c2_leg(local)
 
     # whole-protocol parity + CPU baseline (rank 0): the same fit on the GPU and on the oracle
     parity = None
     cpu = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:     # (N = 1 only: the other ranks would wait)
         np.random.seed(1)
         dev = Vireo(n_var=N, n_cell=M, n_donor=K)
         tg = time.perf_counter()
