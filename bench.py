@@ -91,7 +91,7 @@ def c4_leg(counts, K, comm, n_init=32):
     stats = dict(W.LAST_SEARCH)
     # per-rank numbers -> rank-major arrays on every rank
     keys = ["search_wall", "draw", "skip", "upload+normalise", "fit", "snapshot", "gather",
-            "final_fit", "download", "broadcast"]
+            "final_fit", "download", "broadcast", "template", "device_models"]
     mine = np.array([wall, stats["restart_iterations"], stats["final_iterations"]] +
                     [phases.get(k, 0.0) for k in keys])
     allr = np.asarray(comm.allgather(mine)).reshape(comm.world, -1)

@@ -61,6 +61,24 @@ def test_binom_const(va):
         assert va.device_counts(fmt(AD), fmt(DP)).binom_const() == g["c1"]
 
 
+@pytest.mark.parametrize("stray", [0, 3])
+def test_binom_const_is_numpys_float32_sum(va, stray):
+    """the constant of Vireo.fit (vireo_model.py:313) over several of NumPy's 8192-element
+    buffers, summed on the device in NumPy's order: equal to the oracle's np.sum bit for bit;
+    stray > 0 plants AD entries outside DP's pattern (dp == 0: skipped by the reference's mask,
+    which moves the buffer boundaries)"""
+    AD, DP = O.synth_donor(900, 700, 4, 0.06, seed=8)          # ~37 k entries: 4 buffers + a tail
+    if stray:
+        A, D = AD.toarray(), DP.toarray()
+        holes = np.argwhere(D == 0)[:: max(1, (D == 0).sum() // stray)][:stray]
+        for r, c in holes:
+            A[r, c] = 2
+        AD, DP = csc_matrix(A), csc_matrix(D)
+    assert AD.nnz > 4 * 8192 or DP.nnz > 4 * 8192
+    c = va.device_counts(AD, DP).binom_const()
+    assert c.dtype == np.float32 and c == np.float32(O.binom_const(AD, DP))
+
+
 def test_onestep_each_update(va):
     g = gold.load("c1_onestep")
     AD, DP = gold.c1()

@@ -1000,9 +1000,10 @@ extern "C" int vrx_problem_binom_const(vrx_problem* p, double* sum_out) {
         VRX_HIP(hipSetDevice(p->device));
         const Orient& o = p->by_var;
         const int64_t n = o.nnz;
-        std::vector<float> h((size_t)n);
+        float total = 0.f;
         if (n > 0) {
-            DevBuf<float> terms;
+            DevBuf<float> terms, sums;
+            DevBuf<int32_t> flag;
             VRX_HIP(terms.alloc((size_t)n));
             const unsigned nb = (unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK);
             if (o.fmt == VRX_FMT_P32)
@@ -1012,15 +1013,44 @@ extern "C" int vrx_problem_binom_const(vrx_problem* p, double* sum_out) {
             else
                 vrx_binom_terms<VRX_FMT_WIDE><<<nb, VRX_BLOCK, 0, p->stream>>>(n, o.ent.p, terms.p);
             VRX_HIP(hipGetLastError());
-            VRX_HIP(hipMemcpyAsync(h.data(), terms.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost,
-                                   p->stream));
+            // NumPy sums 8192 elements at a time: the full buffers are summed on the device in
+            // its order, their sums and the last partial buffer are added on the host.  A NaN
+            // mark (an entry with dp == 0, which the reference's DP > 0 mask skips) shifts the
+            // buffer boundaries: then all terms come back and are compacted first.
+            const int64_t n_chunk = n / 8192, tail = n - n_chunk * 8192;
+            std::vector<float> hs((size_t)n_chunk), ht((size_t)tail);
+            int32_t has_nan = 0;
+            VRX_HIP(flag.alloc(1));
+            VRX_HIP(hipMemsetAsync(flag.p, 0, sizeof(int32_t), p->stream));
+            if (n_chunk > 0) {
+                VRX_HIP(sums.alloc((size_t)n_chunk));
+                vrx_np_chunk_sums_f32<<<(unsigned)n_chunk, 64, 0, p->stream>>>(n_chunk, terms.p, sums.p, flag.p);
+                VRX_HIP(hipGetLastError());
+                VRX_HIP(hipMemcpyAsync(hs.data(), sums.p, (size_t)n_chunk * sizeof(float),
+                                       hipMemcpyDeviceToHost, p->stream));
+            }
+            if (tail > 0)
+                VRX_HIP(hipMemcpyAsync(ht.data(), terms.p + n_chunk * 8192, (size_t)tail * sizeof(float),
+                                       hipMemcpyDeviceToHost, p->stream));
+            VRX_HIP(hipMemcpyAsync(&has_nan, flag.p, sizeof(int32_t), hipMemcpyDeviceToHost, p->stream));
             VRX_HIP(hipStreamSynchronize(p->stream));
+            for (float v : ht) has_nan |= v != v;
+            if (!has_nan) {
+                for (float v : hs) total += v;
+                float t = 0.f;
+                if (vrx_np_sum_f32(ht.data(), tail, &t)) return VRX_ERR_ARG;
+                if (tail > 0) total += t;
+            } else {
+                std::vector<float> h((size_t)n);
+                VRX_HIP(hipMemcpyAsync(h.data(), terms.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost,
+                                       p->stream));
+                VRX_HIP(hipStreamSynchronize(p->stream));
+                int64_t m = 0;
+                for (int64_t i = 0; i < n; ++i)
+                    if (h[(size_t)i] == h[(size_t)i]) h[(size_t)m++] = h[(size_t)i];  // drop the marks
+                if (vrx_np_sum_f32(h.data(), m, &total)) return VRX_ERR_ARG;
+            }
         }
-        int64_t m = 0;
-        for (int64_t i = 0; i < n; ++i)
-            if (h[(size_t)i] == h[(size_t)i]) h[(size_t)m++] = h[(size_t)i];  // drop the dp == 0 marks
-        float total = 0.f;
-        if (vrx_np_sum_f32(h.data(), m, &total)) return VRX_ERR_ARG;
         p->binom_sum = (double)total;
         p->binom_done = true;
     }

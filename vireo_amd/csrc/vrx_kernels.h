@@ -1638,6 +1638,42 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_normalize_rows(int64_t rows, in
 // ------------------------------------------------------------------------------------
 // per-entry terms in storage order; entries with dp == 0 (never indexed by the reference's
 // DP > 0 mask) are marked with a NaN
+// NumPy's float32 sum of one full iterator buffer (8192 elements): pairwise_sum splits in
+// halves down to blocks of 128, a block is eight running sums combined as
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) (numpy/_core/src/umath/loops_utils.h.src; the host
+// restatement is np_pairwise_sum_f32 in vrx_host.cpp).  One wave per buffer: lane = block of
+// 128, then the binary tree over the 64 block sums.  Also flags NaN marks (dp == 0 entries).
+__global__ __launch_bounds__(64) void vrx_np_chunk_sums_f32(int64_t n_chunk, const float* __restrict__ a,
+                                                            float* __restrict__ sums, int32_t* has_nan) {
+#pragma clang fp contract(off)
+    __shared__ float sh[64];
+    const int64_t c = blockIdx.x;
+    if (c >= n_chunk) return;
+    const float* p = a + c * 8192 + (int64_t)threadIdx.x * 128;
+    float r[8];
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        r[j] = p[j];
+        bad = bad || r[j] != r[j];
+    }
+    for (int i = 8; i < 128; i += 8)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = p[i + j];
+            bad = bad || v != v;
+            r[j] += v;
+        }
+    sh[threadIdx.x] = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    __syncthreads();
+    for (int w = 1; w < 64; w <<= 1) {
+        if ((threadIdx.x & (2 * w - 1)) == 0) sh[threadIdx.x] = sh[threadIdx.x] + sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[c] = sh[0];
+    if (bad) atomicOr(has_nan, 1);
+}
+
 template <int FMT>
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_binom_terms(int64_t nnz,
                                                              const uint32_t* __restrict__ ent,

@@ -127,7 +127,8 @@ def _search(counts, plan, comm, max_iter_init, delay_fit_theta, kwargs, restarts
     refines it (unless extra donors are still to be dropped) and broadcasts the state."""
     n_var, n_cell = counts.shape
     K, T = plan.search_donors, kwargs.get("n_GT", 3)
-    tmpl = _template(counts, K, plan.learn_GT, plan.search_prior, kwargs)
+    with _phase("template"):
+        tmpl = _template(counts, K, plan.learn_GT, plan.search_prior, kwargs)
     # what one reference constructor draws, in its order (vireo_model.py:98,103)
     fixed_ID = kwargs.get("ID_prob_init")
     ID0 = None if fixed_ID is None else normalize(fixed_ID, axis=1)
@@ -139,7 +140,8 @@ def _search(counts, plan, comm, max_iter_init, delay_fit_theta, kwargs, restarts
     stream = LegacyStream()
     mine = set(my_restarts(plan.n_init, comm.rank, comm.world))
     batch = restart_batch(K, len(mine), counts.nnz) if hasattr(restarts_cls, "submit") else 1
-    runner = restarts_cls(counts, tmpl, batch) if batch > 1 else restarts_cls(counts, tmpl)
+    with _phase("device_models"):
+        runner = restarts_cls(counts, tmpl, batch) if batch > 1 else restarts_cls(counts, tmpl)
 
     def draws():
         """this rank's restarts in order, each with what its constructor draws; the draws of
