@@ -32,6 +32,11 @@ inline uint32_t mt_twist(uint32_t u, uint32_t v) {
 
 // one regeneration of the state, in place; every loop's reads are either of words the loop
 // does not write or lie >= 227 words behind its writes, so the loops vectorise
+// (compiled for AVX-512 / AVX2 / baseline x86-64 and picked at load time: the build flags
+//  stay generic)
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+__attribute__((target_clones("avx512f", "avx2", "default")))
+#endif
 void mt_regen(uint32_t* __restrict__ k) {
     uint32_t nxt[MT_N + 1];
     std::memcpy(nxt, k, sizeof(uint32_t) * MT_N);
