@@ -150,6 +150,11 @@ def main():
     ap.add_argument("--no-c4", action="store_true", help="skip the n_init=32 restart-shard leg")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line: libraries that print on the C stdout (librccl's
+    # version banner sits in the stdio buffer until exit) get stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -334,7 +339,7 @@ def main():
         }
         if cpu:
             out["speedup_vs_cpu_1core"] = out["value"] / cpu["value"]
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if isinstance(comm, vdist.RcclComm):
         comm.barrier()
         comm.close()

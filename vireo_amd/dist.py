@@ -14,6 +14,7 @@ three methods: tests/gloo_comm.py)
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -53,7 +54,19 @@ class RcclComm:
             raw = exchange(None)
         uid = (C.c_uint8 * _lib.UNIQUE_ID_BYTES).from_buffer_copy(raw)
         self._h = C.c_void_p()
-        _lib.check(_lib.lib().vrx_comm_create(device, rank, world, uid, C.byref(self._h)))
+        # librccl prints a version banner on the C stdout of rank 0 when a communicator is
+        # made; callers that emit machine-readable output there (bench.py: ONE JSON line) must
+        # not see it, so stdout points at stderr for the duration of the call
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            rc = _lib.lib().vrx_comm_create(device, rank, world, uid, C.byref(self._h))
+        finally:
+            C.CDLL(None).fflush(None)
+            os.dup2(keep, 1)
+            os.close(keep)
+        _lib.check(rc)
 
     def allgather(self, local):
         local = _lib.f64(local).ravel()
