@@ -25,56 +25,64 @@ from .vireo_base import optimal_match
 from .vireo_wrap import vireo_wrap
 
 
+# The reference's option surface (vireo.py:35-88): same flags, destinations, types and
+# defaults; the help texts are this package's own.
+#   (flags, dest, kind, default, help)      kind: None = string, int, or "flag" = store_true
+_MAIN_OPTIONS = [
+    (("--cellData", "-c"), "cell_data", None, None,
+     "cell genotypes: a cellSNP output folder (sparse matrices) or a VCF file"),
+    (("--nDonor", "-N"), "n_donor", int, None,
+     "donors in the pool; may exceed the number of donors in the donor VCF"),
+    (("--outDir", "-o"), "out_dir", None, None,
+     "output folder [default: <cell data>/vireo]"),
+]
+_INPUT_OPTIONS = [
+    (("--vartrixData",), "vartrix_data", None, None,
+     "vartrix output instead of --cellData: alt.mtx,ref.mtx,barcodes.tsv[,SNPs.vcf.gz]"),
+    (("--donorFile", "-d"), "donor_file", None, None,
+     "donor genotypes (VCF; subset samples and regions with bcftools beforehand)"),
+    (("--genoTag", "-t"), "geno_tag", None, "PL",
+     "FORMAT tag holding the donor genotypes: GT, GP or PL [default: %default]"),
+]
+_MODEL_OPTIONS = [
+    (("--noDoublet",), "no_doublet", "flag", False, "skip the doublet step"),
+    (("--nInit", "-M"), "n_init", int, 50,
+     "random restarts when genotypes are learned [default: %default]"),
+    (("--extraDonor",), "n_extra_donor", int, 0,
+     "additional donors searched for first and dropped afterwards [default: %default]"),
+    (("--extraDonorMode",), "extra_donor_mode", None, "distance",
+     "which of the extra donors to drop: 'size' (fewest cells) or 'distance' (closest "
+     "genotypes) [default: %default]"),
+    (("--forceLearnGT",), "force_learnGT", "flag", False,
+     "use the donor genotypes as a prior only and learn them"),
+    (("--ASEmode",), "ASE_mode", "flag", False, "one allelic ratio per variant"),
+    (("--noPlot",), "no_plot", "flag", False,
+     "accepted; vireo_amd never draws the genotype-distance figure"),
+    (("--randSeed",), "rand_seed", int, None, "seed of the restarts [default: %default]"),
+    (("--cellRange",), "cell_range", "str", None, "cells to process, e.g. 0-10000 [default: all]"),
+    (("--callAmbientRNAs",), "check_ambient", "flag", False,
+     "not available in vireo_amd (experimental upstream)"),
+    (("--nproc", "-p"), "nproc", int, 1,
+     "accepted; the restarts run on the GPU [default: %default]"),
+]
+
+
 def build_parser():
-    """the reference's option surface (vireo.py:35-88), flag for flag"""
-    p = OptionParser()
-    p.add_option("--cellData", "-c", dest="cell_data", default=None,
-                 help="The cell genotype file in VCF format or cellSNP folder with sparse "
-                      "matrices.")
-    p.add_option("--nDonor", "-N", type="int", dest="n_donor", default=None,
-                 help="Number of donors to demultiplex; can be larger than provided in "
-                      "donor_file")
-    p.add_option("--outDir", "-o", dest="out_dir", default=None,
-                 help="Dirtectory for output files [default: $cellFilePath/vireo]")
-    g0 = OptionGroup(p, "Optional input files")
-    g0.add_option("--vartrixData", dest="vartrix_data", default=None,
-                  help="The cell genotype files in vartrix outputs (three/four files, comma "
-                       "separated): alt.mtx,ref.mtx,barcodes.tsv,SNPs.vcf.gz. This will "
-                       "suppress cellData argument.")
-    g0.add_option("--donorFile", "-d", dest="donor_file", default=None,
-                  help="The donor genotype file in VCF format. Please filter the sample and "
-                       "region with bcftools -s and -R first!")
-    g0.add_option("--genoTag", "-t", dest="geno_tag", default='PL',
-                  help="The tag for donor genotype: GT, GP, PL [default: %default]")
-    g1 = OptionGroup(p, "Optional arguments")
-    g1.add_option("--noDoublet", dest="no_doublet", action="store_true", default=False,
-                  help="If use, not checking doublets.")
-    g1.add_option("--nInit", "-M", type="int", dest="n_init", default=50,
-                  help="Number of random initializations, when GT needs to learn "
-                       "[default: %default]")
-    g1.add_option("--extraDonor", type=int, dest="n_extra_donor", default=0,
-                  help="Number of extra donor in pre-cluster, when GT needs to learn "
-                       "[default: %default]")
-    g1.add_option("--extraDonorMode", dest="extra_donor_mode", default="distance",
-                  help="Method for searching from extra donors. size: n_cell per donor; "
-                       "distance: GT distance between donors [default: %default]")
-    g1.add_option("--forceLearnGT", dest="force_learnGT", default=False, action="store_true",
-                  help="If use, treat donor GT as prior only.")
-    g1.add_option("--ASEmode", dest="ASE_mode", default=False, action="store_true",
-                  help="If use, turn on SNP specific allelic ratio.")
-    g1.add_option("--noPlot", dest="no_plot", default=False, action="store_true",
-                  help="If use, turn off plotting GT distance (always off in vireo_amd).")
-    g1.add_option("--randSeed", type="int", dest="rand_seed", default=None,
-                  help="Seed for random initialization [default: %default]")
-    g1.add_option("--cellRange", type="str", dest="cell_range", default=None,
-                  help="Range of cells to process, eg. 0-10000 [default: all]")
-    g1.add_option("--callAmbientRNAs", dest="check_ambient", default=False,
-                  action="store_true", help="Not supported by vireo_amd (experimental upstream)")
-    g1.add_option("--nproc", "-p", type="int", dest="nproc", default=1,
-                  help="Accepted for compatibility; restarts run on the GPU [default: %default]")
-    p.add_option_group(g0)
-    p.add_option_group(g1)
-    return p
+    parser = OptionParser()
+
+    def declare(target, table):
+        for flags, dest, kind, default, text in table:
+            extra = dict(action="store_true") if kind == "flag" else (
+                {} if kind is None else dict(type=kind))
+            target.add_option(*flags, dest=dest, default=default, help=text, **extra)
+
+    declare(parser, _MAIN_OPTIONS)
+    for title, table in (("Optional input files", _INPUT_OPTIONS),
+                         ("Optional arguments", _MODEL_OPTIONS)):
+        group = OptionGroup(parser, title)
+        declare(group, table)
+        parser.add_option_group(group)
+    return parser
 
 
 def load_cells(options):
