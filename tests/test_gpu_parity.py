@@ -643,7 +643,7 @@ def _independent_fits(va, counts, N, M, K, n, seed, **fit):
 
 
 @pytest.mark.parametrize("K,R,lds", [(4, 4, True), (4, 3, True), (3, 5, True), (16, 2, True),
-                                     (4, 4, False), (2, 16, False)])
+                                     (4, 4, False), (2, 16, False), (16, 3, False), (7, 5, False)])
 def test_restart_batch_equals_independent_fits(va, monkeypatch, K, R, lds):
     """vrx_model_cfg.n_batch: R restarts in one device model (one sparse pass for all of them,
     per-restart theta / trace / stop rule) == R independent fits from the same draws.  On the
