@@ -1600,32 +1600,36 @@ static auto lds_kernel_rw(int K, bool strided) {
     const bool pad = K % (16 / LPE) != 0 || strided;
     if constexpr (LPE >= 4)
         if (split == 4)
-            return pad ? vrx_spmm_lds<LPE, MODE, RW, true, 4> : vrx_spmm_lds<LPE, MODE, RW, false, 4>;
+            return pad ? vrx_spmm_lds<LPE, MODE, RW, 1, 4> : vrx_spmm_lds<LPE, MODE, RW, 0, 4>;
     if constexpr (LPE >= 2)
         if (split == 2)
-            return pad ? vrx_spmm_lds<LPE, MODE, RW, true, 2> : vrx_spmm_lds<LPE, MODE, RW, false, 2>;
-    return pad ? vrx_spmm_lds<LPE, MODE, RW, true, 1> : vrx_spmm_lds<LPE, MODE, RW, false, 1>;
+            return pad ? vrx_spmm_lds<LPE, MODE, RW, 1, 2> : vrx_spmm_lds<LPE, MODE, RW, 0, 2>;
+    return pad ? vrx_spmm_lds<LPE, MODE, RW, 1, 1> : vrx_spmm_lds<LPE, MODE, RW, 0, 1>;
 }
 
 // the AD/BD form of the cell pass (FORM 1): one instance for K = 16, one that stages
 // element-wise and masks its stores for every other K / column block
+// (pad: 0 flat rows of 16 columns, 1 element-wise, 2 whole 16-B units -- see the kernel)
 template <int RW>
-static auto lds_kernel_form1(bool pad) {
-    return pad ? vrx_spmm_lds<VRX_LDS_LPE, 1, RW, true, 1, 1> : vrx_spmm_lds<VRX_LDS_LPE, 1, RW, false, 1, 1>;
+static auto lds_kernel_form1(int pad) {
+    return pad == 0   ? vrx_spmm_lds<VRX_LDS_LPE, 1, RW, 0, 1, 1>
+           : pad == 1 ? vrx_spmm_lds<VRX_LDS_LPE, 1, RW, 1, 1, 1>
+                      : vrx_spmm_lds<VRX_LDS_LPE, 1, RW, 2, 1, 1>;
 }
 
 // rows per wave: the pass default, or (cell pass) the shorter tile of short_tile_pays()
 template <int LPE, int MODE>
-static auto lds_kernel(int K, bool strided, int rw, int form) {
+static auto lds_kernel(int K, int ld, bool strided, int rw, int form) {
+    // AD/BD forms: flat rows, or whole 16-B units (even K and row stride), or element-wise
+    const int pad = K == 16 && !strided ? 0 : ((K | ld) & 1) == 0 ? 2 : 1;
     if (MODE == 1 && form == 1) {
-        const bool pad = K != 16 || strided;
         return rw == VRX_LDS_RW_CELL_SHORT ? lds_kernel_form1<VRX_LDS_RW_CELL_SHORT>(pad)
                                            : lds_kernel_form1<VRX_LDS_RW_CELL>(pad);
     }
     if (MODE == 0 && form == 2) {
-        const bool pad = K != 16 || strided;
-        return pad ? vrx_spmm_lds<VRX_LDS_LPE, 0, VRX_LDS_RW_VARIANT, true, 1, 2>
-                   : vrx_spmm_lds<VRX_LDS_LPE, 0, VRX_LDS_RW_VARIANT, false, 1, 2>;
+        return pad == 0   ? vrx_spmm_lds<VRX_LDS_LPE, 0, VRX_LDS_RW_VARIANT, 0, 1, 2>
+               : pad == 1 ? vrx_spmm_lds<VRX_LDS_LPE, 0, VRX_LDS_RW_VARIANT, 1, 1, 2>
+                          : vrx_spmm_lds<VRX_LDS_LPE, 0, VRX_LDS_RW_VARIANT, 2, 1, 2>;
     }
     if (MODE == 1 && rw == VRX_LDS_RW_CELL_SHORT)
         return lds_kernel_rw<LPE, MODE, MODE == 1 ? VRX_LDS_RW_CELL_SHORT : VRX_LDS_RW_VARIANT>(K, strided);
@@ -1647,7 +1651,7 @@ static int launch_lds_one(const Orient& o, hipStream_t s, const double* X, int K
         const bool f2 = MODE == 0 && t.form == 2;  // 128-B LDS rows whatever K
         const size_t lds = (size_t)t.slab_rows * (f1 ? 256 : f2 ? 128 : (kb + CPL - 1) / CPL * CPL * (MODE == 1 ? 16 : 8)) +
                            VRX_LDS_WAVES * VRX_RING * 4;
-        auto kern = lds_kernel<LPE, MODE>(kb, K > 16, t.rw, t.form);
+        auto kern = lds_kernel<LPE, MODE>(kb, K, K > 16, t.rw, t.form);
         VRX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         kern<<<grid, VRX_LDS_WAVES * 64, lds, s>>>(t.ent.p, t.wave_start.p, t.bnd.p, t.rowmap.p, t.n_slab,

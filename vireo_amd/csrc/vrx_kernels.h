@@ -397,7 +397,11 @@ constexpr int VRX_LDS_U = VRX_LDS_U_DEF;    // entries per trip and group; rows 
 #ifdef VRX_TIMING
 __device__ unsigned long long vrx_timing[16];  // per pass: total, barrier 1, barrier 2, stage, waves
 #endif
-template <int LPE, int MODE, int RW, bool PADK, int SPLIT, int FORM = 0>
+// PADK: 0 = rows of exactly 16 contiguous columns (flat slab copy); 1 = any K / row stride
+// (element-wise staging into zero-padded rows, masked stores); 2 = AD/BD forms with even K and
+// even row stride (column blocks of wider operands, restart batches, K = 2 ... 14): as 1, but
+// a 16-B unit is either whole or absent, so it is staged with one load.
+template <int LPE, int MODE, int RW, int PADK, int SPLIT, int FORM = 0>
 __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
 #if VRX_LDS_L2PF
     __attribute__((amdgpu_num_vgpr(120)))
@@ -500,25 +504,53 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
                 pf[i] = at < n16 ? src[at] : make_double2(0.0, 0.0);
             }
         } else {
+            // 32-bit offsets from one wave-uniform base (scalar base + vector offset loads): the
+            // unit's column, its masks and the row stride are per-thread constants
             const double* src = X + row0 * ld * XD;  // (FORM 1: planar rows of 2 * ld doubles)
+            const int rows32 = (int)rows;
+            // even K and even row stride (column blocks of a wider operand, restart batches,
+            // K = 2, 4, ... 14): a unit is either whole or absent and 16-B aligned -> one load
+            if (PADK == 2) {
+                const int cc = FORM == 1 ? 2 * (j0 & 7) : 2 * j0;
+                const bool m0 = cc < K;
+                const int off0 = FORM == 1 ? r0 * 2 * ld + (j0 >> 3) * ld + cc : r0 * ld + cc;
+                const int step = FORM == 1 ? rstep * 2 * ld : rstep * ld;
 #pragma unroll
-            for (int i = 0; i < PF; ++i) {
-                const int row = r0 + i * rstep;
-                double2 v = make_double2(0.0, 0.0);
-                if (pad_act && row < rows) {
-                    if (FORM == 1) {  // unit j0 = columns 2*(j0 & 7), +1 of half j0 >> 3
-                        const int cc = 2 * (j0 & 7);
-                        const double* sr = src + (int64_t)row * 2 * ld + (j0 >> 3) * ld + cc;
-                        if (cc < K) v.x = sr[0];
-                        if (cc + 1 < K) v.y = sr[1];
-                    } else if (MODE == 1) {  // unit j0 = (w1, w2) of column j0
-                        if (j0 < K) v = reinterpret_cast<const double2*>(src)[row * ld + j0];
-                    } else {  // unit j0 = columns 2*j0, 2*j0 + 1
-                        if (2 * j0 < K) v.x = src[row * ld + 2 * j0];
-                        if (2 * j0 + 1 < K) v.y = src[row * ld + 2 * j0 + 1];
-                    }
+                for (int i = 0; i < PF; ++i) {
+                    const bool in = pad_act && m0 && r0 + i * rstep < rows32;
+                    pf[i] = in ? *reinterpret_cast<const double2*>(src + off0 + i * step) : make_double2(0.0, 0.0);
                 }
-                pf[i] = v;
+            } else if (FORM == 1) {  // unit j0 = columns 2*(j0 & 7), +1 of half j0 >> 3
+                const int cc = 2 * (j0 & 7);
+                const bool m0 = cc < K, m1 = cc + 1 < K;
+                const int off0 = r0 * 2 * ld + (j0 >> 3) * ld + cc, step = rstep * 2 * ld;
+#pragma unroll
+                for (int i = 0; i < PF; ++i) {
+                    const bool in = pad_act && r0 + i * rstep < rows32;
+                    double2 v;
+                    v.x = in && m0 ? src[off0 + i * step] : 0.0;
+                    v.y = in && m1 ? src[off0 + i * step + 1] : 0.0;
+                    pf[i] = v;
+                }
+            } else if (MODE == 1) {  // unit j0 = (w1, w2) of column j0
+                const bool m0 = j0 < K;
+                const int off0 = r0 * ld + j0, step = rstep * ld;
+#pragma unroll
+                for (int i = 0; i < PF; ++i) {
+                    const bool in = pad_act && m0 && r0 + i * rstep < rows32;
+                    pf[i] = in ? reinterpret_cast<const double2*>(src)[off0 + i * step] : make_double2(0.0, 0.0);
+                }
+            } else {  // unit j0 = columns 2*j0, 2*j0 + 1
+                const bool m0 = 2 * j0 < K, m1 = 2 * j0 + 1 < K;
+                const int off0 = r0 * ld + 2 * j0, step = rstep * ld;
+#pragma unroll
+                for (int i = 0; i < PF; ++i) {
+                    const bool in = pad_act && r0 + i * rstep < rows32;
+                    double2 v;
+                    v.x = in && m0 ? src[off0 + i * step] : 0.0;
+                    v.y = in && m1 ? src[off0 + i * step + 1] : 0.0;
+                    pf[i] = v;
+                }
             }
         }
     };
@@ -891,7 +923,10 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
                         double* o = dst + row * ld + 2 * slice;
                         if (!PADK)
                             *reinterpret_cast<double2*>(o) = make_double2(acc[r][q][0], acc[r][q][1]);
-                        else {
+                        else if (PADK == 2) {  // even K and stride: the pair is whole or absent
+                            if (2 * slice < K)
+                                *reinterpret_cast<double2*>(o) = make_double2(acc[r][q][0], acc[r][q][1]);
+                        } else {
                             if (2 * slice < K) o[0] = acc[r][q][0];
                             if (2 * slice + 1 < K) o[1] = acc[r][q][1];
                         }

@@ -70,10 +70,13 @@ class LegacyStream:
 
 
 def restart_batch(n_donor, n_owned, nnz):
-    """How many restarts share one device model.  The LDS-resident passes compute 16 columns per
-    sweep of the entry stream whatever n_donor is, so restarts are packed until the 16 columns
+    """How many restarts share one device model (vrx_model_cfg.n_batch).  A sweep of the entry
+    stream computes 16 columns whatever n_donor is, so restarts are packed until the 16 columns
     are full; a problem small enough to be bound by kernel launches rather than by the stream
-    takes a full batch of 16.  VIREO_RESTART_BATCH overrides (1 = one restart at a time)."""
+    takes a full batch of 16.  Wider batches were measured and do not pay: at n_donor = 16 four
+    restarts per model save 8 % per iteration (shared dense kernels) and lose it again because a
+    batch runs until its slowest restart stops (c4: 0.59 s either way).
+    VIREO_RESTART_BATCH overrides (1 = one restart at a time)."""
     forced = int(os.environ.get("VIREO_RESTART_BATCH", "0"))
     if forced > 0:
         return max(1, min(forced, 16, n_owned))

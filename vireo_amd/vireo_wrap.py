@@ -83,11 +83,11 @@ def _bcast_model(comm, model, root):
     model.ELBO_ = comm.bcast(trace, root)
 
 
-def _one_ahead(gen):
-    """Iterate ``gen`` with its next item being produced on a helper thread while the caller
-    works on the current one (the library calls on both sides release the GIL).  The helper has
+def _one_ahead(gen, depth=1):
+    """Iterate ``gen`` with its next ``depth`` items being produced on a helper thread while the
+    caller works on the current one (the library calls on both sides release the GIL).  The helper has
     finished -- or failed, and the error is re-raised here -- when the iteration ends."""
-    box = queue.Queue(maxsize=1)
+    box = queue.Queue(maxsize=max(1, depth))
     stop = threading.Event()
     done = object()
 
@@ -157,7 +157,7 @@ def _search(counts, plan, comm, max_iter_init, delay_fit_theta, kwargs, restarts
     t_search = time.perf_counter()
     # the generator runs one restart ahead on a helper thread: the Mersenne Twister (host, serial)
     # and the fit (device) overlap; the helper is the only user of the stream meanwhile
-    for im, ID_raw, GT_raw in _one_ahead(draws()):
+    for im, ID_raw, GT_raw in _one_ahead(draws(), depth=batch):
         args = (im, ID_raw, GT_raw, ID0, GT0_first if im == 0 else GT0, max_iter_init,
                 delay_fit_theta)
         if batch > 1:
