@@ -205,7 +205,7 @@ class BinomMixtureVB():
         const = counts.binom_const()
         dm = self._device_model(counts, None)
         self.ELBO_inits = []
-        R = restart_batch(self.n_donor, n_init, counts.nnz)
+        R = restart_batch(self.n_donor, n_init, counts.nnz, wide=False)
         if R > 1:
             best = self._fit_inits_batched(counts, dm, n_init, R, max_iter_pre, **kwargs)
         for i in range(n_init if R == 1 else 0):

@@ -69,21 +69,31 @@ class LegacyStream:
             self._advance(None, n)
 
 
-def restart_batch(n_donor, n_owned, nnz):
-    """How many restarts share one device model (vrx_model_cfg.n_batch).  A sweep of the entry
-    stream computes 16 columns whatever n_donor is, so restarts are packed until the 16 columns
-    are full; a problem small enough to be bound by kernel launches rather than by the stream
-    takes a full batch of 16.  Wider batches were measured and do not pay: at n_donor = 16 four
-    restarts per model save 8 % per iteration (shared dense kernels) and lose it again because a
-    batch runs until its slowest restart stops (c4: 0.59 s either way).
+def restart_batch(n_donor, n_owned, nnz, wide=True):
+    """How many restarts share one device model (vrx_model_cfg.n_batch).
+
+    A sweep of the entry stream computes 16 columns whatever n_donor is; restarts packed side by
+    side fill whole sweeps.  Cost of a restart-iteration in sweeps, from the measurements in
+    DESIGN.md section 4.4: ceil(R * n_donor / 16) sweeps -- 1.25x each when the column count is odd
+    (element-wise staging of the dense operand) -- divided by R, plus 10 % for a batch running
+    until its slowest restart has stopped.  The smallest R within 5 % of the best wins
+    (n_donor = 16: 1; 12: 4; 8: 2; 5: 6; 4: 4).  ``wide`` = False (pair-word streams, whose
+    column-block kernels are not tuned for strided operands): at most one sweep.  A problem small
+    enough to be bound by kernel launches rather than by the stream takes a full batch of 16.
     VIREO_RESTART_BATCH overrides (1 = one restart at a time)."""
     forced = int(os.environ.get("VIREO_RESTART_BATCH", "0"))
     if forced > 0:
         return max(1, min(forced, 16, n_owned))
-    fill = max(1, 16 // n_donor)
     if nnz * n_donor < (1 << 24):
-        fill = 16
-    return max(1, min(fill, n_owned))
+        return max(1, min(16, n_owned))
+    if not wide:
+        return max(1, min(16 // n_donor, n_owned))
+    costs = {}
+    for R in range(1, min(n_owned, 8) + 1):
+        cols = R * n_donor
+        costs[R] = -(-cols // 16) * (1.25 if cols & 1 else 1.0) * (1.1 if R > 1 else 1.0) / R
+    best = min(costs.values())
+    return min(R for R, c in costs.items() if c <= 1.05 * best)
 
 
 class DeviceRestarts:
@@ -93,7 +103,9 @@ class DeviceRestarts:
     restarts are collected with ``submit`` and fitted ``batch`` at a time by one
     ``DeviceBatch`` (every sparse pass serves all of them); ``flush`` returns their ELBOs."""
 
-    def __init__(self, counts, template, batch=1):
+    def __init__(self, counts, template, batch=None, n_owned=1):
+        """batch = None: chosen by ``restart_batch`` for ``n_owned`` restarts and the stream
+        words this problem uses"""
         self.counts = counts
         self.t = template
         shape = dict(n_gt=template.n_GT, learn_gt=template.learn_GT,
@@ -101,6 +113,11 @@ class DeviceRestarts:
                      fix_beta_sum=template.fix_beta_sum)
         self.dm = DeviceModel(counts, _lib.KIND_VIREO, template.n_donor, **shape)
         template._set_device_prior(self.dm)
+        if batch is None:
+            info = self.dm.info()
+            ad_bd = (not info["lds_cell"] and not info["lds_variant"]) or (
+                info["cell_form"] == 1 and info["var_form"] == 2)
+            batch = restart_batch(template.n_donor, n_owned, counts.nnz, wide=ad_bd)
         self.batch = int(batch)
         self.db = None
         if self.batch > 1:

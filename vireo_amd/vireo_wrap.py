@@ -21,7 +21,7 @@ import numpy as np
 from .counts import device_counts
 from .dist import LocalComm, gather_restart_elbos, my_restarts
 from . import restarts as restarts_mod
-from .restarts import DeviceRestarts, LegacyStream, _phase, restart_batch
+from .restarts import DeviceRestarts, LegacyStream, _phase
 from .vireo_base import donor_select, normalize, optimal_match
 from .vireo_doublet import predict_doublet
 from .vireo_model import Vireo
@@ -139,9 +139,12 @@ def _search(counts, plan, comm, max_iter_init, delay_fit_theta, kwargs, restarts
         GT0_first, GT0 = tmpl.GT_prob.copy(), normalize(plan.search_prior)
     stream = LegacyStream()
     mine = set(my_restarts(plan.n_init, comm.rank, comm.world))
-    batch = restart_batch(K, len(mine), counts.nnz) if hasattr(restarts_cls, "submit") else 1
     with _phase("device_models"):
-        runner = restarts_cls(counts, tmpl, batch) if batch > 1 else restarts_cls(counts, tmpl)
+        if hasattr(restarts_cls, "submit"):       # packs restarts into one device model
+            runner = restarts_cls(counts, tmpl, n_owned=len(mine))
+            batch = runner.batch
+        else:
+            runner, batch = restarts_cls(counts, tmpl), 1
 
     def draws():
         """this rank's restarts in order, each with what its constructor draws; the draws of
