@@ -276,6 +276,21 @@ int vrx_merge_counts(int64_t n_var, int64_t n_cell, const void* ad_ptr, const vo
 int vrx_mtx_read(const char* path, int64_t nnz, int32_t* row, int32_t* col, int32_t* val,
                  int n_threads);
 
+/* ---- text writers of the command (host only) ----------------------------------------------
+ * vrx_write_table: prob_singlet.tsv / prob_doublet.tsv of write_donor_id (io_utils.py:147-170):
+ * `header`, then per row its label and `cols` numbers in the printf format `fmt` ("%.2e"), tab
+ * separated.  vrx_write_vcf_records: the donor genotype VCF of write_VCF (vcf_utils.py:234-296)
+ * with the tags GT:AD:DP:PL -- `head`, then per variant its prefix (fixed columns + FORMAT) and
+ * per sample <0/0|1/0|1/1>:AD:DP:PL,PL,PL from integer arrays.  gz != 0 writes gzip (one member
+ * per chunk of rows).  Chunks are formatted and deflated on several threads. */
+int vrx_write_table(const char* path, const char* header, const char* names,
+                    const int64_t* name_off /* rows + 1 */, const double* table, int64_t rows,
+                    int64_t cols, const char* fmt, int32_t gz);
+int vrx_write_vcf_records(const char* path, const char* head, const char* prefix,
+                          const int64_t* prefix_off /* n_var + 1 */, const int8_t* call,
+                          const int64_t* ad, const int64_t* dp, const int64_t* pl /* [..][3] */,
+                          int64_t n_var, int64_t n_sample, int32_t gz);
+
 #ifdef __cplusplus
 }
 #endif

@@ -293,3 +293,43 @@ def test_float32_sum_is_numpys():
                                     ctypes.byref(out)))
         assert np.float32(out.value) == np.sum(a), a.size
     assert np.float32(out.value) != 0
+
+
+@pytest.mark.parametrize("chunk_bytes", [None, "2000"])
+def test_native_text_writers_format_like_python(tmp_path, monkeypatch, chunk_bytes):
+    """prob_*.tsv.gz (io_utils.py:147-170) and the donor genotype VCF (vcf_utils.py:234-296) come
+    out of the library's threaded writers byte for byte as the reference's Python formatting
+    produces them -- also when the rows are cut into many chunks (one gzip member each)"""
+    import gzip
+    from vireo_amd import io_utils, vcf_utils
+    if chunk_bytes:
+        monkeypatch.setenv("VIREO_WRITER_CHUNK_BYTES", chunk_bytes)
+    rng = np.random.default_rng(0)
+    M, K = 257, 5
+    names = ["CELL%d-1" % i for i in range(M)]
+    T = rng.random((M, K)) ** 8
+    T[3, 2], T[4, 1], T[5, 0], T[6, 0], T[7, 3] = 0.0, 1.0, 1e-300, np.nan, 9.995e-5
+    header = ["cell"] + ["donor%d" % i for i in range(K)]
+    io_utils._write_table_gz(str(tmp_path / "t.tsv.gz"), header, names, T)
+    want = "\t".join(header) + "\n" + "".join(
+        "\t".join([names[i]] + ["%.2e" % x for x in T[i]]) + "\n" for i in range(M))
+    assert gzip.open(tmp_path / "t.tsv.gz", "rt").read() == want
+    io_utils._write_table_gz(str(tmp_path / "e.tsv.gz"), ["cell"], names, np.zeros((M, 0)))
+    assert gzip.open(tmp_path / "e.tsv.gz", "rt").read() == "cell\n" + "".join(n + "\n" for n in names)
+
+    N = 123
+    GT = rng.dirichlet([0.3, 0.3, 0.3], (N, K))
+    GT[2, 1] = [1.0, 0.0, 0.0]                       # floored at 1e-10 -> PL 100
+    AD = rng.random((N, K)) * 50
+    geno = vcf_utils.GenoINFO_maker(GT.copy(), AD, AD + rng.random((N, K)) * 30)
+    fixed = {c: [str(x) for x in (["1"] * N if c == "CHROM" else range(N))]
+             for c in ["CHROM", "POS", "ID", "REF", "ALT", "QUAL", "FILTER", "INFO"]}
+    dat = dict(comments=["##fileformat=VCFv4.2", "##FORMAT=<ID=GT,old>", "##contig=<ID=1>"],
+               samples=["s%d" % i for i in range(K)], variants=["v%d" % i for i in range(N)],
+               FixedINFO=fixed, GenoINFO=geno)
+    vcf_utils.write_VCF(str(tmp_path / "a.vcf.gz"), dat)
+    plain = dict(dat, GenoINFO={k: geno[k] for k in ("GT", "AD", "DP", "PL")})   # the reference's lists
+    assert plain["GenoINFO"]["PL"][2][1] == "0,100,100"
+    vcf_utils.write_VCF(str(tmp_path / "b.vcf.gz"), plain)
+    fast, slow = (gzip.open(tmp_path / f, "rt").read() for f in ("a.vcf.gz", "b.vcf.gz"))
+    assert fast == slow and fast.count("\n") == N + 7

@@ -532,3 +532,164 @@ extern "C" int vrx_merge_counts(int64_t n_var, int64_t n_cell, const void* ad_pt
         }
     return VRX_OK;
 }
+
+// ------------------------------------------------------------------------------------
+// Text writers of the command (vireoSNP/utils/io_utils.py:147-170 prob_singlet.tsv /
+// prob_doublet.tsv; vcf_utils.py:234-296 the donor genotype VCF).  The reference formats every
+// number with a Python "%" expression inside nested loops; at 50 k cells x 120 donor pairs or
+// 100 k variants x 16 donors that is where a run spends its time once the fit takes a fraction
+// of a second.  Here rows are cut into chunks, every chunk is formatted (and deflated, each
+// chunk one gzip member: concatenated members are one valid gzip file) on its own thread, and
+// the chunks are written in order.  Same bytes as the reference's text, number for number:
+// "%.2e" of glibc and of CPython are both correctly rounded.
+// ------------------------------------------------------------------------------------
+#include <zlib.h>
+
+#include <functional>
+
+namespace {
+int writer_threads() {
+    const char* v = getenv("VIREO_HOST_THREADS");
+    int n = v && *v ? atoi(v) : (int)std::thread::hardware_concurrency();
+    return std::max(1, std::min(n, 32));
+}
+
+bool gzip_member(const std::string& in, std::string& out) {
+    z_stream zs;
+    std::memset(&zs, 0, sizeof zs);
+    if (deflateInit2(&zs, 6, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    out.resize(deflateBound(&zs, (uLong)in.size()));
+    zs.next_in = reinterpret_cast<Bytef*>(const_cast<char*>(in.data()));
+    zs.avail_in = (uInt)in.size();
+    zs.next_out = reinterpret_cast<Bytef*>(&out[0]);
+    zs.avail_out = (uInt)out.size();
+    const int rc = deflate(&zs, Z_FINISH);
+    const uLong n = zs.total_out;
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END) return false;
+    out.resize(n);
+    return true;
+}
+
+// rows [0, n_rows) formatted by `line(row, text)` (appends one or more complete lines) in
+// chunks of at most ~64 MB of text; `head` goes in front of the first chunk
+int write_rows(const char* path, const std::string& head, int64_t n_rows, int64_t bytes_per_row,
+               bool gz, const std::function<void(int64_t, std::string&)>& line) {
+    const char* cb = getenv("VIREO_WRITER_CHUNK_BYTES");  // (tests shrink the chunks)
+    const int64_t chunk_bytes = cb && *cb ? std::max<int64_t>(1, atoll(cb)) : (64ll << 20);
+    // chunks of at most chunk_bytes of text, and enough of them to keep every thread busy
+    // (but not below ~256 KB of text each)
+    int64_t per_chunk = std::max<int64_t>(1, chunk_bytes / std::max<int64_t>(bytes_per_row, 1));
+    const int64_t spread = (n_rows + 4 * writer_threads() - 1) / (4 * writer_threads());
+    const int64_t floor_rows = std::max<int64_t>(1, std::min<int64_t>(chunk_bytes, 256 << 10) /
+                                                        std::max<int64_t>(bytes_per_row, 1));
+    per_chunk = std::max<int64_t>(1, std::min(per_chunk, std::max(spread, floor_rows)));
+    const int64_t n_chunk = std::max<int64_t>(1, (n_rows + per_chunk - 1) / per_chunk);
+    FILE* f = std::fopen(path, "wb");
+    if (!f) {
+        vrx_set_error("cannot open %s for writing", path);
+        return VRX_ERR_ARG;
+    }
+    const int nt = (int)std::min<int64_t>(writer_threads(), n_chunk);
+    bool ok = true;
+    for (int64_t c0 = 0; c0 < n_chunk && ok; c0 += nt) {  // one wave of chunks at a time, in order
+        const int64_t nc = std::min<int64_t>(nt, n_chunk - c0);
+        std::vector<std::string> out((size_t)nc);
+        std::vector<char> good((size_t)nc, 1);
+        std::vector<std::thread> th;
+        for (int64_t j = 0; j < nc; ++j)
+            th.emplace_back([&, j] {
+                const int64_t c = c0 + j, lo = c * per_chunk, hi = std::min(n_rows, lo + per_chunk);
+                std::string text;
+                text.reserve((size_t)((hi - lo) * bytes_per_row + head.size() + 64));
+                if (c == 0) text = head;
+                for (int64_t r = lo; r < hi; ++r) line(r, text);
+                if (gz)
+                    good[(size_t)j] = gzip_member(text, out[(size_t)j]);
+                else
+                    out[(size_t)j].swap(text);
+            });
+        for (auto& t : th) t.join();
+        for (int64_t j = 0; j < nc && ok; ++j)
+            ok = good[(size_t)j] && std::fwrite(out[(size_t)j].data(), 1, out[(size_t)j].size(), f) ==
+                                        out[(size_t)j].size();
+    }
+    if (std::fclose(f) != 0) ok = false;
+    if (!ok) {
+        vrx_set_error("writing %s failed", path);
+        return VRX_ERR_ARG;
+    }
+    return VRX_OK;
+}
+
+inline void put_int(std::string& s, int64_t v) {
+    char b[24];
+    const int n = std::snprintf(b, sizeof b, "%lld", (long long)v);
+    s.append(b, (size_t)n);
+}
+}  // namespace
+
+// header + one line per row: names[row] and the row's `cols` numbers in `fmt` (a printf format of
+// one double, e.g. "%.2e"), tab separated.  names: the concatenated row labels, name_off[row]
+// .. name_off[row + 1] each.  gz != 0: `path` is written as gzip.
+extern "C" int vrx_write_table(const char* path, const char* header, const char* names,
+                               const int64_t* name_off, const double* table, int64_t rows,
+                               int64_t cols, const char* fmt, int32_t gz) {
+    if (!path || !header || !names || !name_off || (!table && rows * cols > 0) || rows < 0 ||
+        cols < 0 || !fmt) {
+        vrx_set_error("vrx_write_table: bad argument");
+        return VRX_ERR_ARG;
+    }
+    const std::string f(fmt);
+    return write_rows(path, header, rows, 24 + 10 * cols, gz != 0, [&](int64_t r, std::string& s) {
+        s.append(names + name_off[r], (size_t)(name_off[r + 1] - name_off[r]));
+        char b[64];
+        for (int64_t c = 0; c < cols; ++c) {
+            const int n = std::snprintf(b, sizeof b, f.c_str(), table[r * cols + c]);
+            s.push_back('\t');
+            s.append(b, (size_t)std::min<int>(n, (int)sizeof b - 1));
+        }
+        s.push_back('\n');
+    });
+}
+
+// The records of the donor genotype VCF (vcf_utils.py:283-290 with the tags GT:AD:DP:PL):
+// head (comment and #CHROM lines), then per variant its prefix (the eight fixed columns and the
+// FORMAT column, prefix_off[i] .. prefix_off[i + 1]) and per sample
+// <0/0|1/0|1/1>:<AD>:<DP>:<PL,PL,PL>.  call [n_var][n_sample] in 0..2, ad / dp [n_var][n_sample],
+// pl [n_var][n_sample][3], already rounded to integers.
+extern "C" int vrx_write_vcf_records(const char* path, const char* head, const char* prefix,
+                                     const int64_t* prefix_off, const int8_t* call,
+                                     const int64_t* ad, const int64_t* dp, const int64_t* pl,
+                                     int64_t n_var, int64_t n_sample, int32_t gz) {
+    if (!path || !head || !prefix || !prefix_off || n_var < 0 || n_sample < 0 ||
+        (n_var * n_sample > 0 && (!call || !ad || !dp || !pl))) {
+        vrx_set_error("vrx_write_vcf_records: bad argument");
+        return VRX_ERR_ARG;
+    }
+    static const char* const gt_name[3] = {"0/0", "1/0", "1/1"};
+    for (int64_t i = 0; i < n_var * n_sample; ++i)
+        if (call[i] < 0 || call[i] > 2) {
+            vrx_set_error("vrx_write_vcf_records: genotype call outside 0..2");
+            return VRX_ERR_ARG;
+        }
+    return write_rows(path, head, n_var, 64 + 24 * n_sample, gz != 0, [&](int64_t i, std::string& s) {
+        s.append(prefix + prefix_off[i], (size_t)(prefix_off[i + 1] - prefix_off[i]));
+        for (int64_t d = 0; d < n_sample; ++d) {
+            const int64_t j = i * n_sample + d;
+            s.push_back('\t');
+            s.append(gt_name[call[j]], 3);
+            s.push_back(':');
+            put_int(s, ad[j]);
+            s.push_back(':');
+            put_int(s, dp[j]);
+            s.push_back(':');
+            put_int(s, pl[j * 3]);
+            s.push_back(',');
+            put_int(s, pl[j * 3 + 1]);
+            s.push_back(',');
+            put_int(s, pl[j * 3 + 2]);
+        }
+        s.push_back('\n');
+    });
+}

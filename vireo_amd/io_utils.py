@@ -15,7 +15,7 @@ import numpy as np
 from scipy.sparse import coo_matrix
 
 from . import _lib
-from .vcf_utils import load_VCF, match_SNPs
+from .vcf_utils import _labels_blob, load_VCF, match_SNPs
 
 
 def read_mtx(path, n_threads=0):
@@ -93,6 +93,18 @@ def _gzip_file(path):
     os.remove(path)
 
 
+def _write_table_gz(path, header, row_names, table):
+    """<header>, then <row name> TAB "%.2e" ... per row, gzipped (the reference writes the text
+    with a Python loop and runs ``gzip -f``, io_utils.py:147-170); formatted and deflated on
+    several threads by libvireo_hip.so"""
+    table = np.ascontiguousarray(table, dtype=np.float64)
+    blob, off = _labels_blob(row_names)
+    _lib.check(_lib.lib().vrx_write_table(
+        path.encode(), ("\t".join(header) + "\n").encode(), blob,
+        off.ctypes.data_as(C.c_void_p), _lib.dptr(table), table.shape[0], table.shape[1],
+        b"%.2e", 1))
+
+
 def write_donor_id(out_dir, donor_names, cell_names, n_vars, res_vireo):
     """donor_ids.tsv, summary.tsv, prob_singlet.tsv.gz, prob_doublet.tsv.gz, _log.txt with the
     reference's thresholds (prob_max < 0.9 -> unassigned, doublet >= 0.9, n_vars < 10 ->
@@ -131,8 +143,4 @@ def write_donor_id(out_dir, donor_names, cell_names, n_vars, res_vireo):
 
     for name, header, table in (("prob_singlet.tsv", donor_names, ID_prob),
                                 ("prob_doublet.tsv", pair_names, doublet_prob)):
-        with open(out_dir + "/" + name, "w") as f:
-            f.write("\t".join(["cell"] + list(header)) + "\n")
-            for i in range(len(cell_names)):
-                f.write("\t".join([cell_names[i]] + ["%.2e" % x for x in table[i, :]]) + "\n")
-        _gzip_file(out_dir + "/" + name)
+        _write_table_gz(out_dir + "/" + name + ".gz", ["cell"] + list(header), cell_names, table)

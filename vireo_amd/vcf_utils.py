@@ -10,9 +10,12 @@ import gzip
 import shutil
 import subprocess
 
+import ctypes as C
+
 import numpy as np
 from scipy.sparse import csr_matrix
 
+from . import _lib
 from .vireo_base import match
 
 _MISSING = (".", "./.", ".|.")
@@ -160,21 +163,64 @@ def match_SNPs(SNP_ids1, SNPs_ids2):
     return idx
 
 
+class _GenoArrays(dict):
+    """What ``GenoINFO_maker`` returns: the reference's dict of per-variant string lists
+    (vcf_utils.py:208-231), formed only when somebody reads a tag; ``write_VCF`` takes the integer
+    arrays behind it and lets the library format the records."""
+    _NAMES = ('0/0', '1/0', '1/1')
+
+    def __init__(self, call, AD, DP, PL):
+        super().__init__()
+        self.call, self.AD, self.DP, self.PL = call, AD, DP, PL
+
+    def _strings(self, tag):
+        n = self.call.shape[0]
+        if tag == 'GT':
+            return [[self._NAMES[x] for x in self.call[i]] for i in range(n)]
+        if tag == 'PL':
+            txt = self.PL.astype(str)
+            return [[",".join(x) for x in txt[i]] for i in range(n)]
+        txt = getattr(self, tag).astype(str)
+        return [list(txt[i]) for i in range(n)]
+
+    def __missing__(self, tag):
+        if tag not in ('GT', 'AD', 'DP', 'PL'):
+            raise KeyError(tag)
+        self[tag] = self._strings(tag)
+        return dict.__getitem__(self, tag)
+
+    def __contains__(self, tag):
+        return tag in ('GT', 'AD', 'DP', 'PL')
+
+    def keys(self):
+        return ['GT', 'AD', 'DP', 'PL']
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return 4
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+
+def _labels_blob(labels):
+    """(concatenated utf-8 labels, int64 offsets) for the native writers"""
+    enc = [str(x).encode() for x in labels]
+    off = np.zeros(len(enc) + 1, dtype=np.int64)
+    np.cumsum([len(b) for b in enc], out=off[1:])
+    return b"".join(enc), off
+
+
 def GenoINFO_maker(GT_prob, AD_reads, DP_reads):
-    """GT / AD / DP / PL strings of the estimated donor genotypes (vcf_utils.py:208-231).
-    Floors GT_prob at 1e-10 in place, like the reference."""
+    """GT / AD / DP / PL of the estimated donor genotypes (vcf_utils.py:208-231): the called
+    genotype, the rounded read counts and PL = round(-10 log10 GT_prob).  Floors GT_prob at
+    1e-10 in place, like the reference."""
     call = np.argmax(GT_prob, axis=2)
     GT_prob[GT_prob < 10 ** (-10)] = 10 ** (-10)
-    PL = np.round(-10 * np.log10(GT_prob)).astype(int).astype(str)
-    AD = np.round(AD_reads).astype(int).astype(str)
-    DP = np.round(DP_reads).astype(int).astype(str)
-    names = ['0/0', '1/0', '1/1']
-    return {
-        'GT': [[names[x] for x in call[i]] for i in range(GT_prob.shape[0])],
-        'AD': [list(AD[i]) for i in range(GT_prob.shape[0])],
-        'DP': [list(DP[i]) for i in range(GT_prob.shape[0])],
-        'PL': [[",".join(x) for x in PL[i]] for i in range(GT_prob.shape[0])],
-    }
+    PL = np.round(-10 * np.log10(GT_prob)).astype(int)
+    return _GenoArrays(call, np.round(AD_reads).astype(int), np.round(DP_reads).astype(int), PL)
 
 
 _FORMAT_HEADER = {
@@ -194,14 +240,30 @@ def write_VCF(out_file, VCF_dat, GenoTags=['GT', 'AD', 'DP', 'PL']):
         if GenoTags != []:
             print("No sample available: GenoTags will be ignored.")
     cols = ["CHROM", "POS", "ID", "REF", "ALT", "QUAL", "FILTER", "INFO", "FORMAT"]
+    head = [line for line in VCF_dat['comments']
+            if not any(line.startswith("##FORMAT=<ID=" + t) for t in GenoTags)]
+    head += [_FORMAT_HEADER[t] for t in GenoTags if t in _FORMAT_HEADER]
+    head.append("#" + "\t".join(cols + list(VCF_dat['samples'])))
+    geno = VCF_dat.get('GenoINFO')
+    if (isinstance(geno, _GenoArrays) and list(GenoTags) == ['GT', 'AD', 'DP', 'PL']
+            and geno.PL.shape[2:] == (3,) and geno.call.shape[1] == len(VCF_dat['samples'])):
+        # the records are formatted (and gzipped) by the library from the integer arrays
+        fixed = VCF_dat['FixedINFO']
+        n = len(VCF_dat['variants'])
+        prefix = ["\t".join([fixed[c][i] for c in cols[:8]] + ["GT:AD:DP:PL"]) for i in range(n)]
+        blob, off = _labels_blob(prefix)
+        i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)     # noqa: E731
+        call = np.ascontiguousarray(geno.call, dtype=np.int8)
+        ad, dp, pl = i64(geno.AD), i64(geno.DP), i64(geno.PL)
+        void = lambda a: a.ctypes.data_as(C.c_void_p)               # noqa: E731
+        # (like the generic path below: the result is always <plain name>.gz)
+        _lib.check(_lib.lib().vrx_write_vcf_records(
+            (plain + ".gz").encode(), ("\n".join(head) + "\n").encode(), blob, void(off),
+            void(call), void(ad), void(dp), void(pl), n, call.shape[1], 1))
+        return
     with open(plain, "w") as out:
-        for line in VCF_dat['comments']:
-            if not any(line.startswith("##FORMAT=<ID=" + t) for t in GenoTags):
-                out.write(line + "\n")
-        for t in GenoTags:
-            if t in _FORMAT_HEADER:
-                out.write(_FORMAT_HEADER[t] + "\n")
-        out.write("#" + "\t".join(cols + list(VCF_dat['samples'])) + "\n")
+        for line in head:
+            out.write(line + "\n")
         fmt = ":".join(GenoTags)
         for i in range(len(VCF_dat['variants'])):
             rec = [VCF_dat['FixedINFO'][c][i] for c in cols[:8]] + [fmt]
