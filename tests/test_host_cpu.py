@@ -333,3 +333,32 @@ def test_native_text_writers_format_like_python(tmp_path, monkeypatch, chunk_byt
     vcf_utils.write_VCF(str(tmp_path / "b.vcf.gz"), plain)
     fast, slow = (gzip.open(tmp_path / f, "rt").read() for f in ("a.vcf.gz", "b.vcf.gz"))
     assert fast == slow and fast.count("\n") == N + 7
+
+
+@pytest.mark.parametrize("tag", ["GT", "GP", "PL"])
+def test_donor_genotype_codes_parse_the_same_in_bulk(tag, monkeypatch):
+    """parse_donor_GPb (vcf_utils.py:299-336) converts all codes of the donor VCF in a few array
+    operations; bit for bit what the one-code-at-a-time conversion gives, and irregular input
+    still takes that path"""
+    from vireo_amd import vcf_utils
+    rng = np.random.default_rng(3)
+    N, K = 400, 6
+    if tag == "GT":
+        pool = ["0/0", "0/1", "1/0", "1|1", "./.", ".", "1/1"]
+        dat = [[pool[x] for x in rng.integers(0, len(pool), K)] for _ in range(N)]
+    elif tag == "GP":
+        dat = [["." if rng.random() < 0.05 else ",".join("%.4f" % v for v in rng.dirichlet([1, 1, 1]))
+                for _ in range(K)] for _ in range(N)]
+    else:
+        dat = [["./." if rng.random() < 0.05 else ",".join(str(v) for v in rng.integers(0, 255, 3))
+                for _ in range(K)] for _ in range(N)]
+    fast = vcf_utils.parse_donor_GPb(dat, tag, min_prob=1e-4)
+    assert vcf_utils._parse_codes_vectorised(dat, tag) is not None
+    monkeypatch.setattr(vcf_utils, "_parse_codes_vectorised", lambda *a: None)
+    slow = vcf_utils.parse_donor_GPb(dat, tag, min_prob=1e-4)
+    assert np.array_equal(fast, slow)
+    monkeypatch.undo()
+    if tag != "GT":
+        odd = [row[:] for row in dat]
+        odd[5][2] = "1,2"                           # not three fields: the bulk path declines
+        assert vcf_utils._parse_codes_vectorised(odd, tag) is None

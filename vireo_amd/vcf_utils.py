@@ -130,24 +130,62 @@ def read_sparse_GeneINFO(GenoINFO, keys=['AD', 'DP'], axes=[-1, -1]):
     return out
 
 
+def _parse_codes_vectorised(GT_dat, tag):
+    """All genotype codes of a donor VCF at once (the reference converts them one string at a time,
+    vcf_utils.py:311-331: seconds per 10^5 variants): the same arithmetic on whole arrays.
+    None when the input is not a regular table of well-formed codes."""
+    n_var = len(GT_dat)
+    n_don = len(GT_dat[0]) if n_var else 0
+    if any(len(row) != n_don for row in GT_dat):
+        return None
+    flat = [code for row in GT_dat for code in row]
+    missing = np.fromiter((code in _MISSING for code in flat), dtype=bool, count=len(flat))
+    good = [code for code, m in zip(flat, missing) if not m]
+    P = np.zeros((len(flat), 3))
+    P[missing] = 1 / 3
+    try:
+        if tag == 'GT':
+            if any(len(code) < 1 for code in good):
+                return None
+            first = np.array([code[0] for code in good], dtype=float)
+            last = np.array([code[-1] for code in good], dtype=float)
+            idx = (first + last).astype(int)
+            if good and (idx.min() < 0 or idx.max() > 2):
+                return None
+            P[np.flatnonzero(~missing), idx] = 1
+        else:
+            if any(code.count(",") != 2 for code in good):
+                return None
+            vals = np.array(",".join(good).split(","), dtype=float).reshape(-1, 3) if good \
+                else np.zeros((0, 3))
+            if tag == 'PL':
+                vals = 10 ** (-0.1 * (vals - vals.min(axis=1, keepdims=True)) - 0.025)
+            P[~missing] = vals
+    except ValueError:
+        return None
+    return P.reshape(n_var, n_don, 3)
+
+
 def parse_donor_GPb(GT_dat, tag='GT', min_prob=0.0):
     """(n_var, n_donor, 3) genotype probabilities from GT / GP / PL strings
     (vcf_utils.py:299-336); missing calls are uniform."""
     if tag not in ('GT', 'GP', 'PL'):
         print("[parse_donor_GPb] Error: no support tag: %s" % tag)
         return None
-    P = np.zeros((len(GT_dat), len(GT_dat[0]), 3))
-    for i, row in enumerate(GT_dat):
-        for j, code in enumerate(row):
-            if code in _MISSING:
-                P[i, j] = 1 / 3
-            elif tag == 'GT':
-                P[i, j, int(float(code[0]) + float(code[-1]))] = 1
-            elif tag == 'GP':
-                P[i, j] = np.array(code.split(','), float)
-            else:
-                phred = np.array(code.split(','), float)
-                P[i, j] = 10 ** (-0.1 * (phred - min(phred)) - 0.025)
+    P = _parse_codes_vectorised(GT_dat, tag)
+    if P is None:           # ragged rows or fields that are not three numbers: one code at a time
+        P = np.zeros((len(GT_dat), len(GT_dat[0]), 3))
+        for i, row in enumerate(GT_dat):
+            for j, code in enumerate(row):
+                if code in _MISSING:
+                    P[i, j] = 1 / 3
+                elif tag == 'GT':
+                    P[i, j, int(float(code[0]) + float(code[-1]))] = 1
+                elif tag == 'GP':
+                    P[i, j] = np.array(code.split(','), float)
+                else:
+                    phred = np.array(code.split(','), float)
+                    P[i, j] = 10 ** (-0.1 * (phred - min(phred)) - 0.025)
     P += min_prob
     P /= P.sum(axis=2, keepdims=True)
     return P
