@@ -362,3 +362,32 @@ def test_donor_genotype_codes_parse_the_same_in_bulk(tag, monkeypatch):
         odd = [row[:] for row in dat]
         odd[5][2] = "1,2"                           # not three fields: the bulk path declines
         assert vcf_utils._parse_codes_vectorised(odd, tag) is None
+
+
+def test_one_ahead_iterator_hands_over_items_errors_and_early_exits():
+    """the helper-thread iterator behind the restart draws (vireo_wrap._one_ahead): order kept,
+    a producer error re-raised in the consumer, a consumer that stops early does not hang"""
+    import sys
+    import threading
+    import time
+    W = sys.modules["vireo_amd.vireo_wrap"]
+    assert list(W._one_ahead(iter(range(7)), depth=3)) == list(range(7))
+    assert list(W._one_ahead(iter(()))) == []
+
+    def broken():
+        yield 1
+        raise RuntimeError("draw failed")
+    got = []
+    with pytest.raises(RuntimeError, match="draw failed"):
+        for x in W._one_ahead(broken()):
+            got.append(x)
+    assert got == [1]
+
+    n0 = threading.active_count()
+    it = W._one_ahead(iter(range(100)))
+    assert next(it) == 0
+    it.close()                                    # consumer leaves: the helper must finish
+    t0 = time.time()
+    while threading.active_count() > n0 and time.time() - t0 < 5:
+        time.sleep(0.05)
+    assert threading.active_count() <= n0

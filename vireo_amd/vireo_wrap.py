@@ -91,20 +91,24 @@ def _one_ahead(gen, depth=1):
     stop = threading.Event()
     done = object()
 
+    def hand_over(item):
+        """False when the consumer has gone away"""
+        while not stop.is_set():
+            try:
+                box.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                pass
+        return False
+
     def produce():
         try:
             for item in gen:
-                while not stop.is_set():
-                    try:
-                        box.put(item, timeout=0.1)
-                        break
-                    except queue.Full:
-                        pass
-                if stop.is_set():
+                if not hand_over(item):
                     return
-            box.put(done)
+            hand_over(done)
         except BaseException as e:      # noqa: BLE001 -- handed to the consumer
-            box.put(e)
+            hand_over(e)
 
     th = threading.Thread(target=produce, name="vireo-restart-draws", daemon=True)
     th.start()
