@@ -318,7 +318,7 @@ def main():
                        "host_setup_s": {"generate": round(t_gen, 1), "upload+transpose": round(t_up, 1)}},
             "roofline": {"bound": "hbm",
                          "kernel": "%s (%s pass)" % (
-                             "vrx_spmm_lds<MODE %d, FORM %d>" % (dom == "cell", kinfo["cell_form"] if dom == "cell" else 0)
+                             "vrx_spmm_lds<MODE %d, FORM %d>" % (dom == "cell", kinfo["cell_form"] if dom == "cell" else kinfo["var_form"])
                              if kinfo["lds_" + dom]
                              else "vrx_spmm<..,%d,fmt%d>" % (dom == "cell", kinfo["fmt_" + dom]), dom),
                          "kernel_info": kinfo,
