@@ -293,8 +293,8 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_build_fill(VrxTileArgs A, const
     if (!pair) {  // natural order, zero-valued words behind the segment
         for (int m = 0; m < 2; ++m) {
             int n = 0;
-            vrx_segment_words(A, lo[m], hi[m], step[m], base, ph, [&](uint32_t wd) { dst[(int64_t)n++ * A.G + gs[m]] = wd; });
-            for (; n < Lr; ++n) dst[(int64_t)n * A.G + gs[m]] = A.pad_word;
+            vrx_segment_words(A, lo[m], hi[m], step[m], base, ph, [&](uint32_t wd) { dst[vrx_trip_slot(n++, gs[m], A.G, A.U, A.form)] = wd; });
+            for (; n < Lr; ++n) dst[vrx_trip_slot(n, gs[m], A.G, A.U, A.form)] = A.pad_word;
         }
         return;
     }
@@ -312,14 +312,14 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_build_fill(VrxTileArgs A, const
         int c0 = 0, c1 = fits ? z : p0;
         vrx_segment_words(A, lo[0], hi[0], step[0], base, ph, [&](uint32_t wd) {
             const int at = ((wd >> A.bit_shift) & 1u) ? c1++ : c0++;
-            dst[(int64_t)at * A.G + g0] = wd;
+            dst[vrx_trip_slot(at, g0, A.G, A.U, A.form)] = wd;
         });
         if (fits) {
-            for (int n = p0; n < z; ++n) dst[(int64_t)n * A.G + g0] = pad0;
-            for (int n = z + p1; n < L; ++n) dst[(int64_t)n * A.G + g0] = pad1;
-            for (int n = L; n < Lr; ++n) dst[(int64_t)n * A.G + g0] = A.pad_word;
+            for (int n = p0; n < z; ++n) dst[vrx_trip_slot(n, g0, A.G, A.U, A.form)] = pad0;
+            for (int n = z + p1; n < L; ++n) dst[vrx_trip_slot(n, g0, A.G, A.U, A.form)] = pad1;
+            for (int n = L; n < Lr; ++n) dst[vrx_trip_slot(n, g0, A.G, A.U, A.form)] = A.pad_word;
         } else {
-            for (int n = p0 + p1; n < Lr; ++n) dst[(int64_t)n * A.G + g0] = A.pad_word;
+            for (int n = p0 + p1; n < Lr; ++n) dst[vrx_trip_slot(n, g0, A.G, A.U, A.form)] = A.pad_word;
         }
     }
     // its partner: bit-1 words first
@@ -327,14 +327,14 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_build_fill(VrxTileArgs A, const
         int c1 = 0, c0 = fits ? z : q1;
         vrx_segment_words(A, lo[1], hi[1], step[1], base, ph, [&](uint32_t wd) {
             const int at = ((wd >> A.bit_shift) & 1u) ? c1++ : c0++;
-            dst[(int64_t)at * A.G + g1] = wd;
+            dst[vrx_trip_slot(at, g1, A.G, A.U, A.form)] = wd;
         });
         if (fits) {
-            for (int n = q1; n < z; ++n) dst[(int64_t)n * A.G + g1] = pad1;
-            for (int n = z + q0; n < L; ++n) dst[(int64_t)n * A.G + g1] = pad0;
-            for (int n = L; n < Lr; ++n) dst[(int64_t)n * A.G + g1] = A.pad_word;
+            for (int n = q1; n < z; ++n) dst[vrx_trip_slot(n, g1, A.G, A.U, A.form)] = pad1;
+            for (int n = z + q0; n < L; ++n) dst[vrx_trip_slot(n, g1, A.G, A.U, A.form)] = pad0;
+            for (int n = L; n < Lr; ++n) dst[vrx_trip_slot(n, g1, A.G, A.U, A.form)] = A.pad_word;
         } else {
-            for (int n = q0 + q1; n < Lr; ++n) dst[(int64_t)n * A.G + g1] = A.pad_word;
+            for (int n = q0 + q1; n < Lr; ++n) dst[vrx_trip_slot(n, g1, A.G, A.U, A.form)] = A.pad_word;
         }
     }
 }

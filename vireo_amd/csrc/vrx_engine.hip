@@ -547,7 +547,8 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
                 dst.resize((size_t)(rel + longest * G));
                 for (int64_t j = 0; j < longest; ++j)
                     for (int g = 0; g < G; ++g)  // padding: value 0 (forms 1, 2: at the slab's first row)
-                        dst[(size_t)(rel + j * G + g)] = j < (int64_t)segw[g].size() ? segw[g][(size_t)j] : pad_word;
+                        dst[(size_t)(rel + vrx_trip_slot(j, g, G, U, form))] =
+                            j < (int64_t)segw[g].size() ? segw[g][(size_t)j] : pad_word;
                 rel += longest * G;  // (a multiple of 64 words: streams stay 16-B aligned)
                 }
             }

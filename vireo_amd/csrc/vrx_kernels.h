@@ -350,6 +350,18 @@ constexpr int VRX_CHUNK = 256;  // entries per refill (64 lanes x 16 B of one LD
 #ifndef VRX_LDS_WAVES
 #define VRX_LDS_WAVES 16
 #endif
+// Word order inside a trip (U entries for each of the G lane groups).  Pair words (FORM 0):
+// entry-major, word j of group g at j * G + g.  AD/BD words (FORM 1, 2): group-major, the U
+// words of a group adjacent (g * U + u), so that a lane takes its trip with ONE ds_read_b128
+// instead of two ds_read2_b32.  Both builders place the words with vrx_trip_slot.
+#ifndef VRX_TRIP_GROUP_MAJOR
+#define VRX_TRIP_GROUP_MAJOR 1
+#endif
+// stream position, relative to the round's base, of entry n (0, 1, ...) of lane group g
+__host__ __device__ inline int64_t vrx_trip_slot(int64_t n, int g, int G, int U, int form) {
+    if (form != 0 && VRX_TRIP_GROUP_MAJOR) return (n / U) * ((int64_t)U * G) + (int64_t)g * U + n % U;
+    return n * G + g;
+}
 #ifndef VRX_F1_PREFETCH
 #define VRX_F1_PREFETCH 0  // measured: 0.403 vs 0.391 ms (the four extra registers spill)
 #endif
@@ -669,7 +681,7 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
             ring_need(stream_lo);
             const uint32_t* rp = ring_g + (stream_lo & (VRX_RING - 1));
 #pragma unroll
-            for (int u = 0; u < U; ++u) wn[u] = rp[u * G];
+            for (int u = 0; u < U; ++u) wn[u] = VRX_TRIP_GROUP_MAJOR ? ring[(stream_lo & (VRX_RING - 1)) + g * U + u] : rp[u * G];
         }
     }
     int bvec = bw[(int64_t)s_lo * NRV + min(lane, NRV)];
@@ -733,7 +745,7 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
                             ring_need(nx);
                             const uint32_t* rn = ring_g + (nx & (VRX_RING - 1));
 #pragma unroll
-                            for (int u = 0; u < U; ++u) wn[u] = rn[u * G];
+                            for (int u = 0; u < U; ++u) wn[u] = VRX_TRIP_GROUP_MAJOR ? ring[(nx & (VRX_RING - 1)) + g * U + u] : rn[u * G];
                         }
                     }
 #else
@@ -747,6 +759,14 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
 #pragma unroll
                     for (int u = 0; u < NE; ++u) w[u] = 0x3ff00000u | 32768u | (uint32_t)((at + u * 64 + g * 8) & 0xff80);
                     (void)rp;
+#elif VRX_TRIP_GROUP_MAJOR
+                    {   // the group's U words are adjacent (padding words fill a short last trip)
+                        const uint4 q4 = *reinterpret_cast<const uint4*>(ring + (at & (VRX_RING - 1)) + g * U);
+                        const uint32_t qq[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+                        for (int u = 0; u < NE; ++u) w[u] = qq[u];
+                        (void)rp;
+                    }
 #else
 #pragma unroll
                     for (int u = 0; u < NE; ++u) w[u] = rp[u * G];
