@@ -94,3 +94,33 @@ def test_cli_matches_reference_outputs(mode, tmp_path, capsys):
     assert (n_text_diff, n_vcf_diff) == OBSERVED_TEXT_DIFFS.get(mode, (0, 0))
     for name in ("prob_singlet.tsv.gz", "prob_doublet.tsv.gz"):
         assert os.path.exists(out + "/" + name)
+    # the probability tables (written by the library's threaded writer): one row per cell in
+    # donor_ids.tsv order, and the largest singlet probability of a row prints as prob_max does
+    rows = [line.split("\t") for line in gzip.open(out + "/prob_singlet.tsv.gz", "rt").read().splitlines()]
+    assert rows[0][0] == "cell" and [r[0] for r in rows[1:]] == [g[0] for g in got[1:]]
+    for r, g in zip(rows[1:], got[1:]):
+        assert "%.2e" % max(float(x) for x in r[1:]) == g[2]
+
+
+def test_cli_with_a_communicator_writes_the_same_files(tmp_path, capsys, monkeypatch):
+    """the command launched once per GPU shares its restarts over the ranks (RCCL) and rank 0
+    writes; here the same code path at world size 1 against the plain run"""
+    import socket
+    from vireo_amd import _lib
+    from vireo_amd.vireo import main
+    _lib.require_gpu()
+    mode = sorted(MODES)[0]
+    plain, shared = str(tmp_path / "plain"), str(tmp_path / "shared")
+    main(MODES[mode] + ["-o", plain, "--randSeed", "2", "--noPlot"])
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    for k, v in dict(VIREO_CLI_FORCE_RCCL="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                     MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)).items():
+        monkeypatch.setenv(k, v)
+    main(MODES[mode] + ["-o", shared, "--randSeed", "2", "--noPlot"])
+    capsys.readouterr()
+    for name in ("summary.tsv", "donor_ids.tsv", "_log.txt"):
+        assert open(plain + "/" + name).read() == open(shared + "/" + name).read()
+    for name in ("prob_singlet.tsv.gz", "prob_doublet.tsv.gz"):
+        assert gzip.open(plain + "/" + name).read() == gzip.open(shared + "/" + name).read()

@@ -18,6 +18,7 @@ import numpy as np
 
 from . import __version__
 from .counts import device_counts
+from .dist import RcclComm, env_rank_world, socket_exchange
 from .io_utils import match_donor_VCF, read_cellSNP, read_vartrix, write_donor_id
 from .vcf_utils import (GenoINFO_maker, load_VCF, parse_donor_GPb, read_sparse_GeneINFO,
                         write_VCF)
@@ -183,6 +184,16 @@ def main(argv=None):
     n_donor, learn_GT, donor_GPb = donors["n_donor"], donors["learn_GT"], donors["GPb"]
     donor_names, donor_vcf = donors["names"], donors["vcf"]
 
+    # Launched once per GPU (python -m torch.distributed.run --nproc-per-node N -m vireo_amd.vireo
+    # ...; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) the restarts are shared
+    # out over the ranks; every rank computes the same result and rank 0 writes the files.
+    rank, world, local = env_rank_world()
+    comm = None
+    if world > 1 or os.environ.get("VIREO_CLI_FORCE_RCCL") == "1":    # (the latter: a 1-GPU test)
+        if rank != 0:
+            sys.stdout = open(os.devnull, "w")                      # rank 0 speaks for all
+        comm = RcclComm(rank, world, local, socket_exchange(rank, world))
+
     counts = device_counts(cell_dat['AD'], cell_dat['DP'])         # one upload for everything
     n_vars = counts.n_vars()                                        # vireo.py:191
     if options.force_learnGT:
@@ -199,7 +210,13 @@ def main(argv=None):
                      n_init=n_init, n_extra_donor=n_extra_donor,
                      extra_donor_mode=options.extra_donor_mode, check_doublet=check_doublet,
                      random_seed=options.rand_seed, ASE_mode=options.ASE_mode,
-                     check_ambient=options.check_ambient, nproc=options.nproc)
+                     check_ambient=options.check_ambient, nproc=options.nproc,
+                     **({} if comm is None else {"comm": comm}))
+    if comm is not None:
+        comm.barrier()
+        comm.close()
+        if rank != 0:
+            return
 
     if n_donor is not None and donor_GPb is not None and n_donor < donor_GPb.shape[1]:
         idx = optimal_match(res['GT_prob'], donor_GPb)[1]           # vireo.py:219-222
