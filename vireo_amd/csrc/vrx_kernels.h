@@ -333,18 +333,6 @@ constexpr int VRX_CHUNK = 256;  // entries per refill (64 lanes x 16 B of one LD
 #ifndef VRX_LDS_U_DEF
 #define VRX_LDS_U_DEF 4
 #endif
-#ifndef VRX_F1_FULLTRIPS
-#define VRX_F1_FULLTRIPS 0
-#endif
-#ifndef VRX_LDS_L2PF
-#define VRX_LDS_L2PF 0
-#endif
-#ifndef VRX_L2PF_AHEAD
-#define VRX_L2PF_AHEAD 2
-#endif
-// FORM 1 / 2: the ring words of a trip are read one trip ahead (a wave's stream is contiguous
-// across rounds and slabs, so the next trip is always U*G words further): the trip's critical
-// path has ONE LDS round trip (the slices) instead of two.
 // waves per workgroup of the LDS-resident passes (16: one 160-KiB workgroup per CU; 8: two
 // 80-KiB workgroups per CU whose barrier / staging phases overlap -- experimental builds)
 #ifndef VRX_LDS_WAVES
@@ -354,23 +342,11 @@ constexpr int VRX_CHUNK = 256;  // entries per refill (64 lanes x 16 B of one LD
 // entry-major, word j of group g at j * G + g.  AD/BD words (FORM 1, 2): group-major, the U
 // words of a group adjacent (g * U + u), so that a lane takes its trip with ONE ds_read_b128
 // instead of two ds_read2_b32.  Both builders place the words with vrx_trip_slot.
-#ifndef VRX_TRIP_GROUP_MAJOR
-#define VRX_TRIP_GROUP_MAJOR 1
-#endif
 // stream position, relative to the round's base, of entry n (0, 1, ...) of lane group g
 __host__ __device__ inline int64_t vrx_trip_slot(int64_t n, int g, int G, int U, int form) {
-    if (form != 0 && VRX_TRIP_GROUP_MAJOR) return (n / U) * ((int64_t)U * G) + (int64_t)g * U + n % U;
+    if (form != 0) return (n / U) * ((int64_t)U * G) + (int64_t)g * U + n % U;
     return n * G + g;
 }
-#ifndef VRX_F1_PREFETCH
-#define VRX_F1_PREFETCH 0  // measured: 0.403 vs 0.391 ms (the four extra registers spill)
-#endif
-#ifndef VRX_LDS_PRIO
-#define VRX_LDS_PRIO 0
-#endif
-#ifndef VRX_F1_ANDOR
-#define VRX_F1_ANDOR 0
-#endif
 // output rows per wave (tile = 16 x this), per pass: measured best on MI355X at c3
 #ifndef VRX_LDS_LPE_DEF
 #define VRX_LDS_LPE_DEF 4
@@ -415,9 +391,6 @@ __device__ unsigned long long vrx_timing[16];  // per pass: total, barrier 1, ba
 // a 16-B unit is either whole or absent, so it is staged with one load.
 template <int LPE, int MODE, int RW, int PADK, int SPLIT, int FORM = 0>
 __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
-#if VRX_LDS_L2PF
-    __attribute__((amdgpu_num_vgpr(120)))
-#endif
     void vrx_spmm_lds(
     const uint32_t* __restrict__ ent, const int64_t* __restrict__ wave_start,
     const int32_t* __restrict__ bnd, const int32_t* __restrict__ rowmap, int n_slab,
@@ -441,23 +414,6 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
     constexpr int NRV = NR * PH;           // (round, phase) pairs per slab
     extern __shared__ __attribute__((aligned(16))) char vrx_smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#if VRX_LDS_PRIO == 1
-    // waves w, w+4, w+8, w+12 share a SIMD: distinct issue priorities skew them so that one
-    // wave's LDS phase overlaps another's FMA phase
-    switch (wave >> 2) {
-        case 1: __builtin_amdgcn_s_setprio(1); break;
-        case 2: __builtin_amdgcn_s_setprio(2); break;
-        case 3: __builtin_amdgcn_s_setprio(3); break;
-        default: break;
-    }
-#elif VRX_LDS_PRIO == 2
-    switch (wave & 3) {
-        case 1: __builtin_amdgcn_s_setprio(1); break;
-        case 2: __builtin_amdgcn_s_setprio(2); break;
-        case 3: __builtin_amdgcn_s_setprio(3); break;
-        default: break;
-    }
-#endif
     // LDS rows are padded to a multiple of CP columns (zeros); FORM 1: two halves of 16 columns
     const int KP = FORM != 0 ? 16 : (K + CP - 1) / CP * CP;  // (whole lanes: CP columns each)
     const int slab_doubles = slab_rows * KP * XD;
@@ -607,20 +563,6 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
             : "v"(gsrc), "s"(dst)
             : "memory");
         issued_end = pos + VRX_CHUNK;
-#if VRX_LDS_L2PF
-        // One 1-KiB chunk in flight per wave (16 KiB per CU, 4 MiB on the chip) cannot cover the
-        // HBM latency at the rate the walk consumes the stream (Little: 4 MiB / ~2 us = 2 TB/s).
-        // A plain load touches every 128-B line of the chunk two further ahead, so that the
-        // LDS-DMA of that chunk later hits L2.  Its result is never used; it is always the
-        // YOUNGEST vector-memory operation after a DMA, which is what lets ring_need wait with
-        // vmcnt(1) for every DMA without waiting for the prefetch itself.
-        // (v127 is outside the register budget given to the compiler -- amdgpu_num_vgpr(120) --
-        //  so a result that lands thousands of cycles later can never hit a live value)
-        {
-            const uint32_t* psrc = stream + min(pos + VRX_L2PF_AHEAD * VRX_CHUNK + 4 * lane, clamp_last);
-            asm volatile("global_load_dword v127, %0, off" : : "v"(psrc) : "memory", "v127");
-        }
-#endif
     };
     if (base0 < stream_end) dma_issue(base0);
     if (base0 + VRX_CHUNK < stream_end) dma_issue(base0 + VRX_CHUNK);
@@ -630,28 +572,13 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
     auto ring_need = [&](int at) {
         if (at < ring_evt) return;
         if (at >= landed_end) {
-#if VRX_LDS_L2PF
-            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-#else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
             landed_end = issued_end;
         }
         if ((at & (VRX_CHUNK - 1)) == 0 && at > base0 && at + VRX_CHUNK < stream_end &&
             at + VRX_CHUNK >= issued_end)
             dma_issue(at + VRX_CHUNK);  // into the slot of the chunk just finished
         ring_evt = (at & ~(VRX_CHUNK - 1)) + VRX_CHUNK;
-    };
-    // FORM 1: LDS byte offset of a slice = (word & half-row offset bits) | lane offset
-    const uint32_t f1_mask = 0x1ff80u;
-    auto f1_addr = [&](uint32_t w, uint32_t lane_off) -> uint32_t {
-#if VRX_F1_ANDOR
-        uint32_t a;
-        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(a) : "v"(w), "s"(f1_mask), "v"(lane_off));
-        return a;
-#else
-        return (w & f1_mask) | lane_off;
-#endif
     };
     // one entry of this group's segment: word -> 4 column slices -> FMAs
     auto entry = [&](uint32_t w, double (&a)[NQ][2], double (&a2)[NQ][2]) {
@@ -673,17 +600,6 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
         }
     };
 
-    uint32_t wn[U];  // (VRX_F1_PREFETCH) the words of the next trip
-    if (FORM != 0 && VRX_F1_PREFETCH) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) wn[u] = 0u;
-        if (stream_lo < stream_end) {
-            ring_need(stream_lo);
-            const uint32_t* rp = ring_g + (stream_lo & (VRX_RING - 1));
-#pragma unroll
-            for (int u = 0; u < U; ++u) wn[u] = VRX_TRIP_GROUP_MAJOR ? ring[(stream_lo & (VRX_RING - 1)) + g * U + u] : rp[u * G];
-        }
-    }
     int bvec = bw[(int64_t)s_lo * NRV + min(lane, NRV)];
     slab_fetch(s_lo);
 #ifdef VRX_TIMING
@@ -736,40 +652,19 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
                 auto trip = [&](int at, auto ne_tag) {
                     constexpr int NE = decltype(ne_tag)::value;
                     uint32_t w[NE];
-#if VRX_F1_PREFETCH
-#pragma unroll
-                    for (int u = 0; u < NE; ++u) w[u] = wn[u];
-                    {
-                        const int nx = at + U * G;  // (the slot of the chunk this trip ends may
-                        if (nx < stream_end) {      //  be refilled: its words are in registers)
-                            ring_need(nx);
-                            const uint32_t* rn = ring_g + (nx & (VRX_RING - 1));
-#pragma unroll
-                            for (int u = 0; u < U; ++u) wn[u] = VRX_TRIP_GROUP_MAJOR ? ring[(nx & (VRX_RING - 1)) + g * U + u] : rn[u * G];
-                        }
-                    }
-#else
 #ifndef VRX_X_NODMA
                     ring_need(at);
 #endif
-                    const uint32_t* rp = ring_g + (at & (VRX_RING - 1));
-#endif
-#if VRX_F1_PREFETCH
-#elif defined(VRX_X_NORING)
+#ifdef VRX_X_NORING
 #pragma unroll
                     for (int u = 0; u < NE; ++u) w[u] = 0x3ff00000u | 32768u | (uint32_t)((at + u * 64 + g * 8) & 0xff80);
-                    (void)rp;
-#elif VRX_TRIP_GROUP_MAJOR
+#else
                     {   // the group's U words are adjacent (padding words fill a short last trip)
                         const uint4 q4 = *reinterpret_cast<const uint4*>(ring + (at & (VRX_RING - 1)) + g * U);
                         const uint32_t qq[4] = {q4.x, q4.y, q4.z, q4.w};
 #pragma unroll
                         for (int u = 0; u < NE; ++u) w[u] = qq[u];
-                        (void)rp;
                     }
-#else
-#pragma unroll
-                    for (int u = 0; u < NE; ++u) w[u] = rp[u * G];
 #endif
 #ifdef VRX_X_EMPTY
 #pragma unroll
@@ -869,16 +764,10 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
 #endif
                     }
                 };
-#if VRX_F1_FULLTRIPS
-                // (the words that pad a round's last trip carry the value 0: executing them is
-                //  harmless and saves the three partial-trip variants of the loop body)
-                for (int at = base; at < end; at += U * G) trip(at, std::integral_constant<int, 4>());
-#else
                 for (int at = base; at < full_end; at += U * G) trip(at, std::integral_constant<int, 4>());
                 if (tail == 1) trip(full_end, std::integral_constant<int, 1>());
                 if (tail == 2) trip(full_end, std::integral_constant<int, 2>());
                 if (tail == 3) trip(full_end, std::integral_constant<int, 3>());
-#endif
                 continue;
             }
             for (int at = base; at < full_end; at += U * G) {
