@@ -1,4 +1,5 @@
-"""Worker of tests/test_host_cpu.py::test_sharded_wrap_gloo_world2 (one process per rank).
+"""Worker of tests/test_host_cpu.py::test_sharded_wrap_gloo_world2 / _wider_than_n_init (one
+process per rank).
 
 The device restarts are replaced by the CPU oracle (test infrastructure) so that the complete
 sharded control flow of vireo_amd.vireo_wrap -- the C continuation of the NumPy random
@@ -15,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main(rank, world, port, out_path):
+def main(rank, world, port, out_path, n_init=4):
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank,
                             world_size=world)
@@ -83,7 +84,7 @@ def main(rank, world, port, out_path):
     import io
     import contextlib
     with contextlib.redirect_stdout(io.StringIO()):
-        rv = W.vireo_wrap(AD, DP, n_donor=4, n_init=4, random_seed=2, comm=GlooComm())
+        rv = W.vireo_wrap(AD, DP, n_donor=4, n_init=n_init, random_seed=2, comm=GlooComm())
     rv["n_fits_on_rank"] = len(fitted)
     with open(out_path, "wb") as f:
         pickle.dump(rv, f)
@@ -92,4 +93,5 @@ def main(rank, world, port, out_path):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
+    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4],
+         int(sys.argv[5]) if len(sys.argv) > 5 else 4)

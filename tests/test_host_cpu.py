@@ -147,6 +147,32 @@ def test_sharded_wrap_gloo_world2(tmp_path):
     assert sorted(fits) == [2, 3]
 
 
+def test_sharded_wrap_gloo_wider_than_n_init(tmp_path):
+    """A shard wider than n_init (a donor VCF fixes the genotypes -> n_init = 1, on 2 GPUs): the
+    rank that owns no restart still sizes its runner, joins the all-gather and receives the
+    winner (restart_batch raised on n_owned = 0 and rank 0 hung in the gather)."""
+    from vireo_amd.restarts import restart_batch
+    for wide in (True, False):
+        assert restart_batch(8, 0, 1 << 22, wide) == 1
+        assert restart_batch(4, 0, 1000, wide) == 1
+    port = _free_port()
+    outs = [str(tmp_path / ("rank%d.pkl" % r)) for r in range(2)]
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"),
+                               str(r), "2", str(port), outs[r], "1"], env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    g = gold.load("c1_wrap_seed2_init1")
+    fits = []
+    for path in outs:
+        rv = pickle.load(open(path, "rb"))
+        fits.append(rv["n_fits_on_rank"])
+        for k in ("ID_prob", "GT_prob", "doublet_prob", "doublet_LLR", "theta_mean", "theta_sum",
+                  "LB_list"):
+            assert np.array_equal(rv[k], g[k]), k
+    assert sorted(fits) == [0, 2]     # the restart and its refinement on rank 0, nothing on rank 1
+
+
 def test_match_and_optimal_match():
     from vireo_amd import match, optimal_match
     assert list(match([5, 9, 1], [1, 2, 5, 7, 9])) == [2, 4, 0]

@@ -611,7 +611,7 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
 static int pick_rw_cell(int64_t n_var, int64_t n_cell) {
     const int n_slab_c = (int)((n_var + 511) / 512);
     auto cost = [&](int rw) {  // rounds x rows per wave x slabs per workgroup
-        const int64_t tiles = (n_cell + 16 * (int64_t)rw - 1) / (16 * (int64_t)rw);
+        const int64_t tiles = (n_cell + VRX_LDS_WAVES * (int64_t)rw - 1) / (VRX_LDS_WAVES * (int64_t)rw);
         const int64_t ranges = std::max<int64_t>(
             1, std::min<int64_t>(n_slab_c, env_int("VIREO_LDS_BLOCKS", 1024) / std::max<int64_t>(tiles, 1)));
         const int64_t w = tiles * ranges;
@@ -842,8 +842,8 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
         if (!force_host && lds0 != 0 && (force_dev || big)) {
             bool built = false;
             int rc = device_build(p.get(), colptr, rowidx, ad, dp, pick_rw_cell(n_var, n_cell),
-                                  std::min(512, std::max(16, env_int("VIREO_LDS_SLAB_CELL", 512))),
-                                  std::min(1024, std::max(16, env_int("VIREO_LDS_SLAB_VAR", 1024))), forms,
+                                  std::min(VRX_LDS_SLAB_BYTES / 256, std::max(16, env_int("VIREO_LDS_SLAB_CELL", VRX_LDS_SLAB_BYTES / 256))),
+                                  std::min(VRX_LDS_SLAB_BYTES / 128, std::max(16, env_int("VIREO_LDS_SLAB_VAR", VRX_LDS_SLAB_BYTES / 128))), forms,
                                   lds0 != 1, &built);
             if (rc) return rc;
             if (built) {
@@ -965,7 +965,7 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
             const int rw_cell = pick_rw_cell(n_var, n_cell);
             if (cell_form == 1 || max_count < 2048) {
                 rc = build_tiled(p->by_cell, colptr, rowidx, cval.data(), rw_cell,
-                                 std::min(512, std::max(16, env_int("VIREO_LDS_SLAB_CELL", 512))),
+                                 std::min(VRX_LDS_SLAB_BYTES / 256, std::max(16, env_int("VIREO_LDS_SLAB_CELL", VRX_LDS_SLAB_BYTES / 256))),
                                  lds != 1, cell_form == 1 ? 1 : 0, 1, p->stream);
                 if (rc) return rc;
             }
@@ -974,7 +974,7 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
         if ((var_form == 2 || max_count < 2048) &&
             (lds == 1 || nnz >= (int64_t)env_int("VIREO_LDS_MIN_NNZ_VAR", 32000000))) {
             rc = build_tiled(p->by_var, rptr.data(), ridx.data(), rval.data(), VRX_LDS_RW_VARIANT,
-                             std::min(1024, std::max(16, env_int("VIREO_LDS_SLAB_VAR", 1024))),
+                             std::min(VRX_LDS_SLAB_BYTES / 128, std::max(16, env_int("VIREO_LDS_SLAB_VAR", VRX_LDS_SLAB_BYTES / 128))),
                              lds != 1, var_form == 2 ? 2 : 0, 0, p->stream);
             if (rc) return rc;
         }
@@ -1227,8 +1227,8 @@ extern "C" int vrx_model_create(vrx_problem* p, const vrx_model_cfg* cfg, vrx_mo
     const size_t th = (size_t)(m->R * m->th_rows * m->th_cols);
     VRX_HIP(m->ID.alloc((size_t)(m->M * m->Kt)));
     VRX_HIP(m->LID.alloc((size_t)(m->M * m->Kt)));
-    VRX_HIP(m->mu.alloc(th * m->R));
-    VRX_HIP(m->sm.alloc(th * m->R));
+    VRX_HIP(m->mu.alloc(th));  // (th already counts the R restarts)
+    VRX_HIP(m->sm.alloc(th));
     VRX_HIP(m->prior1.alloc(th));
     VRX_HIP(m->prior2.alloc(th));
     VRX_HIP(m->S.alloc((size_t)m->NKt * 2));
@@ -2085,13 +2085,14 @@ extern "C" int vrx_model_step(vrx_model* m, int32_t which, double* elbo_out) {
     return prof_drain(m);
 }
 
-#ifdef VRX_TIMING
-// scratch builds only: read and clear the per-pass cycle counters of vrx_spmm_lds
-extern "C" int vrx_debug_timing(unsigned long long* out16) {
+#ifdef VRX_PROBE_BUILD
+// scratch builds only (scratch/vrx_probe.h): read and clear the per-wave records of vrx_spmm_lds
+extern "C" int vrx_debug_probe(unsigned long long* rec) {
     VRX_HIP(hipDeviceSynchronize());
-    VRX_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(vrx_timing), 16 * sizeof(unsigned long long)));
-    unsigned long long z[16] = {};
-    VRX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(vrx_timing), z, sizeof z));
+    VRX_HIP(hipMemcpyFromSymbol(rec, HIP_SYMBOL(vrx_probe_rec), sizeof(vrx_probe_rec)));
+    void* dev = nullptr;
+    VRX_HIP(hipGetSymbolAddress(&dev, HIP_SYMBOL(vrx_probe_rec)));
+    VRX_HIP(hipMemset(dev, 0, sizeof(vrx_probe_rec)));
     return VRX_OK;
 }
 #endif

@@ -328,7 +328,11 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_spmm(
 // Output: one partial array per contracted range (summed in fixed order afterwards).
 typedef double vrx_d2 __attribute__((ext_vector_type(2)));
 typedef uint32_t vrx_u2 __attribute__((ext_vector_type(2)));
-constexpr int VRX_RING = 512;   // entries per wave
+typedef uint32_t vrx_u4 __attribute__((ext_vector_type(4)));
+#ifndef VRX_LDS_RING
+#define VRX_LDS_RING 512
+#endif
+constexpr int VRX_RING = VRX_LDS_RING;   // entries per wave
 constexpr int VRX_CHUNK = 256;  // entries per refill (64 lanes x 16 B of one LDS-DMA load)
 #ifndef VRX_LDS_U_DEF
 #define VRX_LDS_U_DEF 4
@@ -338,6 +342,28 @@ constexpr int VRX_CHUNK = 256;  // entries per refill (64 lanes x 16 B of one LD
 #ifndef VRX_LDS_WAVES
 #define VRX_LDS_WAVES 16
 #endif
+#ifndef VRX_LDS_PRECISE
+#define VRX_LDS_PRECISE 1
+#endif
+#ifndef VRX_LDS_L2PF
+#define VRX_LDS_L2PF 0
+#endif
+#if VRX_LDS_L2PF
+#define VRX_LDS_REGS __attribute__((amdgpu_num_vgpr(127)))
+#else
+#define VRX_LDS_REGS
+#endif
+#ifndef VRX_LDS_AHEAD
+#define VRX_LDS_AHEAD 0
+#endif
+// LDS of a pass = one 2-KiB entry ring per wave + the slab; a slab is staged through PF 16-B
+// registers per thread: 16 waves: 32 KiB + 8 x 16 KiB = 160 KiB
+#ifdef VRX_LDS_PF_DEF
+constexpr int VRX_LDS_PF = VRX_LDS_PF_DEF;
+#else
+constexpr int VRX_LDS_PF = (160 * 1024 - VRX_LDS_WAVES * VRX_RING * 4) / (VRX_LDS_WAVES * 64 * 16);
+#endif
+constexpr int VRX_LDS_SLAB_BYTES = VRX_LDS_PF * VRX_LDS_WAVES * 64 * 16;
 // Word order inside a trip (U entries for each of the G lane groups).  Pair words (FORM 0):
 // entry-major, word j of group g at j * G + g.  AD/BD words (FORM 1, 2): group-major, the U
 // words of a group adjacent (g * U + u), so that a lane takes its trip with ONE ds_read_b128
@@ -382,15 +408,21 @@ constexpr int VRX_LDS_U = VRX_LDS_U_DEF;    // entries per trip and group; rows 
 // then their BD entries, accumulated into S2 = BD @ ID (SS = S1 + S2 at the store); each phase is
 // padded to its own longest row.  ~22 % more slots than the (ad, dp) pair words, but 7 instead of
 // ~15 vector instructions per slot, no conversions, and counts of any size.
-#ifdef VRX_TIMING
-__device__ unsigned long long vrx_timing[16];  // per pass: total, barrier 1, barrier 2, stage, waves
+// Probe hooks: the product build defines them away.  A scratch build with -DVRX_PROBE_BUILD includes
+// scratch/vrx_probe.h, which times the bracketed statements with s_memtime.
+#ifdef VRX_PROBE_BUILD
+#include "../../scratch/vrx_probe.h"
+#else
+#define VRX_PROBE_BEGIN
+#define VRX_PROBE(var, stmt) stmt;
+#define VRX_PROBE_END
 #endif
 // PADK: 0 = rows of exactly 16 contiguous columns (flat slab copy); 1 = any K / row stride
 // (element-wise staging into zero-padded rows, masked stores); 2 = AD/BD forms with even K and
 // even row stride (column blocks of wider operands, restart batches, K = 2 ... 14): as 1, but
 // a 16-B unit is either whole or absent, so it is staged with one load.
 template <int LPE, int MODE, int RW, int PADK, int SPLIT, int FORM = 0>
-__global__ __launch_bounds__(VRX_LDS_WAVES * 64)
+__global__ __launch_bounds__(VRX_LDS_WAVES * 64) VRX_LDS_REGS
     void vrx_spmm_lds(
     const uint32_t* __restrict__ ent, const int64_t* __restrict__ wave_start,
     const int32_t* __restrict__ bnd, const int32_t* __restrict__ rowmap, int n_slab,
@@ -404,7 +436,7 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
     constexpr int XD = MODE == 1 ? 2 : 1;  // doubles per (contracted row, column)
     constexpr int CP = 16 / LPE;           // dense columns per lane (LPE lanes cover K <= 16)
     constexpr int NQ = FORM == 1 ? CP / 2 : CP * XD / 2;  // 16-B reads per lane per entry
-    constexpr int PF = 8;                  // 16-B prefetch registers per thread: 128 KiB / 1024
+    constexpr int PF = VRX_LDS_PF;         // 16-B prefetch registers per thread (a slab / the workgroup)
     constexpr int NV = MODE == 0 ? 2 : 1;  // accumulated values per column
     constexpr int U = VRX_LDS_U;           // entries per trip and group
     static_assert(RW % G == 0 && 2 * (RW / G) < 63, "rows per wave");
@@ -412,6 +444,14 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
                   "AD/BD forms");
     constexpr int PH = FORM == 2 ? 2 : 1;  // phases of a round (FORM 2: AD entries, then BD entries)
     constexpr int NRV = NR * PH;           // (round, phase) pairs per slab
+    // AD/BD forms staged in whole 16-B units: the slab prefetch is exactly PF vector loads per
+    // thread, every one of them unconditional (lanes outside the slab re-read a valid unit; the
+    // rows / columns they fill are never referenced by a word resp. never stored), so the walk
+    // can leave the prefetch in flight while it waits for a chunk of its stream
+    constexpr bool PRECISE = FORM != 0 && PADK != 1 && VRX_LDS_PRECISE;
+    constexpr bool AHEAD = FORM != 0 && VRX_LDS_AHEAD;  // ring words read a trip ahead
+    constexpr int L2PF = FORM != 0 ? VRX_LDS_L2PF : 0;   // chunks the L2 look-ahead runs beyond the LDS-DMA
+    constexpr int NPF = PF + 1;  // + the bnd words of the next slab
     extern __shared__ __attribute__((aligned(16))) char vrx_smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // LDS rows are padded to a multiple of CP columns (zeros); FORM 1: two halves of 16 columns
@@ -454,7 +494,7 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
     // PADK: K columns become KP columns per LDS row (zero filled).  Thread t stages the 16-B
     // unit j0 = t % upr of rows r0 + i*rstep (t below the largest multiple T of upr), so the
     // unit's column never changes and nothing is divided inside the loop.
-    double2 pf[PF];
+    vrx_d2 pf[PF];  // (a native vector type: struct copies would keep the array in scratch)
     const int upr = KP * XD / 2;  // 16-B units per LDS row
     constexpr int NT = VRX_LDS_WAVES * 64;  // threads of the workgroup
     const int padT = NT / upr * upr, j0 = threadIdx.x % upr, r0 = threadIdx.x / upr;
@@ -465,11 +505,14 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
         const int64_t rows = min((int64_t)slab_rows, n_contract - row0);
         if (!PADK) {  // rows are contiguous 16-B units: flat copy
             const int n16 = (int)(rows * K * XD / 2);
-            const double2* src = reinterpret_cast<const double2*>(X + row0 * K * XD);
+            const vrx_d2* src = reinterpret_cast<const vrx_d2*>(X + row0 * K * XD);
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
                 const int at = threadIdx.x + i * NT;
-                pf[i] = at < n16 ? src[at] : make_double2(0.0, 0.0);
+                if (PRECISE)
+                    pf[i] = src[min(at, n16 - 1)];
+                else
+                    pf[i] = at < n16 ? src[at] : vrx_d2{0.0, 0.0};
             }
         } else {
             // 32-bit offsets from one wave-uniform base (scalar base + vector offset loads): the
@@ -486,7 +529,10 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
 #pragma unroll
                 for (int i = 0; i < PF; ++i) {
                     const bool in = pad_act && m0 && r0 + i * rstep < rows32;
-                    pf[i] = in ? *reinterpret_cast<const double2*>(src + off0 + i * step) : make_double2(0.0, 0.0);
+                    if (PRECISE)  // (offset 0: the first unit of the slab, always there)
+                        pf[i] = *reinterpret_cast<const vrx_d2*>(src + (in ? off0 + i * step : 0));
+                    else
+                        pf[i] = in ? *reinterpret_cast<const vrx_d2*>(src + off0 + i * step) : vrx_d2{0.0, 0.0};
                 }
             } else if (FORM == 1) {  // unit j0 = columns 2*(j0 & 7), +1 of half j0 >> 3
                 const int cc = 2 * (j0 & 7);
@@ -495,7 +541,7 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
 #pragma unroll
                 for (int i = 0; i < PF; ++i) {
                     const bool in = pad_act && r0 + i * rstep < rows32;
-                    double2 v;
+                    vrx_d2 v;
                     v.x = in && m0 ? src[off0 + i * step] : 0.0;
                     v.y = in && m1 ? src[off0 + i * step + 1] : 0.0;
                     pf[i] = v;
@@ -506,7 +552,7 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
 #pragma unroll
                 for (int i = 0; i < PF; ++i) {
                     const bool in = pad_act && m0 && r0 + i * rstep < rows32;
-                    pf[i] = in ? reinterpret_cast<const double2*>(src)[off0 + i * step] : make_double2(0.0, 0.0);
+                    pf[i] = in ? reinterpret_cast<const vrx_d2*>(src)[off0 + i * step] : vrx_d2{0.0, 0.0};
                 }
             } else {  // unit j0 = columns 2*j0, 2*j0 + 1
                 const bool m0 = 2 * j0 < K, m1 = 2 * j0 + 1 < K;
@@ -514,7 +560,7 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
 #pragma unroll
                 for (int i = 0; i < PF; ++i) {
                     const bool in = pad_act && r0 + i * rstep < rows32;
-                    double2 v;
+                    vrx_d2 v;
                     v.x = in && m0 ? src[off0 + i * step] : 0.0;
                     v.y = in && m1 ? src[off0 + i * step + 1] : 0.0;
                     pf[i] = v;
@@ -523,7 +569,7 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
         }
     };
     auto slab_store = [&]() {
-        double2* dst = reinterpret_cast<double2*>(slab);
+        vrx_d2* dst = reinterpret_cast<vrx_d2*>(slab);
         if (!PADK) {
             const int n16 = slab_doubles / 2;
 #pragma unroll
@@ -542,15 +588,17 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
 
     // ---- entry stream: global -> LDS directly (LDS-DMA: no staging registers, no ds_write).
     // A chunk is 256 words (one global_load_lds_dwordx4 per wave) on the absolute 256-word grid
-    // of the wave's stream; the ring holds two.  A chunk is issued as soon as the slot it goes
-    // to has been vacated, and awaited (vmcnt(0)) when the walk reaches it one chunk later.
-    // The compiler does not see these loads: its own vmcnt waits only become stricter.
+    // of the wave's stream; the ring holds two.  When the walk enters a chunk it waits for that
+    // chunk and then issues the next one into the slot it has just left, so exactly one chunk
+    // is in flight, a chunk ahead of the walk.  The compiler does not see these loads: its own
+    // vmcnt waits only become stricter.  The walk's wait is exact where the instruction count
+    // of the slab prefetch is fixed (PRECISE): the prefetch of the next slab, issued after the
+    // chunk, stays in flight (s_waitcnt vmcnt(NPF)) instead of being drained with it.
     const int stream_lo = __builtin_amdgcn_readfirstlane(bw[(int64_t)s_lo * NRV]) & ~(U * G - 1);
     const int stream_end = __builtin_amdgcn_readfirstlane(bw[(int64_t)s_hi * NRV]) & ~(U * G - 1);
     const int base0 = stream_lo & ~(VRX_CHUNK - 1);
     const int clamp_last = max(stream_end - 4, 0);  // lanes past the range re-read its last 16 B
     const uint32_t ring_lds = (uint32_t)(wave * VRX_RING * 4);  // (dynamic LDS starts at 0)
-    int landed_end = base0, issued_end = base0;
     auto dma_issue = [&](int pos) {
         const uint32_t* gsrc = stream + min(pos + 4 * lane, clamp_last);
         const uint32_t dst =
@@ -562,23 +610,37 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
             : "=&s"(keep)
             : "v"(gsrc), "s"(dst)
             : "memory");
-        issued_end = pos + VRX_CHUNK;
-    };
-    if (base0 < stream_end) dma_issue(base0);
-    if (base0 + VRX_CHUNK < stream_end) dma_issue(base0 + VRX_CHUNK);
-    // Ring work happens only at the first trip and at chunk boundaries: `ring_evt` is the next
-    // such trip position, so a trip pays one scalar compare (at: multiple of U*G, wave-uniform).
-    int ring_evt = stream_lo;
-    auto ring_need = [&](int at) {
-        if (at < ring_evt) return;
-        if (at >= landed_end) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            landed_end = issued_end;
+        if (L2PF) {
+            // A plain load touches every 128-B line of a chunk further ahead, so that the LDS-DMA
+            // of that chunk later hits L2 (one 1-KiB chunk in flight per wave cannot cover the HBM
+            // latency at the rate the walk consumes the stream).  Its result is never used; v127
+            // is outside the register budget given to the compiler (amdgpu_num_vgpr), so a
+            // result landing thousands of cycles later never hits a live value.  One such load
+            // follows EVERY chunk, which is what the walk's vmcnt counts assume.
+            const uint32_t* psrc = stream + min(pos + L2PF * VRX_CHUNK + 4 * lane, clamp_last);
+            asm volatile("global_load_dword v127, %0, off" : : "v"(psrc) : "memory", "v127");
         }
-        if ((at & (VRX_CHUNK - 1)) == 0 && at > base0 && at + VRX_CHUNK < stream_end &&
-            at + VRX_CHUNK >= issued_end)
-            dma_issue(at + VRX_CHUNK);  // into the slot of the chunk just finished
-        ring_evt = (at & ~(VRX_CHUNK - 1)) + VRX_CHUNK;
+    };
+    // ND chunks are in flight ahead of the walk (the ring holds ND + 1): when the walk enters
+    // the chunk at ring_evt it waits for that chunk -- the ND - 1 younger chunks, and the slab
+    // prefetch if it was issued after the chunk, stay in flight -- and issues the chunk ND
+    // ahead into the slot it has just left (positions past the wave's range re-read its last
+    // words).
+    constexpr int ND = VRX_RING / VRX_CHUNK - 1;
+    if (base0 < stream_end)
+#pragma unroll
+        for (int i = 0; i < ND; ++i) dma_issue(base0 + i * VRX_CHUNK);
+    int ring_evt = base0;     // the chunk boundary the walk services next (multiple of CHUNK)
+    int since_fetch = ND;     // chunks issued since the last slab prefetch (ND: none in flight)
+    auto ring_event = [&]() {
+        constexpr int YOUNGER = (ND - 1) + (L2PF ? ND : 0);  // chunks (and look-ahead loads) behind it
+        if (PRECISE && since_fetch < ND)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER + NPF) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
+        since_fetch = min(since_fetch + 1, ND);
+        dma_issue(ring_evt + ND * VRX_CHUNK);
+        ring_evt += VRX_CHUNK;
     };
     // one entry of this group's segment: word -> 4 column slices -> FMAs
     auto entry = [&](uint32_t w, double (&a)[NQ][2], double (&a2)[NQ][2]) {
@@ -600,43 +662,32 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
         }
     };
 
+    // bnd words of a slab: stream offset (a multiple of U*G) | entries in the round's last trip
+    // (0 = a full trip) for each (round, phase), then the first word of the next slab: lane i
+    // holds word i, ONE vector load a slab ahead (it is part of the prefetch the walk counts)
     int bvec = bw[(int64_t)s_lo * NRV + min(lane, NRV)];
     slab_fetch(s_lo);
-#ifdef VRX_TIMING
-    unsigned long long tm_bar1 = 0, tm_bar2 = 0, tm_stage = 0;
-    const unsigned long long tm_start = __builtin_amdgcn_s_memtime();
-#define VRX_TM(var, stmt)                                            \
-    {                                                                \
-        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
-        stmt;                                                        \
-        var += __builtin_amdgcn_s_memtime() - t_;                   \
+    vrx_u4 wnext = {0u, 0u, 0u, 0u}, wnext2 = wnext;  // (AHEAD) the words of the trip at hand
+    if (AHEAD && FORM != 0 && stream_lo < stream_end) {
+        ring_event();  // the first chunk
+        wnext = *reinterpret_cast<const vrx_u4*>(ring + (stream_lo & (VRX_RING - 1)) + g * U);
     }
-#else
-#define VRX_TM(var, stmt) stmt;
-#endif
+    VRX_PROBE_BEGIN
     for (int s = s_lo; s < s_hi; ++s) {
-#ifndef VRX_X_NOBAR1
-        VRX_TM(tm_bar1, __syncthreads())  // every wave is done reading the previous slab
-#endif
-#ifdef VRX_X_NOSTAGE
-        if (s == s_lo)
-#endif
-        VRX_TM(tm_stage, slab_store())
-#ifndef VRX_X_NOSTAGE
-        if (s + 1 < s_hi) slab_fetch(s + 1);
-#endif
+        VRX_PROBE(tm_bar1, __syncthreads())  // every wave is done reading the previous slab
+        VRX_PROBE(tm_stage, slab_store())
+        if (s + 1 < s_hi) {  // (with the bnd load below: NPF vector loads)
+            slab_fetch(s + 1);
+            since_fetch = 0;
+        }
         const int bcur = bvec;
         if (s + 1 < s_hi) bvec = bw[(int64_t)(s + 1) * NRV + min(lane, NRV)];
-#ifndef VRX_X_NOBAR2
-        VRX_TM(tm_bar2, __syncthreads())
-#endif
+        VRX_PROBE(tm_bar2, __syncthreads())
 #pragma unroll
         for (int rv = 0; rv < NRV; ++rv) {
             const int r = rv / PH;
-            // the round's entries are stored trip-major: word (base + j*G + g) is the j-th
-            // entry of the row owned by group g (zero words where that row is shorter)
-            // bnd = stream offset (a multiple of U*G) | entries in the round's last trip
-            // (0 = a full trip): the zero words that pad the last trip are not executed
+            // the round's entries are stored trip-major; the zero words that pad the round's
+            // last trip are not executed
             const int braw = __builtin_amdgcn_readlane(bcur, rv);
             const int base = braw & ~(U * G - 1), tail = braw & (U - 1);
             const int end = __builtin_amdgcn_readlane(bcur, rv + 1) & ~(U * G - 1);
@@ -649,44 +700,33 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
                 // before the first FMA; the FMAs of the first half wait for their four reads
                 // only.  The value is the high dword of an IEEE double (low dword 0), so there
                 // is no conversion: 3 VALU instructions of overhead per entry.
-                auto trip = [&](int at, auto ne_tag) {
+                auto trip = [&](int at, auto ne_tag, const vrx_u4& wcur, vrx_u4& wnxt) {
                     constexpr int NE = decltype(ne_tag)::value;
                     uint32_t w[NE];
-#ifndef VRX_X_NODMA
-                    ring_need(at);
-#endif
-#ifdef VRX_X_NORING
+                    if (AHEAD) {
+                        // this trip's words were requested a trip ago; the next trip's (the
+                        // stream is contiguous across rounds and slabs) are requested now, ahead
+                        // of the slices, so that their LDS round trip hides behind this trip
+                        const uint32_t qq[4] = {wcur[0], wcur[1], wcur[2], wcur[3]};
 #pragma unroll
-                    for (int u = 0; u < NE; ++u) w[u] = 0x3ff00000u | 32768u | (uint32_t)((at + u * 64 + g * 8) & 0xff80);
-#else
-                    {   // the group's U words are adjacent (padding words fill a short last trip)
+                        for (int u = 0; u < NE; ++u) w[u] = qq[u];
+                        const int nx = at + U * G;
+                        if (nx >= ring_evt) VRX_PROBE(tm_dma, ring_event())
+                        wnxt = *reinterpret_cast<const vrx_u4*>(ring + (nx & (VRX_RING - 1)) + g * U);
+                    } else {
+                        if (at >= ring_evt) VRX_PROBE(tm_dma, ring_event())
+                        // the group's U words are adjacent (padding words fill a short last trip)
                         const uint4 q4 = *reinterpret_cast<const uint4*>(ring + (at & (VRX_RING - 1)) + g * U);
                         const uint32_t qq[4] = {q4.x, q4.y, q4.z, q4.w};
 #pragma unroll
                         for (int u = 0; u < NE; ++u) w[u] = qq[u];
                     }
-#endif
-#ifdef VRX_X_EMPTY
-#pragma unroll
-                    for (int u = 0; u < NE; ++u) asm volatile("" ::"v"(w[u]));
-                    return;
-#endif
                     vrx_d2 x[NE][2];
                     // (all words have landed before the first slice is requested: the compiler's
                     //  own waits do not count the reads issued from inline assembly)
                     if (NE == 4) asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[NE - 1]));
                     if (NE == 3) asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[NE - 1]));
                     if (NE == 2) asm volatile("" : "+v"(w[0]), "+v"(w[NE - 1]));
-#ifdef VRX_X_NOREAD
-#pragma unroll
-                    for (int u = 0; u < NE; ++u)
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            uint32_t a;
-                            asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(a) : "v"(w[u]), "s"(0x3ff80u), "v"(qoff[q]));
-                            x[u][q] = vrx_d2{(double)__uint_as_float(a), 1.0};
-                        }
-#else
                     // ONE statement per trip: between separate asm statements the compiler pads
                     // with an s_nop.  Address = word offset bits | lane offset; two address
                     // registers alternate (an LDS instruction reads its address when it issues).
@@ -729,7 +769,6 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
                                          : "memory");
 #undef VRX_RD
                     }
-#endif
                     constexpr int H = NE > 2 ? 2 : NE;  // entries of the first half
                     if (NE > 2) {
                         if (NE == 4)
@@ -753,25 +792,39 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
                                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0][0]), "+v"(x[0][1]));
                         }
                         const double v = __builtin_bit_cast(double, vrx_u2{0u, w[u] & 0xfffc0000u});
-#ifdef VRX_X_NOFMA
-                        asm volatile("" ::"v"(v), "v"(x[u][0]), "v"(x[u][1]));
-#else
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
                             ac[q][0] = fma(v, x[u][q][0], ac[q][0]);
                             ac[q][1] = fma(v, x[u][q][1], ac[q][1]);
                         }
-#endif
                     }
                 };
-                for (int at = base; at < full_end; at += U * G) trip(at, std::integral_constant<int, 4>());
-                if (tail == 1) trip(full_end, std::integral_constant<int, 1>());
-                if (tail == 2) trip(full_end, std::integral_constant<int, 2>());
-                if (tail == 3) trip(full_end, std::integral_constant<int, 3>());
+                if (AHEAD) {  // two word registers alternate: trips in pairs, no copies
+                    int at = base;
+                    for (; at + U * G < full_end; at += 2 * U * G) {
+                        trip(at, std::integral_constant<int, 4>(), wnext, wnext2);
+                        trip(at + U * G, std::integral_constant<int, 4>(), wnext2, wnext);
+                    }
+                    if (at < full_end) {
+                        trip(at, std::integral_constant<int, 4>(), wnext, wnext2);
+                        wnext = wnext2;
+                    }
+                    if (tail) {
+                        if (tail == 1) trip(full_end, std::integral_constant<int, 1>(), wnext, wnext2);
+                        if (tail == 2) trip(full_end, std::integral_constant<int, 2>(), wnext, wnext2);
+                        if (tail == 3) trip(full_end, std::integral_constant<int, 3>(), wnext, wnext2);
+                        wnext = wnext2;
+                    }
+                    continue;
+                }
+                for (int at = base; at < full_end; at += U * G) trip(at, std::integral_constant<int, 4>(), wnext, wnext);
+                if (tail == 1) trip(full_end, std::integral_constant<int, 1>(), wnext, wnext);
+                if (tail == 2) trip(full_end, std::integral_constant<int, 2>(), wnext, wnext);
+                if (tail == 3) trip(full_end, std::integral_constant<int, 3>(), wnext, wnext);
                 continue;
             }
             for (int at = base; at < full_end; at += U * G) {
-                ring_need(at);
+                if (at >= ring_evt) ring_event();
                 // trips start at multiples of U*G = 64 words and the ring is a multiple of
                 // that, so a trip never wraps: one address, constant offsets
                 const uint32_t* rp = ring_g + (at & (VRX_RING - 1));
@@ -782,7 +835,7 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
                 for (int u = 0; u < US; ++u) entry(w[u], acc[r], acc2[r]);
             }
             if (tail) {  // (entries past the tail are zero words: harmless where SPLIT > 1)
-                ring_need(full_end);
+                if (full_end >= ring_evt) ring_event();
                 const uint32_t* rp = ring_g + (full_end & (VRX_RING - 1));
                 uint32_t w[US];
 #pragma unroll
@@ -796,15 +849,7 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
     // (every issued chunk has been awaited by the walk; this only guards the invariant that no
     //  LDS-DMA write is in flight when the workgroup's LDS is released)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef VRX_TIMING
-    if (lane == 0) {
-        atomicAdd(&vrx_timing[MODE * 8 + 0], __builtin_amdgcn_s_memtime() - tm_start);
-        atomicAdd(&vrx_timing[MODE * 8 + 1], tm_bar1);
-        atomicAdd(&vrx_timing[MODE * 8 + 2], tm_bar2);
-        atomicAdd(&vrx_timing[MODE * 8 + 3], tm_stage);
-        atomicAdd(&vrx_timing[MODE * 8 + 4], 1ull);
-    }
-#endif
+    VRX_PROBE_END
     // ---- every group holds the complete sums of its rows: store them ------------------------
     if (SPLIT > 1) {  // partial sums of the SPLIT entry streams: butterfly over the lanes
 #pragma unroll
@@ -820,10 +865,19 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
                     }
     }
     double* dst = out + (int64_t)blockIdx.y * n_rows * ld * NV;
-    if (kok && sub == 0) {
+    // (the lane's coordinates are derived again, from an opaque copy of the thread index: kept
+    //  live across the walk they would cost registers the walk has not got)
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63, wave_e = tid_e >> 6;
+    const int g_e = lane_e / LPE, sub_e = (lane_e % LPE) / LPR, kl_e = lane_e % LPR;
+    const bool kok_e = kl_e * CP < K;
+    {
+        const int g = g_e, kl = kl_e;
+        if (kok_e && sub_e == 0)
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            const int64_t row = rowmap[((int64_t)tile * VRX_LDS_WAVES + wave) * RW + r * G + g];
+            const int64_t row = rowmap[((int64_t)tile * VRX_LDS_WAVES + wave_e) * RW + r * G + g];
             if (row >= 0) {  // tile position -> row (rows are dealt to rounds by length)
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {

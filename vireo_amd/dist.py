@@ -22,8 +22,12 @@ from . import _lib
 
 
 def env_rank_world():
+    """(rank, world, device).  The device is the one ``counts.default_device`` gives every
+    problem and model of this process (VIREO_DEVICE, else LOCAL_RANK, else 0), so that the RCCL
+    communicator always lives on the GPU that holds the fits."""
+    from .counts import default_device
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
-            int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0"))))
+            default_device())
 
 
 class LocalComm:

@@ -81,6 +81,7 @@ def restart_batch(n_donor, n_owned, nnz, wide=True):
     column-block kernels are not tuned for strided operands): at most one sweep.  A problem small
     enough to be bound by kernel launches rather than by the stream takes a full batch of 16.
     VIREO_RESTART_BATCH overrides (1 = one restart at a time)."""
+    n_owned = max(1, int(n_owned))  # (a rank of a shard wider than n_init owns none)
     forced = int(os.environ.get("VIREO_RESTART_BATCH", "0"))
     if forced > 0:
         return max(1, min(forced, 16, n_owned))

@@ -284,7 +284,10 @@ def write_VCF(out_file, VCF_dat, GenoTags=['GT', 'AD', 'DP', 'PL']):
     head.append("#" + "\t".join(cols + list(VCF_dat['samples'])))
     geno = VCF_dat.get('GenoINFO')
     if (isinstance(geno, _GenoArrays) and list(GenoTags) == ['GT', 'AD', 'DP', 'PL']
-            and geno.PL.shape[2:] == (3,) and geno.call.shape[1] == len(VCF_dat['samples'])):
+            and geno.PL.shape[2:] == (3,) and geno.call.shape[1] == len(VCF_dat['samples'])
+            and len({len(VCF_dat['variants']), geno.call.shape[0], geno.AD.shape[0],
+                     geno.DP.shape[0], geno.PL.shape[0]}) == 1
+            and geno.AD.shape[1] == geno.DP.shape[1] == geno.PL.shape[1] == geno.call.shape[1]):
         # the records are formatted (and gzipped) by the library from the integer arrays
         fixed = VCF_dat['FixedINFO']
         n = len(VCF_dat['variants'])

@@ -166,8 +166,7 @@ def main(argv=None):
         out_dir = "./" + options.out_dir
     else:
         out_dir = options.out_dir
-    if not os.path.exists(out_dir):
-        os.mkdir(out_dir)
+    os.makedirs(out_dir, exist_ok=True)     # (one process per GPU may get here at once)
 
     cell_dat = load_cells(options)
     if options.cell_range is not None:                              # vireo.py:136-142
