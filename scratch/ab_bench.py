@@ -43,6 +43,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         dm.run_iters(1, theta_from_iter=0)
         _lib.lib().vrx_debug_probe(buf)
         rec = np.frombuffer(buf, dtype=np.uint64).reshape(2, MAXW, 8).astype(np.int64)
+        if os.environ.get("AB_DUMP"):
+            np.save(os.environ["AB_DUMP"], rec)
         timing = {}
         for mode, name in ((0, "variant"), (1, "cell")):
             r = rec[mode]

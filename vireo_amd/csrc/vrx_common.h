@@ -77,7 +77,15 @@ struct TiledStream {
     bool ready = false;
     int form = 0;  // 0: (ad, dp) pairs; 1: single-valued AD / BD entries (cell pass, FORM 1)
     int rw = 0, slab_rows = 0, n_slab = 0, n_tile = 0;
-    int n_range = 1;  // contracted ranges = gridDim.y of the LDS-resident pass
+    // The pass runs as n_wg persistent workgroups (one per CU); workgroup b walks the work items
+    // [wg_first[b], wg_first[b + 1]): item = (tile, first slab, end slab, slot) -- a contiguous
+    // run of one tile's slabs whose partial output goes to partial array `slot` (0, 1, ... in
+    // slab order inside a tile).  The (tile, slab) visits are cut into n_wg runs of equal cost.
+    int n_range = 1;  // partial arrays = the most pieces any tile is cut into
+    int n_wg = 0;
+    DevBuf<int32_t> items;     // 4 words per item
+    DevBuf<int32_t> wg_first;  // n_wg + 1
+    DevBuf<uint16_t> npiece;    // per piece row (n_vrows): partial arrays that hold a term of it
     DevBuf<uint32_t> ent;
     DevBuf<int64_t> wave_start;
     DevBuf<int32_t> bnd;

@@ -278,9 +278,85 @@ struct DevRows {
     const int2* val;
 };
 
+// Work list of an LDS-resident pass (TiledStream::items).  The (tile, slab) visits, tile-major,
+// are cut into n_wg contiguous runs of equal cost -- cost of a visit = the longest wave's trips in
+// that slab + the staging of the slab, in trips -- so that every CU is busy for the whole launch
+// and a tile is cut into few pieces (tiles + n_wg pieces at most: the partial outputs the
+// consumers add up).  bnd = the per-wave (slab, round) offsets on the host.
+static int plan_items(TiledStream& t, const int32_t* bnd, int64_t n_wave, int nrv, int n_cu,
+                      const int32_t* rowmap, int mode, hipStream_t s) {
+    constexpr int UG = VRX_LDS_U * (64 / VRX_LDS_LPE);
+    const int64_t per_wave = (int64_t)t.n_slab * nrv + 1, visits = (int64_t)t.n_tile * t.n_slab;
+    const int want = env_int(mode == 1 ? "VIREO_LDS_BLOCKS_CELL" : "VIREO_LDS_BLOCKS_VAR",
+                             env_int("VIREO_LDS_BLOCKS", std::max(1, n_cu)));
+    const int n_wg = (int)std::max<int64_t>(1, std::min<int64_t>(want, visits));
+    const double stage = (double)env_int("VIREO_LDS_STAGE_TRIPS_X10", 50) / 10.0;
+    std::vector<double> cost((size_t)visits);
+    parallel_chunks(t.n_tile, host_threads(), [&](int64_t t0, int64_t t1, int) {
+        for (int64_t tl = t0; tl < t1; ++tl)
+            for (int sl = 0; sl < t.n_slab; ++sl) {
+                int32_t longest = 0;
+                for (int w = 0; w < VRX_LDS_WAVES; ++w) {
+                    const int32_t* bw = bnd + (tl * VRX_LDS_WAVES + w) * per_wave;
+                    longest = std::max(longest, (bw[(int64_t)(sl + 1) * nrv] & ~(UG - 1)) -
+                                                    (bw[(int64_t)sl * nrv] & ~(UG - 1)));
+                }
+                cost[(size_t)(tl * t.n_slab + sl)] = (double)longest / UG + stage;
+            }
+    });
+    (void)n_wave;
+    double total = 0.0;
+    for (double c : cost) total += c;
+    std::vector<int32_t> items, first((size_t)n_wg + 1, 0), pieces((size_t)t.n_tile, 0);
+    double acc = 0.0;
+    int64_t u = 0;
+    for (int b = 0; b < n_wg; ++b) {
+        first[(size_t)b] = (int32_t)(items.size() / 4);
+        // run b ends at the visit where the accumulated cost passes (b + 1) / n_wg of the total
+        // (every run gets at least one visit while visits remain for the runs behind it)
+        const double goal = total * (double)(b + 1) / (double)n_wg;
+        int64_t end = u;
+        while (end < visits && (end == u || acc + cost[(size_t)end] * 0.5 <= goal) &&
+               visits - (end + 1) >= n_wg - 1 - b)
+            acc += cost[(size_t)end++];
+        if (b == n_wg - 1)
+            while (end < visits) acc += cost[(size_t)end++];
+        while (u < end) {  // cut the run at tile boundaries
+            const int64_t tl = u / t.n_slab, s0 = u % t.n_slab;
+            const int64_t s1 = std::min<int64_t>(t.n_slab, s0 + (end - u));
+            items.insert(items.end(), {(int32_t)tl, (int32_t)s0, (int32_t)s1, pieces[(size_t)tl]++});
+            u += s1 - s0;
+        }
+    }
+    first[(size_t)n_wg] = (int32_t)(items.size() / 4);
+    if (env_int("VIREO_LDS_PLAN_REVERSE", 0)) {  // (experiment: run b on workgroup n_wg - 1 - b)
+        std::vector<int32_t> it2, f2((size_t)n_wg + 1, 0);
+        for (int b = n_wg - 1; b >= 0; --b) {
+            f2[(size_t)(n_wg - 1 - b)] = (int32_t)(it2.size() / 4);
+            it2.insert(it2.end(), items.begin() + 4 * first[(size_t)b], items.begin() + 4 * first[(size_t)b + 1]);
+        }
+        f2[(size_t)n_wg] = (int32_t)(it2.size() / 4);
+        items.swap(it2);
+        first.swap(f2);
+    }
+    t.n_wg = n_wg;
+    t.n_range = 1;
+    for (int32_t c : pieces) t.n_range = std::max(t.n_range, (int)c);
+    VRX_REQUIRE(t.n_range < 65536, "tiled stream: a tile is cut into too many pieces");
+    std::vector<uint16_t> npiece((size_t)t.n_vrows, 0);
+    const int64_t tile_pos = (int64_t)VRX_LDS_WAVES * t.rw;
+    for (int64_t pos = 0; pos < (int64_t)t.n_tile * tile_pos; ++pos)
+        if (rowmap[(size_t)pos] >= 0) npiece[(size_t)rowmap[(size_t)pos]] = (uint16_t)pieces[(size_t)(pos / tile_pos)];
+    VRX_HIP(t.items.upload(items.data(), items.size(), s));
+    VRX_HIP(t.wg_first.upload(first.data(), first.size(), s));
+    VRX_HIP(t.npiece.upload(npiece.data(), npiece.size(), s));
+    VRX_HIP(hipStreamSynchronize(s));
+    return VRX_OK;
+}
+
 static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const int2* val,
                        int RW, int slab_rows, bool guard, int form, int mode, hipStream_t s,
-                       const DevRows* dev = nullptr) {
+                       int n_cu, const DevRows* dev = nullptr) {
     constexpr int G = 64 / VRX_LDS_LPE, U = VRX_LDS_U;
     const int NR = RW / G;
     TiledStream& t = o.tiled;
@@ -311,11 +387,6 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
         for (int32_t v = vptr[(size_t)r]; v < vptr[(size_t)r + 1]; ++v) vrow_row[(size_t)v] = (int32_t)r;
     const int64_t tile_rows = VRX_LDS_WAVES * (int64_t)RW;
     t.n_tile = (int)((n_vrows + tile_rows - 1) / tile_rows);
-    // one workgroup per CU at a time (LDS), so the grid should fill whole rounds of CUs:
-    // the largest n_range with n_tile * n_range <= target (4 rounds of 256 CUs by default)
-    const int want = env_int(mode == 1 ? "VIREO_LDS_BLOCKS_CELL" : "VIREO_LDS_BLOCKS_VAR",
-                             env_int("VIREO_LDS_BLOCKS", 1024));
-    t.n_range = std::max(1, std::min(t.n_slab, want / std::max(1, t.n_tile)));
     const int64_t n_wave = (int64_t)t.n_tile * VRX_LDS_WAVES;
     const int PH = form == 2 ? 2 : 1;  // phases of a round (form 2: AD entries, then BD entries)
     const int64_t per_wave = (int64_t)t.n_slab * NR * PH + 1;
@@ -439,7 +510,10 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
         VRX_HIP(hipGetLastError());
         VRX_HIP(t.rowmap.upload(rowmap.data(), rowmap.size(), s));
         if (t.split) VRX_HIP(t.vptr.upload(vptr.data(), vptr.size(), s));
+        VRX_HIP(hipMemcpyAsync(bnd.data(), t.bnd.p, bnd.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         VRX_HIP(hipStreamSynchronize(s));
+        const int rc = plan_items(t, bnd.data(), n_wave, NR * PH, n_cu, rowmap.data(), mode, s);
+        if (rc) return rc;
         t.ready = true;
         return VRX_OK;
     }
@@ -599,23 +673,24 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
     VRX_HIP(t.rowmap.upload(rowmap.data(), rowmap.size(), s));
     if (t.split) VRX_HIP(t.vptr.upload(vptr.data(), vptr.size(), s));
     VRX_HIP(hipStreamSynchronize(s));
+    const int rc = plan_items(t, bnd.data(), n_wave, NR * PH, n_cu, rowmap.data(), mode, s);
+    if (rc) return rc;
     t.ready = true;
     return VRX_OK;
 }
 
-// Rows per wave of the cell pass.  One workgroup per CU at a time: a launch of W workgroups
-// takes ceil(W / 256) rounds.  With many slabs W is ~1000 whatever the tile height; with one or
-// two slabs (few variants: clone mode) W = tiles x slabs, and the shorter tile wins when it
-// fills the last round better (200 k cells: 261 tiles of 768 rows = 2 rounds at 51 %, 391 tiles
-// of 512 rows = 2 rounds at 76 %).
-static int pick_rw_cell(int64_t n_var, int64_t n_cell) {
-    const int n_slab_c = (int)((n_var + 511) / 512);
-    auto cost = [&](int rw) {  // rounds x rows per wave x slabs per workgroup
+// Rows per wave of the cell pass.  The (tile, slab) visits of a pass are dealt to one workgroup
+// per CU (plan_items); a visit is not divisible, so with one or two slabs (few variants: clone
+// mode) the busiest CU gets ceil(visits / CUs) of them, and the shorter tile wins when that
+// rounds up less (200 k cells, one slab: 261 tiles of 768 rows = 2 visits on the busiest CU,
+// 391 tiles of 512 rows = 2 shorter ones).
+static int pick_rw_cell(int64_t n_var, int64_t n_cell, int n_cu) {
+    const int slab = VRX_LDS_SLAB_BYTES / 256;
+    const int n_slab_c = (int)((n_var + slab - 1) / slab);
+    auto cost = [&](int rw) {  // visits of the busiest CU x rows per wave
         const int64_t tiles = (n_cell + VRX_LDS_WAVES * (int64_t)rw - 1) / (VRX_LDS_WAVES * (int64_t)rw);
-        const int64_t ranges = std::max<int64_t>(
-            1, std::min<int64_t>(n_slab_c, env_int("VIREO_LDS_BLOCKS", 1024) / std::max<int64_t>(tiles, 1)));
-        const int64_t w = tiles * ranges;
-        return (double)((w + 255) / 256) * rw * (double)n_slab_c / (double)ranges;
+        const int64_t cus = std::max(1, n_cu);
+        return (double)((tiles * n_slab_c + cus - 1) / cus) * rw;
     };
     const int forced = env_int("VIREO_LDS_RW_CELL", 0);
     return forced == VRX_LDS_RW_CELL_SHORT ||
@@ -779,10 +854,10 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
     if ((rc = set_orient(p->by_var, n_var, n_cell, d_ridx.p, d_rval.p))) return rc;
     const DevRows cell_rows{d_colptr.p, d_row.p, d_cval.p}, var_rows{d_rptr.p, d_ridx.p, d_rval.p};
     rc = build_tiled(p->by_cell, colptr, nullptr, nullptr, rw_cell, slab_cell, guard, cell_form, 1, s,
-                     &cell_rows);
+                     p->n_cu, &cell_rows);
     if (rc) return rc;
     rc = build_tiled(p->by_var, rptr.data(), nullptr, nullptr, VRX_LDS_RW_VARIANT, slab_var, guard,
-                     var_form == 2 ? 2 : 0, 0, s, &var_rows);
+                     var_form == 2 ? 2 : 0, 0, s, p->n_cu, &var_rows);
     if (rc) return rc;
     VRX_HIP(hipStreamSynchronize(s));
     if (!p->by_cell.tiled.ready || !p->by_var.tiled.ready) {  // rejected by the padding guard
@@ -841,7 +916,7 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
                          nnz >= (int64_t)env_int("VIREO_LDS_MIN_NNZ_VAR", 32000000);
         if (!force_host && lds0 != 0 && (force_dev || big)) {
             bool built = false;
-            int rc = device_build(p.get(), colptr, rowidx, ad, dp, pick_rw_cell(n_var, n_cell),
+            int rc = device_build(p.get(), colptr, rowidx, ad, dp, pick_rw_cell(n_var, n_cell, p->n_cu),
                                   std::min(VRX_LDS_SLAB_BYTES / 256, std::max(16, env_int("VIREO_LDS_SLAB_CELL", VRX_LDS_SLAB_BYTES / 256))),
                                   std::min(VRX_LDS_SLAB_BYTES / 128, std::max(16, env_int("VIREO_LDS_SLAB_VAR", VRX_LDS_SLAB_BYTES / 128))), forms,
                                   lds0 != 1, &built);
@@ -962,11 +1037,11 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
     if ((max_count < 2048 || cell_form == 1) && lds != 0) {
         // cell pass: slabs of 512 W rows (128 KiB at K = 16); variant pass: 1024 ID rows
         if (lds == 1 || nnz >= (int64_t)env_int("VIREO_LDS_MIN_NNZ", 4000000)) {
-            const int rw_cell = pick_rw_cell(n_var, n_cell);
+            const int rw_cell = pick_rw_cell(n_var, n_cell, p->n_cu);
             if (cell_form == 1 || max_count < 2048) {
                 rc = build_tiled(p->by_cell, colptr, rowidx, cval.data(), rw_cell,
                                  std::min(VRX_LDS_SLAB_BYTES / 256, std::max(16, env_int("VIREO_LDS_SLAB_CELL", VRX_LDS_SLAB_BYTES / 256))),
-                                 lds != 1, cell_form == 1 ? 1 : 0, 1, p->stream);
+                                 lds != 1, cell_form == 1 ? 1 : 0, 1, p->stream, p->n_cu);
                 if (rc) return rc;
             }
         }
@@ -975,7 +1050,7 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
             (lds == 1 || nnz >= (int64_t)env_int("VIREO_LDS_MIN_NNZ_VAR", 32000000))) {
             rc = build_tiled(p->by_var, rptr.data(), ridx.data(), rval.data(), VRX_LDS_RW_VARIANT,
                              std::min(VRX_LDS_SLAB_BYTES / 128, std::max(16, env_int("VIREO_LDS_SLAB_VAR", VRX_LDS_SLAB_BYTES / 128))),
-                             lds != 1, var_form == 2 ? 2 : 0, 0, p->stream);
+                             lds != 1, var_form == 2 ? 2 : 0, 0, p->stream, p->n_cu);
             if (rc) return rc;
         }
     }
@@ -1642,7 +1717,7 @@ static int launch_lds_one(const Orient& o, hipStream_t s, const double* X, int K
                           const int32_t* ctl, int R) {
     const TiledStream& t = o.tiled;
     constexpr int XD = MODE == 1 ? 2 : 1, NV = MODE == 0 ? 2 : 1;
-    dim3 grid((unsigned)t.n_tile, (unsigned)t.n_range);
+    const unsigned grid = (unsigned)t.n_wg;  // persistent: one workgroup per CU walks its items
     // operands wider than 16 columns go through in blocks of 16 (the stream is re-read per
     // block, like the column chunks of the gather kernels)
     for (int c0 = 0; c0 < K; c0 += 16) {
@@ -1655,7 +1730,8 @@ static int launch_lds_one(const Orient& o, hipStream_t s, const double* X, int K
         auto kern = lds_kernel<LPE, MODE>(kb, K, K > 16, t.rw, t.form);
         VRX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        kern<<<grid, VRX_LDS_WAVES * 64, lds, s>>>(t.ent.p, t.wave_start.p, t.bnd.p, t.rowmap.p, t.n_slab,
+        kern<<<grid, VRX_LDS_WAVES * 64, lds, s>>>(t.ent.p, t.wave_start.p, t.bnd.p, t.rowmap.p, t.items.p,
+                                     t.wg_first.p, t.n_slab,
                                      t.slab_rows, o.n_contract, t.n_vrows,
                                      X + (size_t)c0 * (f1 ? 1 : XD), kb, K, dst + (size_t)c0 * NV, ctl, R);
         VRX_HIP(hipGetLastError());
@@ -1677,15 +1753,15 @@ static int launch_spmm_lds(vrx_model* m, const Orient& o, const double* X, int K
         const int64_t n = o.n_rows * K * NV;
         if ((int64_t)t.n_range * t.n_vrows >= 64 * o.n_rows)  // >= 64 terms per row on average
             vrx_sum_pieces_wave<<<(unsigned)((n * 64 + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
-                o.n_rows, K * NV, t.n_range, t.n_vrows, t.vptr.p, range_partial, out, m->ctl.p, m->R);
+                o.n_rows, K * NV, t.n_range, t.n_vrows, t.vptr.p, t.npiece.p, range_partial, out, m->ctl.p, m->R);
         else
             vrx_sum_pieces<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
-                o.n_rows, K * NV, t.n_range, t.n_vrows, t.vptr.p, range_partial, out, m->ctl.p, m->R);
+                o.n_rows, K * NV, t.n_range, t.n_vrows, t.vptr.p, t.npiece.p, range_partial, out, m->ctl.p, m->R);
         VRX_HIP(hipGetLastError());
     } else if (t.n_range > 1 && !defer_sum) {
         const int64_t n = o.n_rows * K * NV;
         vrx_sum_ranges<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
-            n, t.n_range, range_partial, out, m->ctl.p, m->R);
+            n, K * NV, t.npiece.p, range_partial, out, m->ctl.p, m->R);
         VRX_HIP(hipGetLastError());
     }
     return VRX_OK;
@@ -1755,7 +1831,7 @@ static int resolve_S(vrx_model* m) {
     if (!m->s_pending) return VRX_OK;
     const int64_t n = m->NKt * 2;
     vrx_sum_ranges<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, m->p->stream>>>(
-        n, m->p->by_var.tiled.n_range, m->RV.p, m->S.p, m->ctl.p, m->R);
+        n, m->Kt * 2, m->p->by_var.tiled.npiece.p, m->RV.p, m->S.p, m->ctl.p, m->R);
     VRX_HIP(hipGetLastError());
     m->s_pending = false;
     return VRX_OK;
@@ -1765,7 +1841,7 @@ static int resolve_LID(vrx_model* m) {
     if (!m->l_pending) return VRX_OK;
     const int64_t n = m->M * m->Kt;
     vrx_sum_ranges<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, m->p->stream>>>(
-        n, m->p->by_cell.tiled.n_range, m->RC.p, m->LID.p, m->ctl.p, m->R);
+        n, m->Kt, m->p->by_cell.tiled.npiece.p, m->RC.p, m->LID.p, m->ctl.p, m->R);
     VRX_HIP(hipGetLastError());
     m->l_pending = false;
     return VRX_OK;
@@ -1795,9 +1871,9 @@ static int theta_step(vrx_model* m, int update, bool defer_final = false) {
         m->w_valid = false;
     } else {
         if (update) {
-            const int nr = m->s_pending ? m->p->by_var.tiled.n_range : 0;
+            const uint16_t* np = m->s_pending ? m->p->by_var.tiled.npiece.p : nullptr;
             vrx_theta_partial<<<dim3(m->nb_theta, m->R), VRX_BLOCK, 0, s>>>(
-                m->NK, m->T, reinterpret_cast<double2*>(m->S.p), nr,
+                m->NK, m->T, reinterpret_cast<double2*>(m->S.p), np,
                 reinterpret_cast<const double2*>(m->RV.p), m->GT.p, m->part_theta.p, m->batch(),
                 m->ctl.p);
             VRX_HIP(hipGetLastError());
@@ -1876,7 +1952,7 @@ static int softmax_step(vrx_model* m, int update) {
     ProfScope ps(m, VRX_KERN_DENSE);
     hipStream_t s = m->p->stream;
     const double lu = -std::log((double)m->K);
-    const int nr = m->l_pending ? m->p->by_cell.tiled.n_range : 0;  // fused sum of the partials
+    const uint16_t* nr = m->l_pending ? m->p->by_cell.tiled.npiece.p : nullptr;  // fused sum of the partials
     m->l_pending = false;
 #define VRX_SM_CASE(KPV)                                                                        \
     case KPV:                                                                                   \

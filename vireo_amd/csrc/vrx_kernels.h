@@ -377,7 +377,7 @@ __host__ __device__ inline int64_t vrx_trip_slot(int64_t n, int g, int G, int U,
 #ifndef VRX_LDS_LPE_DEF
 #define VRX_LDS_LPE_DEF 4
 #define VRX_LDS_RWV_DEF 32
-#define VRX_LDS_RWC_DEF 48
+#define VRX_LDS_RWC_DEF 64
 #endif
 constexpr int VRX_LDS_RW_VARIANT = VRX_LDS_RWV_DEF, VRX_LDS_RW_CELL = VRX_LDS_RWC_DEF;
 constexpr int VRX_LDS_RW_CELL_SHORT = VRX_LDS_LPE_DEF == 1 ? 64 : 32;  // cell pass with one or two slabs, see vrx_problem_create
@@ -425,7 +425,8 @@ template <int LPE, int MODE, int RW, int PADK, int SPLIT, int FORM = 0>
 __global__ __launch_bounds__(VRX_LDS_WAVES * 64) VRX_LDS_REGS
     void vrx_spmm_lds(
     const uint32_t* __restrict__ ent, const int64_t* __restrict__ wave_start,
-    const int32_t* __restrict__ bnd, const int32_t* __restrict__ rowmap, int n_slab,
+    const int32_t* __restrict__ bnd, const int32_t* __restrict__ rowmap,
+    const int32_t* __restrict__ items, const int32_t* __restrict__ wg_first, int n_slab,
     int slab_rows, int64_t n_contract, int64_t n_rows, const double* __restrict__ X, int K,
     int ld, double* __restrict__ out, const int32_t* __restrict__ ctl, int n_batch) {
     if (vrx_all_stopped(ctl, n_batch)) return;
@@ -448,12 +449,13 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64) VRX_LDS_REGS
     // thread, every one of them unconditional (lanes outside the slab re-read a valid unit; the
     // rows / columns they fill are never referenced by a word resp. never stored), so the walk
     // can leave the prefetch in flight while it waits for a chunk of its stream
-    constexpr bool PRECISE = FORM != 0 && PADK != 1 && VRX_LDS_PRECISE;
+    constexpr bool PRECISE = FORM != 0 && VRX_LDS_PRECISE;
     constexpr bool AHEAD = FORM != 0 && VRX_LDS_AHEAD;  // ring words read a trip ahead
     constexpr int L2PF = FORM != 0 ? VRX_LDS_L2PF : 0;   // chunks the L2 look-ahead runs beyond the LDS-DMA
-    constexpr int NPF = PF + 1;  // + the bnd words of the next slab
+    constexpr int NPF = (PADK == 1 ? 2 : 1) * PF + 1;  // (element-wise: 2 loads per unit) + the bnd words of the next slab
     extern __shared__ __attribute__((aligned(16))) char vrx_smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (wave-uniform: scalar)
     // LDS rows are padded to a multiple of CP columns (zeros); FORM 1: two halves of 16 columns
     const int KP = FORM != 0 ? 16 : (K + CP - 1) / CP * CP;  // (whole lanes: CP columns each)
     const int slab_doubles = slab_rows * KP * XD;
@@ -461,11 +463,16 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64) VRX_LDS_REGS
     // below 64 KiB
     double* slab = reinterpret_cast<double*>(vrx_smem + VRX_LDS_WAVES * VRX_RING * 4);
     uint32_t* ring = reinterpret_cast<uint32_t*>(vrx_smem) + wave * VRX_RING;
-    const int tile = blockIdx.x;
-    // contracted range of this workgroup: slabs split as evenly as possible over gridDim.y
-    const int s_lo = (int)((int64_t)blockIdx.y * n_slab / gridDim.y);
-    const int s_hi = (int)((int64_t)(blockIdx.y + 1) * n_slab / gridDim.y);
-    if (s_lo >= s_hi) return;
+    // One persistent workgroup per CU walks its work items (TiledStream::items): a contiguous run
+    // of one tile's slabs each, whose sums go to partial array `slot`.
+    const int item_end = wg_first[blockIdx.x + 1];
+    VRX_PROBE_BEGIN
+    for (int item = wg_first[blockIdx.x]; item < item_end; ++item) {
+    const int tile = __builtin_amdgcn_readfirstlane(items[4 * item]);
+    const int s_lo = __builtin_amdgcn_readfirstlane(items[4 * item + 1]);
+    const int s_hi = __builtin_amdgcn_readfirstlane(items[4 * item + 2]);
+    const int slot = __builtin_amdgcn_readfirstlane(items[4 * item + 3]);
+    if (s_lo >= s_hi) continue;
     constexpr int LPR = LPE / SPLIT;  // lanes per entry: they cover LPR*CP >= K columns
     constexpr int US = U / SPLIT;     // entries per trip and lane
     static_assert(LPE % SPLIT == 0 && U % SPLIT == 0, "split");
@@ -526,24 +533,40 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64) VRX_LDS_REGS
                 const bool m0 = cc < K;
                 const int off0 = FORM == 1 ? r0 * 2 * ld + (j0 >> 3) * ld + cc : r0 * ld + cc;
                 const int step = FORM == 1 ? rstep * 2 * ld : rstep * ld;
+                if (PRECISE) {
+                    // unconditional loads: rows past the slab's last re-read it, units past K
+                    // re-read unit 0 (never referenced resp. never stored).  The offsets are formed
+                    // again for every slab from an opaque copy of the thread's first row: hoisted
+                    // out of the walk they would hold PF registers the walk has not got.
+                    int r0v = r0;
+                    asm volatile("" : "+v"(r0v));
+                    const int col = m0 ? (FORM == 1 ? (j0 >> 3) * ld + cc : cc) : 0;
+                    const int pitch = FORM == 1 ? 2 * ld : ld;
 #pragma unroll
-                for (int i = 0; i < PF; ++i) {
-                    const bool in = pad_act && m0 && r0 + i * rstep < rows32;
-                    if (PRECISE)  // (offset 0: the first unit of the slab, always there)
-                        pf[i] = *reinterpret_cast<const vrx_d2*>(src + (in ? off0 + i * step : 0));
-                    else
+                    for (int i = 0; i < PF; ++i)
+                        pf[i] = *reinterpret_cast<const vrx_d2*>(
+                            src + (min(r0v + i * rstep, rows32 - 1) * pitch + col));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < PF; ++i) {
+                        const bool in = pad_act && m0 && r0 + i * rstep < rows32;
                         pf[i] = in ? *reinterpret_cast<const vrx_d2*>(src + off0 + i * step) : vrx_d2{0.0, 0.0};
+                    }
                 }
-            } else if (FORM == 1) {  // unit j0 = columns 2*(j0 & 7), +1 of half j0 >> 3
-                const int cc = 2 * (j0 & 7);
-                const bool m0 = cc < K, m1 = cc + 1 < K;
-                const int off0 = r0 * 2 * ld + (j0 >> 3) * ld + cc, step = rstep * 2 * ld;
+            } else if (FORM != 0) {
+                // any K / row stride, element-wise (two 8-B loads per unit), unconditional like the
+                // 16-B units above: unit j0 = columns cc, cc + 1 (FORM 1: of half j0 >> 3)
+                const int cc = FORM == 1 ? 2 * (j0 & 7) : 2 * j0;
+                int r0v = r0;
+                asm volatile("" : "+v"(r0v));
+                const int half = FORM == 1 ? (j0 >> 3) * ld : 0, pitch = FORM == 1 ? 2 * ld : ld;
+                const int c0 = half + (cc < K ? cc : 0), c1 = half + (cc + 1 < K ? cc + 1 : 0);
 #pragma unroll
                 for (int i = 0; i < PF; ++i) {
-                    const bool in = pad_act && r0 + i * rstep < rows32;
+                    const int at = min(r0v + i * rstep, rows32 - 1) * pitch;
                     vrx_d2 v;
-                    v.x = in && m0 ? src[off0 + i * step] : 0.0;
-                    v.y = in && m1 ? src[off0 + i * step + 1] : 0.0;
+                    v.x = src[at + c0];
+                    v.y = src[at + c1];
                     pf[i] = v;
                 }
             } else if (MODE == 1) {  // unit j0 = (w1, w2) of column j0
@@ -672,7 +695,6 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64) VRX_LDS_REGS
         ring_event();  // the first chunk
         wnext = *reinterpret_cast<const vrx_u4*>(ring + (stream_lo & (VRX_RING - 1)) + g * U);
     }
-    VRX_PROBE_BEGIN
     for (int s = s_lo; s < s_hi; ++s) {
         VRX_PROBE(tm_bar1, __syncthreads())  // every wave is done reading the previous slab
         VRX_PROBE(tm_stage, slab_store())
@@ -864,7 +886,7 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64) VRX_LDS_REGS
                         if (MODE == 0) acc2[r][q][h] += __shfl_xor(acc2[r][q][h], m, 64);
                     }
     }
-    double* dst = out + (int64_t)blockIdx.y * n_rows * ld * NV;
+    double* dst = out + (int64_t)slot * n_rows * ld * NV;
     // (the lane's coordinates are derived again, from an opaque copy of the thread index: kept
     //  live across the walk they would cost registers the walk has not got)
     int tid_e = threadIdx.x;
@@ -910,12 +932,14 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64) VRX_LDS_REGS
             }
         }
     }
+    }  // work items
 }
 
 // out[row][c] = sum over ranges (outer) and the row's pieces (inner), fixed order
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_pieces(
     int64_t n_rows, int width, int n_range, int64_t n_vrows, const int32_t* __restrict__ vptr,
-    const double* __restrict__ partial, double* __restrict__ out, const int32_t* __restrict__ ctl, int n_batch) {
+    const uint16_t* __restrict__ npiece, const double* __restrict__ partial, double* __restrict__ out,
+    const int32_t* __restrict__ ctl, int n_batch) {
     if (vrx_all_stopped(ctl, n_batch)) return;
     const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
     if (i >= n_rows * width) return;
@@ -931,7 +955,8 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_pieces(
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int t = t0 + j, r = t / np, v = v0 + (t - r * np);
-            x[j] = t < nt ? partial[((int64_t)r * n_vrows + v) * width + c] : 0.0;
+            // (partial array r holds a term of piece v only if the piece's tile was cut that often)
+            x[j] = t < nt && r < npiece[v] ? partial[((int64_t)r * n_vrows + v) * width + c] : 0.0;
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) s += x[j];
@@ -944,7 +969,8 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_pieces(
 // butterfly of wave_sum
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_pieces_wave(
     int64_t n_rows, int width, int n_range, int64_t n_vrows, const int32_t* __restrict__ vptr,
-    const double* __restrict__ partial, double* __restrict__ out, const int32_t* __restrict__ ctl, int n_batch) {
+    const uint16_t* __restrict__ npiece, const double* __restrict__ partial, double* __restrict__ out,
+    const int32_t* __restrict__ ctl, int n_batch) {
     if (vrx_all_stopped(ctl, n_batch)) return;
     const int64_t i = ((int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
@@ -955,22 +981,25 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_pieces_wave(
     double s = 0.0;
     for (int t = lane; t < nt; t += 64) {
         const int r = t / np, v = v0 + (t - r * np);
-        s += partial[((int64_t)r * n_vrows + v) * width + c];
+        if (r < npiece[v]) s += partial[((int64_t)r * n_vrows + v) * width + c];
     }
     s = wave_sum(s);
     if (lane == 0) out[i] = s;
 }
 
-// partial[range][...] summed over the contracted ranges in order
-__global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_ranges(int64_t n, int n_range,
+// partial[slot][row][width] summed in slot order over the npiece[row] partial arrays that hold a
+// term of the row (the pieces its tile was cut into, TiledStream::items)
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_ranges(int64_t n, int width,
+                                                            const uint16_t* __restrict__ npiece,
                                                             const double* __restrict__ partial,
                                                             double* __restrict__ out,
                                                             const int32_t* __restrict__ ctl, int n_batch) {
     if (vrx_all_stopped(ctl, n_batch)) return;
     const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
     if (i >= n) return;
+    const int n_range = npiece[i / width];
     double s = 0.0;
-    for (int r0 = 0; r0 < n_range; r0 += 16) {  // 16 loads in flight, added in range order
+    for (int r0 = 0; r0 < n_range; r0 += 16) {  // 16 loads in flight, added in slot order
         double x[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) x[j] = r0 + j < n_range ? partial[(int64_t)(r0 + j) * n + i] : 0.0;
@@ -1117,12 +1146,12 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_final(int n_part, int T, 
 }
 
 // stage 1 (shared theta): per-block partial sums of S1*GT_t and S2*GT_t over all (n,k).
-// n_range > 0: S has not been formed yet -- it is the in-order sum of the n_range partial
-// arrays the LDS-resident variant pass left in `ranges` (fused here to save a launch).
+// npiece != null: S has not been formed yet -- it is the in-order sum of the partial arrays the
+// LDS-resident variant pass left in `ranges` (npiece[variant] of them; fused here to save a launch).
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_partial(
-    int64_t NK, int T, double2* S, int n_range, const double2* __restrict__ ranges,
-    const double* __restrict__ GT, double* __restrict__ part, VrxBatch B,
-    const int32_t* __restrict__ ctl) {
+    int64_t NK, int T, double2* S, const uint16_t* __restrict__ npiece,
+    const double2* __restrict__ ranges, const double* __restrict__ GT, double* __restrict__ part,
+    VrxBatch B, const int32_t* __restrict__ ctl) {
     const int rb = blockIdx.y;
     if (ctl[rb * VRX_CTL_WORDS + VRX_CTL_STOP]) return;
     const int64_t NKt = NK * B.R;
@@ -1133,7 +1162,8 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_partial(
          i += (int64_t)gridDim.x * VRX_BLOCK) {
         const int64_t j = vrx_col(B, i, rb);
         double2 s;
-        if (n_range > 0) {
+        if (npiece) {  // S is the in-order sum of the partial arrays that hold the variant
+            const int n_range = npiece[i / B.K];
             s = make_double2(0.0, 0.0);
             for (int r0 = 0; r0 < n_range; r0 += 8) {  // (loads of 8 ranges in flight together)
                 double2 v[8];
@@ -1516,13 +1546,14 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_elbo_final(VrxElboIn e, VrxStop
 // A KP-lane group per cell; K > KP loops.  update == 0: ID_prob is left alone and only the
 // ELBO partials are formed from the stored ID_prob (get_ELBO on user-supplied state).
 // id_mode: 0 uniform prior, 1 one row of K, 2 full (M,K).
-// n_range > 0: logLik_ID has not been formed yet -- it is the in-order sum of the n_range
+// npiece != null: logLik_ID has not been formed yet -- it is the in-order sum of the npiece[cell]
 // partial arrays the LDS-resident cell pass left in `ranges` (fused here to save a launch;
 // every lane sums, stores and later re-reads only its own columns).
 // ------------------------------------------------------------------------------------
 template <int KP>
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_cell_softmax(
-    int64_t M, int K, int update, double* LID, int n_range, const double* __restrict__ ranges,
+    int64_t M, int K, int update, double* LID, const uint16_t* __restrict__ npiece,
+    const double* __restrict__ ranges,
     const double* __restrict__ logq, int id_mode, double logq_uni, double* __restrict__ ID,
     double* __restrict__ part, VrxBatch B, const int32_t* __restrict__ ctl) {
     const int rb = blockIdx.y;
@@ -1533,7 +1564,8 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_cell_softmax(
     const bool live = cell < M;
     const int64_t row0 = (live ? cell : 0) * (int64_t)B.Kt + (int64_t)rb * K;  // this restart's K columns
     double* Lr = LID + row0;
-    if (live && n_range > 0)
+    const int n_range = live && npiece ? npiece[cell] : 0;
+    if (n_range > 0)
         for (int k = kl; k < K; k += KP) {
             // the loads of 8 ranges are issued together (one memory round trip instead of 8);
             // the additions keep the range order
