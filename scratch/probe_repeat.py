@@ -30,7 +30,7 @@ dm.run_iters(3, theta_from_iter=10 ** 9)
 MAXW = 16384
 buf = (ctypes.c_ulonglong * (2 * MAXW * 8))()
 _lib.lib().vrx_debug_probe(buf)
-for rep in range(6):
+for rep in range(2):
     dm.run_iters(1, theta_from_iter=0)
     _lib.lib().vrx_debug_probe(buf)
     rec = np.frombuffer(buf, dtype=np.uint64).reshape(2, MAXW, 8).astype(np.int64)
@@ -43,3 +43,8 @@ for rep in range(6):
         where = ["x%d:%03x" % ((wg[i, 0, 7] >> 32) & 15, (wg[i, 0, 7] >> 8) & 0xfff) for i in o]
         print(rep, name, "median %d" % np.median(dur), "slowest", list(o), (dur[o] / np.median(dur)).round(3), where,
               "stage/visit-ish", [int(wg[i, :, 4].mean()) for i in o], flush=True)
+
+vis = (ctypes.c_ulonglong * (2 * 16 * 128 * 3))()
+_lib.lib().vrx_debug_probe_visits(vis)
+np.save(os.path.join(ROOT, "gpurun_out", "probe_visits.npy"),
+        np.frombuffer(vis, dtype=np.uint64).reshape(2, 16, 128, 3).astype(np.int64))

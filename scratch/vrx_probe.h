@@ -8,8 +8,17 @@
 #pragma once
 constexpr int VRX_PROBE_MAXW = 16384;
 __device__ unsigned long long vrx_probe_rec[2][VRX_PROBE_MAXW][8];
+// per-visit log of ONE workgroup (VRX_PROBE_WG): [wave][visit] = (trips start, trips end, trips so far)
+#ifndef VRX_PROBE_WG
+#define VRX_PROBE_WG 100
+#endif
+constexpr int VRX_PROBE_VISITS = 128;
+__device__ unsigned long long vrx_probe_visit[2][VRX_LDS_WAVES][VRX_PROBE_VISITS][3];
 #define VRX_PROBE_BEGIN                                                             \
     unsigned long long tm_bar1 = 0, tm_bar2 = 0, tm_stage = 0, tm_dma = 0, tm_first = 0; \
+    int pv_ = 0;                                                                     \
+    unsigned long long ptrips_ = 0;                                                  \
+    const bool plog_ = blockIdx.x == VRX_PROBE_WG && (threadIdx.x & 63) == 0;        \
     const unsigned long long tm_start = __builtin_amdgcn_s_memtime();
 #define VRX_PROBE(var, stmt)                                          \
     {                                                                 \
@@ -18,11 +27,23 @@ __device__ unsigned long long vrx_probe_rec[2][VRX_PROBE_MAXW][8];
         const unsigned long long u_ = __builtin_amdgcn_s_memtime();  \
         var += u_ - t_;                                               \
         if (&var == &tm_bar2 && tm_first == 0) tm_first = u_;         \
+        if (plog_ && &var == &tm_bar1 && pv_ > 0 && pv_ <= VRX_PROBE_VISITS) {       \
+            vrx_probe_visit[MODE][wave][pv_ - 1][1] = t_;             \
+            vrx_probe_visit[MODE][wave][pv_ - 1][2] = ptrips_;        \
+        }                                                             \
+        if (plog_ && &var == &tm_bar2 && pv_ < VRX_PROBE_VISITS) {    \
+            vrx_probe_visit[MODE][wave][pv_][0] = u_;                 \
+            ++pv_;                                                    \
+        }                                                             \
     }
 #define VRX_PROBE_END                                                                  \
     {                                                                                  \
         const unsigned long long tm_end = __builtin_amdgcn_s_memtime();               \
         const int w_ = (blockIdx.y * gridDim.x + blockIdx.x) * VRX_LDS_WAVES + wave;   \
+        if (plog_ && pv_ > 0 && pv_ <= VRX_PROBE_VISITS) {                             \
+            vrx_probe_visit[MODE][wave][pv_ - 1][1] = tm_end;                          \
+            vrx_probe_visit[MODE][wave][pv_ - 1][2] = ptrips_;                         \
+        }                                                                              \
         if (lane == 0 && w_ < VRX_PROBE_MAXW) {                                        \
             unsigned hw_, xcc_;                                                        \
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));          \
@@ -33,3 +54,4 @@ __device__ unsigned long long vrx_probe_rec[2][VRX_PROBE_MAXW][8];
             r_[7] = ((unsigned long long)xcc_ << 32) | hw_;                            \
         }                                                                              \
     }
+#define VRX_PROBE_TRIP ++ptrips_;

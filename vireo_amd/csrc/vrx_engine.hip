@@ -684,7 +684,8 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
 // mode) the busiest CU gets ceil(visits / CUs) of them, and the shorter tile wins when that
 // rounds up less (200 k cells, one slab: 261 tiles of 768 rows = 2 visits on the busiest CU,
 // 391 tiles of 512 rows = 2 shorter ones).
-static int pick_rw_cell(int64_t n_var, int64_t n_cell, int n_cu) {
+static int pick_rw_cell(int64_t n_var, int64_t n_cell, int n_cu, int cell_form) {
+    const int tall = cell_form == 1 ? VRX_LDS_RW_CELL : VRX_LDS_RW_CELL_PAIR;
     const int slab = VRX_LDS_SLAB_BYTES / 256;
     const int n_slab_c = (int)((n_var + slab - 1) / slab);
     auto cost = [&](int rw) {  // visits of the busiest CU x rows per wave
@@ -694,9 +695,9 @@ static int pick_rw_cell(int64_t n_var, int64_t n_cell, int n_cu) {
     };
     const int forced = env_int("VIREO_LDS_RW_CELL", 0);
     return forced == VRX_LDS_RW_CELL_SHORT ||
-                   (forced == 0 && n_slab_c <= 2 && cost(VRX_LDS_RW_CELL_SHORT) < cost(VRX_LDS_RW_CELL))
+                   (forced == 0 && n_slab_c <= 2 && cost(VRX_LDS_RW_CELL_SHORT) < cost(tall))
                ? VRX_LDS_RW_CELL_SHORT
-               : VRX_LDS_RW_CELL;
+               : tall;
 }
 
 // Which stream words the LDS-resident passes use.  Single-valued AD / BD words (cell form 1,
@@ -916,7 +917,7 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
                          nnz >= (int64_t)env_int("VIREO_LDS_MIN_NNZ_VAR", 32000000);
         if (!force_host && lds0 != 0 && (force_dev || big)) {
             bool built = false;
-            int rc = device_build(p.get(), colptr, rowidx, ad, dp, pick_rw_cell(n_var, n_cell, p->n_cu),
+            int rc = device_build(p.get(), colptr, rowidx, ad, dp, pick_rw_cell(n_var, n_cell, p->n_cu, forms.cell),
                                   std::min(VRX_LDS_SLAB_BYTES / 256, std::max(16, env_int("VIREO_LDS_SLAB_CELL", VRX_LDS_SLAB_BYTES / 256))),
                                   std::min(VRX_LDS_SLAB_BYTES / 128, std::max(16, env_int("VIREO_LDS_SLAB_VAR", VRX_LDS_SLAB_BYTES / 128))), forms,
                                   lds0 != 1, &built);
@@ -1037,7 +1038,7 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
     if ((max_count < 2048 || cell_form == 1) && lds != 0) {
         // cell pass: slabs of 512 W rows (128 KiB at K = 16); variant pass: 1024 ID rows
         if (lds == 1 || nnz >= (int64_t)env_int("VIREO_LDS_MIN_NNZ", 4000000)) {
-            const int rw_cell = pick_rw_cell(n_var, n_cell, p->n_cu);
+            const int rw_cell = pick_rw_cell(n_var, n_cell, p->n_cu, cell_form);
             if (cell_form == 1 || max_count < 2048) {
                 rc = build_tiled(p->by_cell, colptr, rowidx, cval.data(), rw_cell,
                                  std::min(VRX_LDS_SLAB_BYTES / 256, std::max(16, env_int("VIREO_LDS_SLAB_CELL", VRX_LDS_SLAB_BYTES / 256))),
@@ -1709,7 +1710,7 @@ static auto lds_kernel(int K, int ld, bool strided, int rw, int form) {
     }
     if (MODE == 1 && rw == VRX_LDS_RW_CELL_SHORT)
         return lds_kernel_rw<LPE, MODE, MODE == 1 ? VRX_LDS_RW_CELL_SHORT : VRX_LDS_RW_VARIANT>(K, strided);
-    return lds_kernel_rw<LPE, MODE, MODE == 1 ? VRX_LDS_RW_CELL : VRX_LDS_RW_VARIANT>(K, strided);
+    return lds_kernel_rw<LPE, MODE, MODE == 1 ? VRX_LDS_RW_CELL_PAIR : VRX_LDS_RW_VARIANT>(K, strided);
 }
 
 template <int LPE, int MODE>
@@ -2163,6 +2164,11 @@ extern "C" int vrx_model_step(vrx_model* m, int32_t which, double* elbo_out) {
 
 #ifdef VRX_PROBE_BUILD
 // scratch builds only (scratch/vrx_probe.h): read and clear the per-wave records of vrx_spmm_lds
+extern "C" int vrx_debug_probe_visits(unsigned long long* out) {
+    VRX_HIP(hipDeviceSynchronize());
+    VRX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(vrx_probe_visit), sizeof(vrx_probe_visit)));
+    return VRX_OK;
+}
 extern "C" int vrx_debug_probe(unsigned long long* rec) {
     VRX_HIP(hipDeviceSynchronize());
     VRX_HIP(hipMemcpyFromSymbol(rec, HIP_SYMBOL(vrx_probe_rec), sizeof(vrx_probe_rec)));

@@ -345,17 +345,6 @@ constexpr int VRX_CHUNK = 256;  // entries per refill (64 lanes x 16 B of one LD
 #ifndef VRX_LDS_PRECISE
 #define VRX_LDS_PRECISE 1
 #endif
-#ifndef VRX_LDS_L2PF
-#define VRX_LDS_L2PF 0
-#endif
-#if VRX_LDS_L2PF
-#define VRX_LDS_REGS __attribute__((amdgpu_num_vgpr(127)))
-#else
-#define VRX_LDS_REGS
-#endif
-#ifndef VRX_LDS_AHEAD
-#define VRX_LDS_AHEAD 0
-#endif
 // LDS of a pass = one 2-KiB entry ring per wave + the slab; a slab is staged through PF 16-B
 // registers per thread: 16 waves: 32 KiB + 8 x 16 KiB = 160 KiB
 #ifdef VRX_LDS_PF_DEF
@@ -373,13 +362,18 @@ __host__ __device__ inline int64_t vrx_trip_slot(int64_t n, int g, int G, int U,
     if (form != 0) return (n / U) * ((int64_t)U * G) + (int64_t)g * U + n % U;
     return n * G + g;
 }
-// output rows per wave (tile = 16 x this), per pass: measured best on MI355X at c3
+// output rows per wave (tile = 16 x this), per pass: the tallest tile the 128 registers of a
+// 1024-thread workgroup hold without spilling (accumulators: RW / 2 registers in the AD/BD cell
+// pass, RW in the AD/BD variant pass and the pair-word cell pass) -- every slab is staged once
+// per tile, so a taller tile means less staging per entry (c3 cell pass: 0.389 / 0.362 / 0.349 /
+// 0.341 ms at 48 / 64 / 80 / 96 rows)
 #ifndef VRX_LDS_LPE_DEF
 #define VRX_LDS_LPE_DEF 4
 #define VRX_LDS_RWV_DEF 32
-#define VRX_LDS_RWC_DEF 64
+#define VRX_LDS_RWC_DEF 96
 #endif
 constexpr int VRX_LDS_RW_VARIANT = VRX_LDS_RWV_DEF, VRX_LDS_RW_CELL = VRX_LDS_RWC_DEF;
+constexpr int VRX_LDS_RW_CELL_PAIR = 64;  // cell pass on (ad, dp) pair words (FORM 0): twice the accumulators
 constexpr int VRX_LDS_RW_CELL_SHORT = VRX_LDS_LPE_DEF == 1 ? 64 : 32;  // cell pass with one or two slabs, see vrx_problem_create
 constexpr int VRX_LDS_LPE = VRX_LDS_LPE_DEF;  // lanes per output row (16 / this columns per lane)
 constexpr int VRX_LDS_U = VRX_LDS_U_DEF;    // entries per trip and group; rows are padded to it
@@ -415,6 +409,7 @@ constexpr int VRX_LDS_U = VRX_LDS_U_DEF;    // entries per trip and group; rows 
 #else
 #define VRX_PROBE_BEGIN
 #define VRX_PROBE(var, stmt) stmt;
+#define VRX_PROBE_TRIP
 #define VRX_PROBE_END
 #endif
 // PADK: 0 = rows of exactly 16 contiguous columns (flat slab copy); 1 = any K / row stride
@@ -422,7 +417,7 @@ constexpr int VRX_LDS_U = VRX_LDS_U_DEF;    // entries per trip and group; rows 
 // even row stride (column blocks of wider operands, restart batches, K = 2 ... 14): as 1, but
 // a 16-B unit is either whole or absent, so it is staged with one load.
 template <int LPE, int MODE, int RW, int PADK, int SPLIT, int FORM = 0>
-__global__ __launch_bounds__(VRX_LDS_WAVES * 64) VRX_LDS_REGS
+__global__ __launch_bounds__(VRX_LDS_WAVES * 64)
     void vrx_spmm_lds(
     const uint32_t* __restrict__ ent, const int64_t* __restrict__ wave_start,
     const int32_t* __restrict__ bnd, const int32_t* __restrict__ rowmap,
@@ -450,8 +445,6 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64) VRX_LDS_REGS
     // rows / columns they fill are never referenced by a word resp. never stored), so the walk
     // can leave the prefetch in flight while it waits for a chunk of its stream
     constexpr bool PRECISE = FORM != 0 && VRX_LDS_PRECISE;
-    constexpr bool AHEAD = FORM != 0 && VRX_LDS_AHEAD;  // ring words read a trip ahead
-    constexpr int L2PF = FORM != 0 ? VRX_LDS_L2PF : 0;   // chunks the L2 look-ahead runs beyond the LDS-DMA
     constexpr int NPF = (PADK == 1 ? 2 : 1) * PF + 1;  // (element-wise: 2 loads per unit) + the bnd words of the next slab
     extern __shared__ __attribute__((aligned(16))) char vrx_smem[];
     const int lane = threadIdx.x & 63;
@@ -513,11 +506,15 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64) VRX_LDS_REGS
         if (!PADK) {  // rows are contiguous 16-B units: flat copy
             const int n16 = (int)(rows * K * XD / 2);
             const vrx_d2* src = reinterpret_cast<const vrx_d2*>(X + row0 * K * XD);
+            // (offsets formed again for every slab from an opaque copy of the thread index: hoisted
+            //  out of the walk they would hold registers the walk has not got)
+            int tid_f = threadIdx.x;
+            asm volatile("" : "+v"(tid_f));
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
-                const int at = threadIdx.x + i * NT;
+                const int at = tid_f + i * NT;
                 if (PRECISE)
-                    pf[i] = src[min(at, n16 - 1)];
+                    pf[i] = src[(uint32_t)min(at, n16 - 1)];  // (unsigned: scalar base + 32-bit lane offset)
                 else
                     pf[i] = at < n16 ? src[at] : vrx_d2{0.0, 0.0};
             }
@@ -536,16 +533,19 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64) VRX_LDS_REGS
                 if (PRECISE) {
                     // unconditional loads: rows past the slab's last re-read it, units past K
                     // re-read unit 0 (never referenced resp. never stored).  The offsets are formed
-                    // again for every slab from an opaque copy of the thread's first row: hoisted
+                    // again for every slab from an opaque copy of the thread index: hoisted
                     // out of the walk they would hold PF registers the walk has not got.
-                    int r0v = r0;
-                    asm volatile("" : "+v"(r0v));
+                    int tid_f = threadIdx.x;
+                    asm volatile("" : "+v"(tid_f));
+                    const int j0 = tid_f % upr, r0v = tid_f / upr;
+                    const int cc = FORM == 1 ? 2 * (j0 & 7) : 2 * j0;
+                    const bool m0 = cc < K;
                     const int col = m0 ? (FORM == 1 ? (j0 >> 3) * ld + cc : cc) : 0;
                     const int pitch = FORM == 1 ? 2 * ld : ld;
 #pragma unroll
                     for (int i = 0; i < PF; ++i)
                         pf[i] = *reinterpret_cast<const vrx_d2*>(
-                            src + (min(r0v + i * rstep, rows32 - 1) * pitch + col));
+                            src + (uint32_t)(min(r0v + i * rstep, rows32 - 1) * pitch + col));
                 } else {
 #pragma unroll
                     for (int i = 0; i < PF; ++i) {
@@ -556,9 +556,10 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64) VRX_LDS_REGS
             } else if (FORM != 0) {
                 // any K / row stride, element-wise (two 8-B loads per unit), unconditional like the
                 // 16-B units above: unit j0 = columns cc, cc + 1 (FORM 1: of half j0 >> 3)
+                int tid_f = threadIdx.x;
+                asm volatile("" : "+v"(tid_f));
+                const int j0 = tid_f % upr, r0v = tid_f / upr;
                 const int cc = FORM == 1 ? 2 * (j0 & 7) : 2 * j0;
-                int r0v = r0;
-                asm volatile("" : "+v"(r0v));
                 const int half = FORM == 1 ? (j0 >> 3) * ld : 0, pitch = FORM == 1 ? 2 * ld : ld;
                 const int c0 = half + (cc < K ? cc : 0), c1 = half + (cc + 1 < K ? cc + 1 : 0);
 #pragma unroll
@@ -595,16 +596,21 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64) VRX_LDS_REGS
         vrx_d2* dst = reinterpret_cast<vrx_d2*>(slab);
         if (!PADK) {
             const int n16 = slab_doubles / 2;
+            int tid_s = threadIdx.x;
+            asm volatile("" : "+v"(tid_s));
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
-                const int at = threadIdx.x + i * NT;
+                const int at = tid_s + i * NT;
                 if (at < n16) dst[at] = pf[i];
             }
         } else {
+            int tid_s = threadIdx.x;  // (as above: nothing of this survives the walk in a register)
+            asm volatile("" : "+v"(tid_s));
+            const int j0s = tid_s % upr, r0s = tid_s / upr;
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
-                const int row = r0 + i * rstep;
-                if (pad_act && row < slab_rows) dst[row * upr + j0] = pf[i];
+                const int row = r0s + i * rstep;
+                if (tid_s < padT && row < slab_rows) dst[row * upr + j0s] = pf[i];
             }
         }
     };
@@ -623,7 +629,12 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64) VRX_LDS_REGS
     const int clamp_last = max(stream_end - 4, 0);  // lanes past the range re-read its last 16 B
     const uint32_t ring_lds = (uint32_t)(wave * VRX_RING * 4);  // (dynamic LDS starts at 0)
     auto dma_issue = [&](int pos) {
-        const uint32_t* gsrc = stream + min(pos + 4 * lane, clamp_last);
+        // (4 * lane from the hardware lane counter, formed again at every issue: kept live across
+        //  the walk it would cost a register the walk has not got)
+        int lane4;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 2, %0"
+                     : "=v"(lane4));
+        const uint32_t* gsrc = stream + min(pos + lane4, clamp_last);
         const uint32_t dst =
             __builtin_amdgcn_readfirstlane(ring_lds + (uint32_t)((pos & (VRX_RING - 1)) * 4));
         unsigned keep;  // M0 = LDS destination of lane 0; written and restored in one statement
@@ -633,16 +644,6 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64) VRX_LDS_REGS
             : "=&s"(keep)
             : "v"(gsrc), "s"(dst)
             : "memory");
-        if (L2PF) {
-            // A plain load touches every 128-B line of a chunk further ahead, so that the LDS-DMA
-            // of that chunk later hits L2 (one 1-KiB chunk in flight per wave cannot cover the HBM
-            // latency at the rate the walk consumes the stream).  Its result is never used; v127
-            // is outside the register budget given to the compiler (amdgpu_num_vgpr), so a
-            // result landing thousands of cycles later never hits a live value.  One such load
-            // follows EVERY chunk, which is what the walk's vmcnt counts assume.
-            const uint32_t* psrc = stream + min(pos + L2PF * VRX_CHUNK + 4 * lane, clamp_last);
-            asm volatile("global_load_dword v127, %0, off" : : "v"(psrc) : "memory", "v127");
-        }
     };
     // ND chunks are in flight ahead of the walk (the ring holds ND + 1): when the walk enters
     // the chunk at ring_evt it waits for that chunk -- the ND - 1 younger chunks, and the slab
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64) VRX_LDS_REGS
     int ring_evt = base0;     // the chunk boundary the walk services next (multiple of CHUNK)
     int since_fetch = ND;     // chunks issued since the last slab prefetch (ND: none in flight)
     auto ring_event = [&]() {
-        constexpr int YOUNGER = (ND - 1) + (L2PF ? ND : 0);  // chunks (and look-ahead loads) behind it
+        constexpr int YOUNGER = ND - 1;  // chunks issued behind it
         if (PRECISE && since_fetch < ND)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER + NPF) : "memory");
         else
@@ -690,11 +691,6 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64) VRX_LDS_REGS
     // holds word i, ONE vector load a slab ahead (it is part of the prefetch the walk counts)
     int bvec = bw[(int64_t)s_lo * NRV + min(lane, NRV)];
     slab_fetch(s_lo);
-    vrx_u4 wnext = {0u, 0u, 0u, 0u}, wnext2 = wnext;  // (AHEAD) the words of the trip at hand
-    if (AHEAD && FORM != 0 && stream_lo < stream_end) {
-        ring_event();  // the first chunk
-        wnext = *reinterpret_cast<const vrx_u4*>(ring + (stream_lo & (VRX_RING - 1)) + g * U);
-    }
     for (int s = s_lo; s < s_hi; ++s) {
         VRX_PROBE(tm_bar1, __syncthreads())  // every wave is done reading the previous slab
         VRX_PROBE(tm_stage, slab_store())
@@ -702,7 +698,9 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64) VRX_LDS_REGS
             slab_fetch(s + 1);
             since_fetch = 0;
         }
-        const int bcur = bvec;
+        int bcur[NRV + 1];  // (scalar registers: read from the lanes before the vector is reused)
+#pragma unroll
+        for (int i = 0; i <= NRV; ++i) bcur[i] = __builtin_amdgcn_readlane(bvec, i);
         if (s + 1 < s_hi) bvec = bw[(int64_t)(s + 1) * NRV + min(lane, NRV)];
         VRX_PROBE(tm_bar2, __syncthreads())
 #pragma unroll
@@ -710,9 +708,9 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64) VRX_LDS_REGS
             const int r = rv / PH;
             // the round's entries are stored trip-major; the zero words that pad the round's
             // last trip are not executed
-            const int braw = __builtin_amdgcn_readlane(bcur, rv);
+            const int braw = bcur[rv];
             const int base = braw & ~(U * G - 1), tail = braw & (U - 1);
-            const int end = __builtin_amdgcn_readlane(bcur, rv + 1) & ~(U * G - 1);
+            const int end = bcur[rv + 1] & ~(U * G - 1);
             const int full_end = tail ? end - U * G : end;
             if (FORM != 0) {
                 // FORM 2: the AD entries of the round's rows feed S1 (acc), the BD entries S2 (acc2)
@@ -722,20 +720,11 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64) VRX_LDS_REGS
                 // before the first FMA; the FMAs of the first half wait for their four reads
                 // only.  The value is the high dword of an IEEE double (low dword 0), so there
                 // is no conversion: 3 VALU instructions of overhead per entry.
-                auto trip = [&](int at, auto ne_tag, const vrx_u4& wcur, vrx_u4& wnxt) {
+                auto trip = [&](int at, auto ne_tag) {
                     constexpr int NE = decltype(ne_tag)::value;
                     uint32_t w[NE];
-                    if (AHEAD) {
-                        // this trip's words were requested a trip ago; the next trip's (the
-                        // stream is contiguous across rounds and slabs) are requested now, ahead
-                        // of the slices, so that their LDS round trip hides behind this trip
-                        const uint32_t qq[4] = {wcur[0], wcur[1], wcur[2], wcur[3]};
-#pragma unroll
-                        for (int u = 0; u < NE; ++u) w[u] = qq[u];
-                        const int nx = at + U * G;
-                        if (nx >= ring_evt) VRX_PROBE(tm_dma, ring_event())
-                        wnxt = *reinterpret_cast<const vrx_u4*>(ring + (nx & (VRX_RING - 1)) + g * U);
-                    } else {
+                    VRX_PROBE_TRIP
+                    {
                         if (at >= ring_evt) VRX_PROBE(tm_dma, ring_event())
                         // the group's U words are adjacent (padding words fill a short last trip)
                         const uint4 q4 = *reinterpret_cast<const uint4*>(ring + (at & (VRX_RING - 1)) + g * U);
@@ -757,7 +746,7 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64) VRX_LDS_REGS
 #define VRX_RD(X0, X1, W)                                    \
     "v_and_or_b32 %[a0], " W ", %[msk], %[q0]\n\t"            \
     "ds_read_b128 " X0 ", %[a0]\n\t"                         \
-    "v_and_or_b32 %[a1], " W ", %[msk], %[q1]\n\t"            \
+    "v_xor_b32 %[a1], 16, %[a0]\n\t"                         \
     "ds_read_b128 " X1 ", %[a1]\n\t"
                         if constexpr (NE == 4)
                             asm volatile(VRX_RD("%[x00]", "%[x01]", "%[w0]") VRX_RD("%[x10]", "%[x11]", "%[w1]")
@@ -766,7 +755,7 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64) VRX_LDS_REGS
                                            [x11] "=&v"(x[1][1]), [x20] "=&v"(x[2][0]), [x21] "=&v"(x[2][1]),
                                            [x30] "=&v"(x[NE - 1][0]), [x31] "=&v"(x[NE - 1][1]), [a0] "=&v"(a0), [a1] "=&v"(a1)
                                          : [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[NE - 1]),
-                                           [msk] "s"(0x3ff80u), [q0] "v"(qoff[0]), [q1] "v"(qoff[1])
+                                           [msk] "s"(0x3ff80u), [q0] "v"(qoff[0])
                                          : "memory");
                         else if constexpr (NE == 3)
                             asm volatile(VRX_RD("%[x00]", "%[x01]", "%[w0]") VRX_RD("%[x10]", "%[x11]", "%[w1]")
@@ -775,19 +764,19 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64) VRX_LDS_REGS
                                            [x11] "=&v"(x[1][1]), [x20] "=&v"(x[NE - 1][0]), [x21] "=&v"(x[NE - 1][1]),
                                            [a0] "=&v"(a0), [a1] "=&v"(a1)
                                          : [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[NE - 1]),
-                                           [msk] "s"(0x3ff80u), [q0] "v"(qoff[0]), [q1] "v"(qoff[1])
+                                           [msk] "s"(0x3ff80u), [q0] "v"(qoff[0])
                                          : "memory");
                         else if constexpr (NE == 2)
                             asm volatile(VRX_RD("%[x00]", "%[x01]", "%[w0]") VRX_RD("%[x10]", "%[x11]", "%[w1]")
                                          : [x00] "=&v"(x[0][0]), [x01] "=&v"(x[0][1]), [x10] "=&v"(x[NE - 1][0]),
                                            [x11] "=&v"(x[NE - 1][1]), [a0] "=&v"(a0), [a1] "=&v"(a1)
                                          : [w0] "v"(w[0]), [w1] "v"(w[NE - 1]),
-                                           [msk] "s"(0x3ff80u), [q0] "v"(qoff[0]), [q1] "v"(qoff[1])
+                                           [msk] "s"(0x3ff80u), [q0] "v"(qoff[0])
                                          : "memory");
                         else
                             asm volatile(VRX_RD("%[x00]", "%[x01]", "%[w0]")
                                          : [x00] "=&v"(x[0][0]), [x01] "=&v"(x[0][1]), [a0] "=&v"(a0), [a1] "=&v"(a1)
-                                         : [w0] "v"(w[0]), [msk] "s"(0x3ff80u), [q0] "v"(qoff[0]), [q1] "v"(qoff[1])
+                                         : [w0] "v"(w[0]), [msk] "s"(0x3ff80u), [q0] "v"(qoff[0])
                                          : "memory");
 #undef VRX_RD
                     }
@@ -821,28 +810,10 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64) VRX_LDS_REGS
                         }
                     }
                 };
-                if (AHEAD) {  // two word registers alternate: trips in pairs, no copies
-                    int at = base;
-                    for (; at + U * G < full_end; at += 2 * U * G) {
-                        trip(at, std::integral_constant<int, 4>(), wnext, wnext2);
-                        trip(at + U * G, std::integral_constant<int, 4>(), wnext2, wnext);
-                    }
-                    if (at < full_end) {
-                        trip(at, std::integral_constant<int, 4>(), wnext, wnext2);
-                        wnext = wnext2;
-                    }
-                    if (tail) {
-                        if (tail == 1) trip(full_end, std::integral_constant<int, 1>(), wnext, wnext2);
-                        if (tail == 2) trip(full_end, std::integral_constant<int, 2>(), wnext, wnext2);
-                        if (tail == 3) trip(full_end, std::integral_constant<int, 3>(), wnext, wnext2);
-                        wnext = wnext2;
-                    }
-                    continue;
-                }
-                for (int at = base; at < full_end; at += U * G) trip(at, std::integral_constant<int, 4>(), wnext, wnext);
-                if (tail == 1) trip(full_end, std::integral_constant<int, 1>(), wnext, wnext);
-                if (tail == 2) trip(full_end, std::integral_constant<int, 2>(), wnext, wnext);
-                if (tail == 3) trip(full_end, std::integral_constant<int, 3>(), wnext, wnext);
+                for (int at = base; at < full_end; at += U * G) trip(at, std::integral_constant<int, 4>());
+                if (tail == 1) trip(full_end, std::integral_constant<int, 1>());
+                if (tail == 2) trip(full_end, std::integral_constant<int, 2>());
+                if (tail == 3) trip(full_end, std::integral_constant<int, 3>());
                 continue;
             }
             for (int at = base; at < full_end; at += U * G) {
