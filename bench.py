@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- EM iterations/sec of the Vireo VB hot path on MI355X (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|mid|c2] [--no-cpu] [--no-c4]
+  python bench.py [--gpus N] [--steps K=100] [--warmup W=3] [--config c3|mid|c2] [--no-cpu] [--no-c4]
 
 A step is ONE full coordinate-ascent iteration (theta update, GT update, ID update, ELBO:
 vireoSNP/utils/vireo_model.py:257-264) over the synthetic AD/DP of SURVEY.md 8(d), inputs
@@ -24,6 +24,10 @@ Besides the headline value the line carries
   c4            BASELINE.json configs[3]: vireo_wrap(n_init=32) on the same data with the
                 restarts sharded over the N ranks (strong scaling: the 32 restarts are the
                 fixed job), restart-iterations/s, wall time and the per-phase split.
+  c2, c5        BASELINE.json configs[1] (launch-bound small problem) and configs[4]
+                (BinomMixtureVB clone mode) on the driver's clock: us / ms per iteration,
+                c5 with its roofline fraction and the first iterations against the oracle.
+  ms_per_step_repeats   the timed K iterations repeated four more times (min / median / max).
 """
 import argparse
 import contextlib
@@ -140,10 +144,63 @@ def c2_leg(device, steps=200):
     return out
 
 
+def c5_leg(device, steps=50):
+    """BASELINE.json configs[4]: BinomMixtureVB clone mode, N=200 variants x M=200k cells, K=8
+    clones (bmm_model.py:178-201: one iteration = theta update, E[log lik], ID update, ELBO).
+    Iterations/s with inputs and state resident, the first iterations against the oracle, and
+    the HBM roofline on SURVEY.md 8(d)'s 0.89 GB per iteration."""
+    from oracle import vireo_oracle as O
+    from vireo_amd import _lib
+    from vireo_amd.bmm_model import BinomMixtureVB
+    from vireo_amd.counts import DeviceCounts
+    from vireo_amd.engine import DeviceModel
+    N, M, K = 200, 200000, 8
+    AD, DP = O.synth_clone(N, M, K, seed=0)
+    counts = DeviceCounts(AD, DP, device=device)
+    nnz = int(counts.nnz)
+    np.random.seed(1)
+    host = BinomMixtureVB(n_var=N, n_cell=M, n_donor=K)
+    dm = DeviceModel(counts, _lib.KIND_BMM, K)
+    host._push(dm)
+    first, _ = dm.run_iters(3)                       # the first iterations: checked below
+    t0 = time.perf_counter()
+    dm.run_iters(steps)
+    wall = time.perf_counter() - t0
+    dm.profile(True)
+    dm.run_iters(steps)
+    pm, pn = dm.profile_read()
+    info = dm.info()
+    dm.close()
+    np.random.seed(1)
+    ref = O.bmm_new(M, N, K)
+    ref_elbo = []
+    t0 = time.perf_counter()
+    for _ in range(3):
+        O.bmm_theta_step(ref, AD, DP)
+        L = O.bmm_cell_loglik(ref, AD, DP)
+        O.bmm_id_step(ref, L)
+        ref_elbo.append(O.bmm_elbo(ref, L))
+    t_cpu = (time.perf_counter() - t0) / 3
+    # SURVEY.md 8(d): 2 x 12 B per entry + the dense operands once per producer / consumer
+    bytes_it = 2 * 12 * nnz + 8 * (2 * M * K + 2 * N * K * 3)
+    ms_it = wall / steps * 1e3
+    return dict(workload="c5: BinomMixtureVB N=%d x M=%d, K=%d, nnz=%d (SURVEY.md 8d generator, "
+                         "seed 0); %d iterations" % (N, M, K, nnz, steps),
+                ms_per_iteration=ms_it, iterations_per_s=1e3 / ms_it,
+                passes_ms={"variant_pass": pm[0] / max(pn[0], 1), "cell_pass": pm[1] / max(pn[1], 1),
+                           "dense_kernels": pm[2] / steps},
+                algorithmic_bytes_per_iteration=bytes_it,
+                roofline_frac=bytes_it / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                kernel_info=info,
+                elbo_rel_err_first_iterations=[float("%.3g" % (abs(a - b) / abs(b)))
+                                               for a, b in zip(first, ref_elbo)],
+                cpu_oracle_s_per_iteration=t_cpu, cpu_cores=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c3")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity leg")
@@ -211,6 +268,12 @@ def main():
     walls = comm.allgather(np.array([wall]))
     wall_max = float(np.max(walls))
     last_elbos = comm.allgather(np.array([trace[-1]]))            # the restart-shard exchange
+    # spread of the number above: the same K iterations four more times (not part of `value`)
+    repeats = [wall / args.steps * 1e3]
+    for _ in range(4):
+        t0 = time.perf_counter()
+        dm.run_iters(args.steps, theta_from_iter=0)
+        repeats.append((time.perf_counter() - t0) / args.steps * 1e3)
 
     # roofline leg: the same K iterations again with every pass bracketed by HIP events on
     # the library's stream
@@ -221,11 +284,12 @@ def main():
     kinfo = dm.info()
     dm.close()
 
-    c4 = c2 = None
+    c4 = c2 = c5 = None
     if not args.no_c4 and args.config == "c3":
         c4 = c4_leg(counts, K, comm)
         if rank == 0 and world == 1:
             c2 = c2_leg(local)
+            c5 = c5_leg(local)
 
     # whole-protocol parity + CPU baseline (rank 0): the same fit on the GPU and on the oracle
     parity = None
@@ -253,6 +317,22 @@ def main():
         rel_it = np.abs(gtrace - ctrace) / np.abs(ctrace) if same_len else None
         rel = None if rel_it is None else np.max(rel_it)
         differ = dev.ID_prob.argmax(1) != st.ID_prob.argmax(1)
+        # the arbiter: the same protocol in 80-bit extended precision (tests/golden/
+        # make_c3_arbiter.py, run once in the build container) -- which float64 trace is closer to
+        # the mathematics where rounding differences are amplified (iterations 6-10)
+        arb = None
+        apath = os.path.join(ROOT, "tests", "golden", "%s_protocol_longdouble.npz" % args.config)
+        if os.path.exists(apath) and same_len:
+            g = np.load(apath)
+            if int(g["n_iter"]) == n_cpu and int(g["nnz"]) == nnz:
+                exact = g["elbo_hi"].astype(np.longdouble) + g["elbo_lo"].astype(np.longdouble)
+                e_gpu = np.abs((gtrace.astype(np.longdouble) - exact) / exact).astype(float)
+                e_cpu = np.abs((ctrace.astype(np.longdouble) - exact) / exact).astype(float)
+                arb = dict(source="tests/golden/%s_protocol_longdouble.npz (np.longdouble, eps 1.1e-19)" % args.config,
+                           gpu_vs_exact_per_iteration=[float("%.3g" % x) for x in e_gpu],
+                           oracle_vs_exact_per_iteration=[float("%.3g" % x) for x in e_cpu],
+                           gpu_vs_exact_max=float(e_gpu.max()), oracle_vs_exact_max=float(e_cpu.max()),
+                           assignments_equal_exact=bool(np.array_equal(dev.ID_prob.argmax(1), g["assign"])))
         parity = dict(protocol="_fit_VB(min_iter=5, max_iter=20, delay_fit_theta=3) from "
                                "np.random.seed(1): ELBO[:it] without the binomial constant",
                       iterations_gpu=len(gtrace), iterations_cpu=n_cpu,
@@ -266,6 +346,7 @@ def main():
                       id_prob_max_abs_err=float(np.max(np.abs(dev.ID_prob - st.ID_prob))),
                       assignment_mismatches=int(differ.sum()),
                       identical_assignments=bool(not differ.any()),
+                      extended_precision_arbiter=arb,
                       gpu_fit_wall_s=round(tg, 3))
         # the oracle executes one more iteration than it keeps (ELBO[:it], vireo_model.py:276)
         cpu = dict(value=(n_cpu + 1) / dt, unit="EM iterations/s", cores=1, kind="port",
@@ -336,6 +417,12 @@ def main():
             "parity": parity,
             "c4": c4,
             "c2": c2,
+            "c5": c5,
+            "ms_per_step_repeats": {"runs": [round(x, 4) for x in repeats],
+                                    "min": round(min(repeats), 4), "median": round(float(np.median(repeats)), 4),
+                                    "max": round(max(repeats), 4),
+                                    "note": "run 0 is the timed run `value` comes from; runs 1-4 "
+                                            "repeat the same K iterations on this rank"},
         }
         if cpu:
             out["speedup_vs_cpu_1core"] = out["value"] / cpu["value"]

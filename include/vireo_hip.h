@@ -249,6 +249,13 @@ int vrx_comm_bcast_f64(vrx_comm* c, double* buf, int64_t n, int root);
  * `out`, or (out == NULL) skip them, advancing the MT19937 state of np.random.get_state()
  * (key[624], pos) in place.  Host only; no GPU needed. */
 int vrx_mt19937_random_sample(uint32_t* key624, int32_t* pos, double* out, int64_t n);
+/* Skip n doubles of the same stream.  A rank of the restart shard (vireo_wrap.py:66-71: restart i
+ * on rank i % world) must pass every other rank's draws; far skips are a JUMP of the generator --
+ * the polynomial x^(624 R) mod phi of its GF(2) transition matrix applied to the state, cached per
+ * skip length, ~1 ms whatever the distance -- instead of R regenerations.  jump: 1 = jump
+ * whenever the skip spans >= 3 regenerations, 0 = always step (the specification the jump is
+ * tested against, bit for bit), -1 = the library's threshold (what out == NULL above uses). */
+int vrx_mt19937_skip(uint32_t* key624, int32_t* pos, int64_t n, int32_t jump);
 /* np.sum() of a contiguous float32 array, bit for bit (NumPy's pairwise summation per 8192-element
  * iterator chunk).  vrx_problem_binom_const adds the float32 terms of get_binom_coeff
  * (vireo_base.py:7-22) with it, like vireo_model.py:313 does with np.sum.  Host only. */

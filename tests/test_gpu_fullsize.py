@@ -171,6 +171,55 @@ def test_config3_whole_protocol_trace_vs_oracle(va):
         np.mean(dev.GT_prob.argmax(2) != st.GT_prob.argmax(2)) < 1e-4     # (exact ties: no reads)
 
 
+def test_config4_restart_search_n_init32(va):
+    """BASELINE.json configs[3] on one GPU: vireo_wrap(n_init=32, max_iter_init=20, random_seed=1,
+    check_doublet=False) on the c3 data (vireo_wrap.py:64-94).  Every restart must be the fit the
+    reference would run from the i-th constructor's draws: checked against independent
+    ``Vireo.fit`` calls from those draws (bitwise: same kernels, same order), for restart 0 (the
+    single-restart timing protocol), three others and the winner; the winner is the FIRST
+    maximum of LB_list, and the returned state is that restart refined by
+    ``fit(min_iter=5)`` (vireo_wrap.py:93)."""
+    import contextlib
+    import io
+    from vireo_amd import synth
+    from vireo_amd.counts import DeviceCounts
+    N, M, K, dens = synth.CONFIGS["c3"]
+    w = synth.donor_workload(N, M, K, dens, seed=0)
+    counts = DeviceCounts.from_merged(w["shape"], w["colptr"], w["rowidx"], w["ad"], w["dp"])
+    n_init = 32
+    with contextlib.redirect_stdout(io.StringIO()):
+        rv = va.vireo_wrap(counts, None, n_donor=K, n_init=n_init, max_iter_init=20, random_seed=1,
+                           check_doublet=False)
+    LB = np.asarray(rv["LB_list"])
+    assert LB.shape == (n_init,) and np.all(np.isfinite(LB))
+    best = int(np.argmax(LB))                               # np.argmax: the first maximum
+    check = sorted({0, 7, 19, 31, best})
+    np.random.seed(1)                                       # the one seeding, vireo_wrap.py:53-54
+    fitted = {}
+    for i in range(n_init):                                 # sequential constructors, :66-71
+        m = va.Vireo(n_var=N, n_cell=M, n_donor=K)
+        if i in check:
+            m.fit(counts, None, min_iter=5, max_iter=20, delay_fit_theta=3, verbose=False)
+            fitted[i] = m
+        else:
+            del m
+    for i in check:
+        assert fitted[i].ELBO_[-1] == LB[i], (i, fitted[i].ELBO_[-1], LB[i])
+    # restart 0 is the timing protocol of bench.py (the same seed, the first constructor)
+    np.random.seed(1)
+    m0 = va.Vireo(n_var=N, n_cell=M, n_donor=K)
+    tr = m0._fit_VB(counts, None, min_iter=5, max_iter=20, delay_fit_theta=3, verbose=False)
+    assert tr[-1] + counts.binom_const() == LB[0]
+    # the refinement of the winner (vireo_wrap.py:93: fit(AD, DP, min_iter=5), all defaults else)
+    win = fitted[best]
+    win.fit(counts, None, min_iter=5, verbose=False)
+    assert np.array_equal(rv["ID_prob"], win.ID_prob)
+    assert np.array_equal(rv["GT_prob"], win.GT_prob)
+    assert np.array_equal(rv["theta_mean"], win.beta_mu) and np.array_equal(rv["theta_sum"], win.beta_sum)
+    assert rv["LB_doublet"] == win.ELBO_[-1]
+    assert rv["doublet_prob"].shape == (M, K * (K - 1) // 2) and not rv["doublet_prob"].any()
+
+
 def test_restart_shard_over_rccl_world2(va, tmp_path):
     """vireo_wrap(n_init=4) on the demo data with the restarts sharded over TWO GPUs (one
     process each, RCCL all-gather of the ELBOs, winner broadcast) against the reference's

@@ -173,6 +173,51 @@ def test_sharded_wrap_gloo_wider_than_n_init(tmp_path):
     assert sorted(fits) == [0, 2]     # the restart and its refinement on rank 0, nothing on rank 1
 
 
+def test_generator_jump_equals_stepping():
+    """LegacyStream.skip over far distances jumps (polynomial of the MT19937 transition matrix,
+    vrx_host.cpp) instead of stepping: bitwise the state stepping leaves, for the skips a restart
+    shard makes at c1 and c3 sizes (one and seven foreign restarts of 8 ranks, all 28 of them),
+    and the draws that follow equal np.random.rand's."""
+    import ctypes as C
+    from vireo_amd import _lib
+    from vireo_amd.restarts import LegacyStream
+    lib = _lib.lib()
+
+    def advance(key, pos, n, out=None):
+        key, p = key.copy(), C.c_int32(pos)
+        _lib.check(lib.vrx_mt19937_random_sample(key.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                 C.byref(p), _lib.dptr(out), int(n)))
+        return key, p.value
+
+    c1 = 952 * 4 + 3784 * 4 * 3                 # doubles one constructor draws at c1
+    c3 = 50000 * 16 + 100000 * 16 * 3           # ... at c3
+    np.random.seed(5)
+    np.random.rand(123)                         # (a state in the middle of a block)
+    _, key, pos, _, _ = np.random.get_state()
+    key = np.ascontiguousarray(key, dtype=np.uint32)
+    for n in (c1, 7 * c1, c3, 7 * c3, 7 * c3 + 1, 28 * c3, 12480 * 312 + 5):
+        key2, pos2 = advance(key, pos, n)       # (the library's own threshold decides)
+        # both paths, forced through the explicit entry point
+        jk, jp = key.copy(), C.c_int32(pos)
+        _lib.check(lib.vrx_mt19937_skip(jk.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(jp), int(n), 1))
+        sk, sp = key.copy(), C.c_int32(pos)
+        _lib.check(lib.vrx_mt19937_skip(sk.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(sp), int(n), 0))
+        assert jp.value == sp.value == pos2
+        assert np.array_equal(jk, sk) and np.array_equal(sk, key2)
+        a, b = np.empty(1500), np.empty(1500)
+        advance(jk, jp.value, 1500, a)
+        advance(sk, sp.value, 1500, b)
+        assert np.array_equal(a, b)
+    # the stream object against NumPy itself: skip(n) == discarding rand(n)
+    n = 13_000_000
+    np.random.seed(9)
+    np.random.rand(n)
+    want = np.random.rand(4, 5)
+    np.random.seed(9)
+    LegacyStream().skip(n)
+    assert np.array_equal(LegacyStream().rand(4, 5), want)
+
+
 def test_match_and_optimal_match():
     from vireo_amd import match, optimal_match
     assert list(match([5, 9, 1], [1, 2, 5, 7, 9])) == [2, 4, 0]

@@ -75,6 +75,7 @@ SIGNATURES = {
     "vrx_comm_barrier": (C.c_int, [_P]),
     "vrx_comm_bcast_f64": (C.c_int, [_P, _D, C.c_int64, C.c_int]),
     "vrx_mt19937_random_sample": (C.c_int, [C.POINTER(C.c_uint32), _I32, _D, C.c_int64]),
+    "vrx_mt19937_skip": (C.c_int, [C.POINTER(C.c_uint32), _I32, C.c_int64, C.c_int32]),
     "vrx_np_sum_f32": (C.c_int, [C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_float)]),
     "vrx_mtx_header": (C.c_int, [C.c_char_p, _I64, _I64, _I64]),
     "vrx_merge_counts": (C.c_int, [C.c_int64, C.c_int64, _P, _P, _P, C.c_int, C.c_int, C.c_int,

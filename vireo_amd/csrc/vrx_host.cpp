@@ -15,7 +15,11 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
 
 #include "../../include/vireo_hip.h"
 
@@ -62,14 +66,230 @@ inline double mt_double(uint32_t a, uint32_t b) {
 }
 }  // namespace
 
-extern "C" int vrx_mt19937_random_sample(uint32_t* key624, int32_t* pos, double* out, int64_t n) {
-    if (!key624 || !pos || n < 0 || *pos < 0 || *pos > MT_N) {
-        vrx_set_error("vrx_mt19937_random_sample: bad argument");
-        return VRX_ERR_ARG;
+// ------------------------------------------------------------------------------------
+// Jump-ahead.  A rank of a restart shard has to step the generator past every other rank's
+// restarts (c4 at 8 ranks: 28 of 32 restarts, ~0.3 G outputs).  The state transition is linear
+// over GF(2): 624 * R steps are the polynomial g(x) = x^(624 R) mod phi(x) of the transition
+// matrix T applied to the state, phi = T's characteristic polynomial (degree 19937; Haramoto,
+// Matsumoto, Nishimura, Panneton, L'Ecuyer 2008).  phi comes from Berlekamp-Massey on one output
+// bit of 2 x 19937 steps (once per process), g from square-and-multiply (cached per R), and
+// g(T) s from Horner's rule on a sliding 624-word window: 19937 single steps + ~10^4 XORs of
+// 624 words, ~2 ms whatever R is.
+// ------------------------------------------------------------------------------------
+namespace {
+constexpr int MT_DEG = 19937, MT_PW = (MT_DEG + 64) / 64;  // words of a polynomial of degree <= 19937
+
+struct MtPoly {
+    uint64_t w[MT_PW];
+    bool bit(int i) const { return (w[i >> 6] >> (i & 63)) & 1u; }
+};
+
+// one step of the recurrence on a circular window: the word at `head` leaves, a new one enters
+inline void mt_step(uint32_t* win, int& head) {
+    const int i1 = head + 1 == MT_N ? 0 : head + 1;
+    int im = head + MT_M;
+    if (im >= MT_N) im -= MT_N;
+    win[head] = win[im] ^ mt_twist(win[head], win[i1]);
+    head = i1;
+}
+
+// phi(x) = x^19937 + ... : minimal polynomial of the sequence (lowest bit of every raw word) of
+// an arbitrary non-zero state, Berlekamp-Massey over GF(2)
+const MtPoly& mt_char_poly() {
+    static MtPoly phi;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        constexpr int NS = 2 * MT_DEG + 64, SW = (NS + 63) / 64;
+        std::vector<uint64_t> seq((size_t)SW, 0);
+        uint32_t win[MT_N];
+        uint32_t x = 19650218u;
+        for (int i = 0; i < MT_N; ++i) {
+            win[i] = x;
+            x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i + 1u;
+        }
+        int head = 0;
+        for (int t = 0; t < NS; ++t) {
+            mt_step(win, head);
+            const int newest = head == 0 ? MT_N - 1 : head - 1;
+            if (win[newest] & 1u) seq[(size_t)(t >> 6)] |= 1ull << (t & 63);
+        }
+        // C(x) connection polynomial, B(x) its previous version; bit i = coefficient of x^i
+        constexpr int CW = (MT_DEG + 2 + 63) / 64 + 1;
+        std::vector<uint64_t> Cp((size_t)CW, 0), Bp((size_t)CW, 0), Tp((size_t)CW, 0);
+        // reversed sequence window so that the discrepancy is a word-wise AND + parity:
+        // rev[j] holds seq bit (t - j) at bit j  ->  kept by shifting one bit per step
+        std::vector<uint64_t> rev((size_t)CW, 0);
+        Cp[0] = Bp[0] = 1;
+        int L = 0, m = 1;
+        for (int t = 0; t < NS; ++t) {
+            // shift the reversed window left by one and insert seq[t] at bit 0
+            uint64_t carry = (seq[(size_t)(t >> 6)] >> (t & 63)) & 1u;
+            for (int j = 0; j < CW; ++j) {
+                const uint64_t nc = rev[(size_t)j] >> 63;
+                rev[(size_t)j] = (rev[(size_t)j] << 1) | carry;
+                carry = nc;
+            }
+            uint64_t acc = 0;
+            const int lw = (L >> 6) + 1;
+            for (int j = 0; j < lw && j < CW; ++j) acc ^= Cp[(size_t)j] & rev[(size_t)j];
+            // (bits above L of C are zero, so whole words may be used)
+            if (__builtin_parityll(acc)) {
+                Tp = Cp;
+                const int ws = m >> 6, bs = m & 63;  // C ^= B << m
+                for (int j = CW - 1; j >= ws; --j) {
+                    uint64_t v = Bp[(size_t)(j - ws)] << bs;
+                    if (bs && j - ws - 1 >= 0) v |= Bp[(size_t)(j - ws - 1)] >> (64 - bs);
+                    Cp[(size_t)j] ^= v;
+                }
+                if (2 * L <= t) {
+                    L = t + 1 - L;
+                    Bp = Tp;
+                    m = 1;
+                } else {
+                    ++m;
+                }
+            } else {
+                ++m;
+            }
+        }
+        // phi(x) = x^L C(1/x): coefficient of x^(L - i) = c_i   (L == 19937 for this generator)
+        std::memset(phi.w, 0, sizeof phi.w);
+        if (L == MT_DEG)
+            for (int i = 0; i <= L; ++i)
+                if ((Cp[(size_t)(i >> 6)] >> (i & 63)) & 1u) phi.w[(L - i) >> 6] |= 1ull << ((L - i) & 63);
+    });
+    return phi;
+}
+
+// r(x) (degree < 2 * 19937 + 64, PW2 words) reduced mod phi, result in r[0 .. MT_PW)
+void mt_poly_reduce(uint64_t* r, int top_bit, const MtPoly& phi) {
+    // phi shifted left by 0..63 bits, so that a set bit is cleared with word-aligned XORs
+    static uint64_t sh[64][MT_PW + 1];
+    static std::once_flag once;
+    std::call_once(once, [&] {
+        for (int s = 0; s < 64; ++s) {
+            for (int j = 0; j <= MT_PW; ++j) sh[s][j] = 0;
+            for (int j = 0; j < MT_PW; ++j) {
+                sh[s][j] |= s ? phi.w[j] << s : phi.w[j];
+                if (s) sh[s][j + 1] |= phi.w[j] >> (64 - s);
+            }
+        }
+    });
+    for (int b = top_bit; b >= MT_DEG; --b) {
+        if (!((r[b >> 6] >> (b & 63)) & 1u)) continue;
+        const int d = b - MT_DEG, ws = d >> 6, bs = d & 63;  // r ^= phi << d
+        for (int j = 0; j <= MT_PW; ++j) r[ws + j] ^= sh[bs][j];
     }
+}
+
+// g(x) = x^(624 * regens) mod phi(x), cached per `regens`
+const MtPoly* mt_jump_poly(uint64_t regens) {
+    static std::mutex mu;
+    static std::map<uint64_t, MtPoly> cache;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = cache.find(regens);
+        if (it != cache.end()) return &it->second;
+    }
+    const MtPoly& phi = mt_char_poly();
+    if (!phi.bit(MT_DEG)) return nullptr;  // (Berlekamp-Massey did not find degree 19937)
+    // E = 624 * regens, square-and-multiply from the top bit: g <- g^2 (bit spreading), g <- g x
+    unsigned __int128 E = (unsigned __int128)regens * 624u;
+    int top = 0;
+    for (int b = 0; b < 100; ++b)
+        if ((E >> b) & 1u) top = b;
+    constexpr int PW2 = 2 * MT_PW + 2;
+    std::vector<uint64_t> r((size_t)PW2 + MT_PW + 2, 0), g((size_t)MT_PW, 0);
+    g[0] = 1;  // x^0
+    auto spread = [](uint32_t v) {  // bits of v to the even bit positions of a 64-bit word
+        uint64_t x = v;
+        x = (x | (x << 16)) & 0x0000ffff0000ffffull;
+        x = (x | (x << 8)) & 0x00ff00ff00ff00ffull;
+        x = (x | (x << 4)) & 0x0f0f0f0f0f0f0f0full;
+        x = (x | (x << 2)) & 0x3333333333333333ull;
+        x = (x | (x << 1)) & 0x5555555555555555ull;
+        return x;
+    };
+    for (int b = top; b >= 0; --b) {
+        std::fill(r.begin(), r.end(), 0);
+        for (int j = 0; j < MT_PW; ++j) {
+            r[(size_t)(2 * j)] = spread((uint32_t)g[(size_t)j]);
+            r[(size_t)(2 * j + 1)] = spread((uint32_t)(g[(size_t)j] >> 32));
+        }
+        mt_poly_reduce(r.data(), 2 * MT_DEG, phi);
+        if ((E >> b) & 1u) {  // times x
+            uint64_t carry = 0;
+            for (int j = 0; j <= MT_PW; ++j) {
+                const uint64_t nc = r[(size_t)j] >> 63;
+                r[(size_t)j] = (r[(size_t)j] << 1) | carry;
+                carry = nc;
+            }
+            mt_poly_reduce(r.data(), MT_DEG, phi);
+        }
+        for (int j = 0; j < MT_PW; ++j) g[(size_t)j] = r[(size_t)j];
+    }
+    MtPoly out;
+    for (int j = 0; j < MT_PW; ++j) out.w[j] = g[(size_t)j];
+    std::lock_guard<std::mutex> lk(mu);
+    return &cache.emplace(regens, out).first->second;
+}
+
+// key <- g(T) key  (the window 624 * regens steps further on; the low 31 bits of key[0] are
+// not part of the state and come out undefined: the caller regenerates once more)
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+__attribute__((target_clones("avx512f", "avx2", "default")))
+#endif
+void mt_apply_poly(const MtPoly& g, uint32_t* __restrict__ key) {
+    uint32_t src[MT_N], win[MT_N];
+    std::memcpy(src, key, sizeof src);
+    int deg = MT_DEG - 1;
+    while (deg >= 0 && !g.bit(deg)) --deg;
+    if (deg < 0) {
+        std::memset(key, 0, sizeof src);
+        return;
+    }
+    std::memcpy(win, src, sizeof src);  // h = s   (the leading coefficient)
+    int head = 0;
+    for (int i = deg - 1; i >= 0; --i) {
+        mt_step(win, head);  // h = T h
+        if (g.bit(i)) {      // h ^= s, word j of s onto window position head + j
+            const int n1 = MT_N - head;
+            for (int j = 0; j < n1; ++j) win[head + j] ^= src[j];
+            for (int j = n1; j < MT_N; ++j) win[j - n1] ^= src[j];
+        }
+    }
+    for (int j = 0; j < MT_N; ++j) key[j] = win[head + j < MT_N ? head + j : head + j - MT_N];
+}
+}  // namespace
+
+// 0 = off (always step), otherwise the smallest number of regenerations a skip jumps over
+static int64_t mt_jump_threshold() {
+    static const int64_t t = [] {
+        const char* e = getenv("VIREO_MT_JUMP_MIN_REGENS");
+        return e ? (int64_t)atoll(e) : (int64_t)20000;  // ~2.5 ms of stepping = one Horner pass
+    }();
+    return t;
+}
+
+// skip n doubles; thr = the fewest regenerations worth a jump (0: always step)
+static int mt_skip(uint32_t* key624, int32_t* pos, int64_t n, int64_t thr) {
     int p = *pos;
     int64_t words = 2 * n;  // 32-bit outputs to consume
-    if (!out) {             // skip: only the state moves
+    {
+        // far skips jump: all but the last two regenerations as ONE polynomial of the transition
+        // matrix (the regenerations that follow rebuild the bits a jump leaves undefined)
+        if (thr > 0 && words > 0) {
+            // (the skip performs (p + words - 1) / 624 regenerations; the jump takes a count that
+            //  depends on `words` alone, so that equal skips share one cached polynomial)
+            const int64_t jump = words / MT_N - 2;
+            if (jump >= thr) {
+                const MtPoly* g = mt_jump_poly((uint64_t)jump);
+                if (g) {
+                    mt_apply_poly(*g, key624);
+                    words -= jump * (int64_t)MT_N;
+                }
+            }
+        }
         while (words > 0) {
             if (p == MT_N) {
                 mt_regen(key624);
@@ -82,6 +302,23 @@ extern "C" int vrx_mt19937_random_sample(uint32_t* key624, int32_t* pos, double*
         *pos = p;
         return VRX_OK;
     }
+}
+
+extern "C" int vrx_mt19937_skip(uint32_t* key624, int32_t* pos, int64_t n, int32_t jump) {
+    if (!key624 || !pos || n < 0 || *pos < 0 || *pos > MT_N) {
+        vrx_set_error("vrx_mt19937_skip: bad argument");
+        return VRX_ERR_ARG;
+    }
+    return mt_skip(key624, pos, n, jump < 0 ? mt_jump_threshold() : jump ? 1 : 0);
+}
+
+extern "C" int vrx_mt19937_random_sample(uint32_t* key624, int32_t* pos, double* out, int64_t n) {
+    if (!key624 || !pos || n < 0 || *pos < 0 || *pos > MT_N) {
+        vrx_set_error("vrx_mt19937_random_sample: bad argument");
+        return VRX_ERR_ARG;
+    }
+    if (!out) return mt_skip(key624, pos, n, mt_jump_threshold());  // skip: only the state moves
+    int p = *pos;
     int64_t done = 0;
     uint32_t t[MT_N];
     bool have_a = false;

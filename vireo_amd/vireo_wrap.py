@@ -152,13 +152,21 @@ def _search(counts, plan, comm, max_iter_init, delay_fit_theta, kwargs, restarts
 
     def draws():
         """this rank's restarts in order, each with what its constructor draws; the draws of
-        the other ranks' restarts are consumed without being formed"""
+        the other ranks' restarts are consumed without being formed -- runs of them in ONE skip
+        (far skips are a jump of the generator: vrx_mt19937_random_sample, cached per length)"""
+        per_restart = (n_cell * K if ID0 is None else 0) + (n_var * K * T if GT0 is None else 0)
+        foreign = 0
         for im in range(plan.n_init):
             if im in mine:
+                if foreign:
+                    stream.skip(foreign * per_restart)
+                    foreign = 0
                 yield (im, stream.rand(n_cell, K) if ID0 is None else None,
                        stream.rand(n_var, K, T) if GT0 is None else None)
             else:
-                stream.skip((n_cell * K if ID0 is None else 0) + (n_var * K * T if GT0 is None else 0))
+                foreign += 1
+        if foreign:        # (the global stream ends where the reference's would)
+            stream.skip(foreign * per_restart)
 
     local = {}
     t_search = time.perf_counter()
