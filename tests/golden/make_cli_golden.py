@@ -19,8 +19,31 @@ MODES = {
                     "--forceLearnGT"],
     "mode5_PL3": ["-c", DATA + "/cells.cellSNP.vcf.gz", "-d", DATA + "/donors.cellSNP.vcf.gz", "-N", "3"],
     "mode1_M1_noDoublet": ["-c", DATA + "/cellSNP_mat", "-N", "4", "-M", "1", "--noDoublet"],
+    # (r3) the remaining inputs / flags of vireo.py:36-84
+    "vartrix": ["--vartrixData", ",".join([DATA + "/vartrix/alt.mtx", DATA + "/vartrix/ref.mtx",
+                                           DATA + "/vartrix/barcodes.tsv", DATA + "/cellSNP_mat/cellSNP.base.vcf.gz"]),
+                "-N", "4", "-M", "2"],
+    "cellRange": ["-c", DATA + "/cellSNP_mat", "-N", "4", "-M", "2", "--cellRange", "100-600"],
+    "extraDonor": ["-c", DATA + "/cellSNP_mat", "-N", "3", "-M", "4", "--extraDonor", "1"],
+    "extraDonor_size": ["-c", DATA + "/cellSNP_mat", "-N", "3", "-M", "4", "--extraDonor", "1",
+                        "--extraDonorMode", "size"],
+    "ASEmode": ["-c", DATA + "/cellSNP_mat", "-N", "4", "-M", "2", "--ASEmode"],
 }
 KEEP = ["donor_ids.tsv", "summary.tsv", "_log.txt"]
+KEEP_GZ = ["prob_singlet.tsv.gz", "prob_doublet.tsv.gz"]     # kept as gzip -n of the decompressed text
+
+# VarTrix-style inputs (io_utils.py:62-88: alt.mtx, ref.mtx, barcodes.tsv) derived from the
+# reference's own demo matrices: alt = AD, ref = DP - AD
+if not os.path.exists(DATA + "/vartrix/ref.mtx"):
+    from scipy.io import mmread, mmwrite
+    os.makedirs(DATA + "/vartrix", exist_ok=True)
+    ad = mmread(DATA + "/cellSNP_mat/cellSNP.tag.AD.mtx").tocsc()
+    dp = mmread(DATA + "/cellSNP_mat/cellSNP.tag.DP.mtx").tocsc()
+    ref = (dp - ad).tocsc()
+    ref.eliminate_zeros()
+    mmwrite(DATA + "/vartrix/alt.mtx", ad.astype(int), field="integer")
+    mmwrite(DATA + "/vartrix/ref.mtx", ref.astype(int), field="integer")
+    shutil.copy(DATA + "/cellSNP_mat/cellSNP.samples.tsv", DATA + "/vartrix/barcodes.tsv")
 
 for name, args in MODES.items():
     tmp = "/tmp/vireo_cli_gold_" + name
@@ -33,6 +56,10 @@ for name, args in MODES.items():
     os.makedirs(dst, exist_ok=True)
     for f in KEEP:
         shutil.copy(os.path.join(tmp, f), os.path.join(dst, f))
+    for f in KEEP_GZ:                  # the reference's own bytes of the probability tables
+        with gzip.open(os.path.join(tmp, f), "rt") as src, open(os.path.join(dst, f[:-3]), "w") as d:
+            d.write(src.read())
+        subprocess.run(["gzip", "-nf", os.path.join(dst, f[:-3])], check=True)
     vcf = os.path.join(tmp, "GT_donors.vireo.vcf.gz")
     if os.path.exists(vcf):            # keep decompressed text re-gzipped deterministically
         with gzip.open(vcf, "rt") as src, open(os.path.join(dst, "GT_donors.vireo.vcf"), "w") as d:

@@ -1,6 +1,7 @@
 """The ``vireo`` command end to end on the GPU against the text outputs of the reference
 command (tests/golden/cli/, produced by tests/golden/make_cli_golden.py): the five modes of
-the reference's examples/demo.sh plus a single-init / no-doublet run, --randSeed 2."""
+the reference's examples/demo.sh, a single-init / no-doublet run, and one run for each remaining
+input / flag (--vartrixData, --cellRange, --extraDonor in both modes, --ASEmode), --randSeed 2."""
 import gzip
 import os
 
@@ -24,6 +25,17 @@ MODES = {
     "mode5_PL3": ["-c", DATA + "/cells.cellSNP.vcf.gz", "-d", DATA + "/donors.cellSNP.vcf.gz",
                   "-N", "3"],
     "mode1_M1_noDoublet": ["-c", DATA + "/cellSNP_mat", "-N", "4", "-M", "1", "--noDoublet"],
+    # the remaining inputs / flags of the reference command (vireo.py:36-84, :136-142;
+    # io_utils.py:62-88 read_vartrix)
+    "vartrix": ["--vartrixData", ",".join([DATA + "/vartrix/alt.mtx", DATA + "/vartrix/ref.mtx",
+                                           DATA + "/vartrix/barcodes.tsv",
+                                           DATA + "/cellSNP_mat/cellSNP.base.vcf.gz"]),
+                "-N", "4", "-M", "2"],
+    "cellRange": ["-c", DATA + "/cellSNP_mat", "-N", "4", "-M", "2", "--cellRange", "100-600"],
+    "extraDonor": ["-c", DATA + "/cellSNP_mat", "-N", "3", "-M", "4", "--extraDonor", "1"],
+    "extraDonor_size": ["-c", DATA + "/cellSNP_mat", "-N", "3", "-M", "4", "--extraDonor", "1",
+                        "--extraDonorMode", "size"],
+    "ASEmode": ["-c", DATA + "/cellSNP_mat", "-N", "4", "-M", "2", "--ASEmode"],
 }
 
 
@@ -71,9 +83,11 @@ def test_cli_matches_reference_outputs(mode, tmp_path, capsys):
     # _log.txt: logLik line identical, theta shapes to 1e-6 relative
     glog, wlog = open(out + "/_log.txt").read().split("\n"), open(ref + "/_log.txt").read().split("\n")
     assert glog[0] == wlog[0]
-    gth = np.array(" ".join(glog[2:]).replace("[", " ").replace("]", " ").split(), float)
-    wth = np.array(" ".join(wlog[2:]).replace("[", " ").replace("]", " ").split(), float)
-    np.testing.assert_allclose(gth, wth, rtol=1e-6)
+    # (--ASEmode: one row per variant, which NumPy abbreviates with "...")
+    nums = lambda lines: np.array([x for x in " ".join(lines).replace("[", " ").replace("]", " ").split()   # noqa: E731
+                                   if x != "..."], float)
+    assert len(glog) == len(wlog)
+    np.testing.assert_allclose(nums(glog[2:]), nums(wlog[2:]), rtol=1e-6)
 
     # estimated donor genotypes: identical VCF text where the reference writes one
     ref_vcf = ref + "/GT_donors.vireo.vcf.gz"
@@ -92,8 +106,16 @@ def test_cli_matches_reference_outputs(mode, tmp_path, capsys):
     print("%s: donor_ids.tsv rows that differ as text: %d; VCF lines that differ: %d"
           % (mode, n_text_diff, n_vcf_diff))
     assert (n_text_diff, n_vcf_diff) == OBSERVED_TEXT_DIFFS.get(mode, (0, 0))
+    # prob_singlet / prob_doublet (io_utils.py:147-170; here the library's threaded writer):
+    # the decompressed text against the reference's own bytes
     for name in ("prob_singlet.tsv.gz", "prob_doublet.tsv.gz"):
         assert os.path.exists(out + "/" + name)
+        g = gzip.open(out + "/" + name, "rt").read().split("\n")
+        w = gzip.open(ref + "/" + name, "rt").read().split("\n")
+        assert len(g) == len(w) and g[0] == w[0]
+        bad = [i for i, (a, b) in enumerate(zip(g, w)) if a != b]
+        print("%s: %s lines that differ as text: %d" % (mode, name, len(bad)))
+        assert not bad, (name, bad[:3], g[bad[0]], w[bad[0]])
     # the probability tables (written by the library's threaded writer): one row per cell in
     # donor_ids.tsv order, and the largest singlet probability of a row prints as prob_max does
     rows = [line.split("\t") for line in gzip.open(out + "/prob_singlet.tsv.gz", "rt").read().splitlines()]

@@ -154,8 +154,22 @@ def test_config3_whole_protocol_trace_vs_oracle(va):
     print("per-iteration GPU self-sensitivity (1e-12 perturbation):", " ".join("%.1e" % x for x in own))
     assert np.all(err[:6] <= 1e-9)                       # before the unstable phase: rounding only
     assert err[-1] <= 1e-7                               # after it: the same fixed point
-    assert np.all(err <= np.maximum(RTOL, 30 * own.max()))    # in between: within the fit's own sensitivity
-    assert np.all(err <= 1e-4)
+    # In between, the arbiter decides: the same protocol in 80-bit extended precision
+    # (tests/golden/make_c3_arbiter.py -> c3_protocol_longdouble.npz; its own rounding noise is
+    # ~1e-3 of float64's).  The reference's float64 arithmetic (the oracle) is itself only
+    # e_cpu-close to the mathematics there; the GPU has to be as close -- up to a factor for the
+    # luck of the rounding draw: both errors are the SAME amplified noise process, sampled twice.
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c3_protocol_longdouble.npz"))
+    assert int(g["n_iter"]) == len(gtrace) and int(g["nnz"]) == int(w["rowidx"].size)
+    exact = g["elbo_hi"].astype(np.longdouble) + g["elbo_lo"].astype(np.longdouble)
+    e_gpu = np.abs((gtrace.astype(np.longdouble) - exact) / exact).astype(float)
+    e_cpu = np.abs((ctrace.astype(np.longdouble) - exact) / exact).astype(float)
+    print("per-iteration |gpu - exact| / |exact|:   ", " ".join("%.1e" % x for x in e_gpu))
+    print("per-iteration |oracle - exact| / |exact|:", " ".join("%.1e" % x for x in e_cpu))
+    assert np.all(e_gpu[:6] <= 1e-9) and e_gpu[-1] <= 1e-7
+    assert np.all(e_gpu <= np.maximum(RTOL, 2.0 * e_cpu.max()))    # (observed: 6.0e-6 against the oracle's 1.3e-5)
+    assert np.array_equal(dev.ID_prob.argmax(1), g["assign"])
     np.testing.assert_allclose(dev.beta_mu, st.beta_mu, rtol=RTOL)
     np.testing.assert_allclose(dev.beta_sum, st.beta_sum, rtol=RTOL)
     # the protocol stops after 20 iterations, before the remnant of that amplified difference has

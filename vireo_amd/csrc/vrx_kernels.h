@@ -1129,12 +1129,22 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_partial(
     double acc[2 * VRX_MAXT];
 #pragma unroll
     for (int t = 0; t < 2 * VRX_MAXT; ++t) acc[t] = 0.0;
+    // (the variant of an element without a 64-bit division per element, as in vrx_gt_update)
+    const int64_t stride = (int64_t)gridDim.x * VRX_BLOCK;
+    const int64_t step_n = stride / B.K;
+    const int step_k = (int)(stride - step_n * B.K);
+    int64_t n = ((int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x) / B.K;
+    int k = (int)(((int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x) - n * B.K);
     for (int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x; i < NK;
-         i += (int64_t)gridDim.x * VRX_BLOCK) {
-        const int64_t j = vrx_col(B, i, rb);
+         i += stride, n += step_n, k += step_k) {
+        if (k >= B.K) {
+            k -= B.K;
+            ++n;
+        }
+        const int64_t j = B.R == 1 ? i : n * B.Kt + (int64_t)rb * B.K + k;
         double2 s;
         if (npiece) {  // S is the in-order sum of the partial arrays that hold the variant
-            const int n_range = npiece[i / B.K];
+            const int n_range = npiece[n];
             s = make_double2(0.0, 0.0);
             for (int r0 = 0; r0 < n_range; r0 += 8) {  // (loads of 8 ranges in flight together)
                 double2 v[8];
@@ -1267,10 +1277,19 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_gt_update(
         psi_r = th_psi;
     }
     double kl[1] = {0.0};
+    // (variant, donor) of this thread's elements without a 64-bit division per element: one at
+    // the start, then steps of the grid stride
+    const int64_t stride = (int64_t)gridDim.x * VRX_BLOCK;
+    const int64_t step_n = stride / K;
+    const int step_k = (int)(stride - step_n * K);
+    int64_t n = ((int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x) / K;
+    int k = (int)(((int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x) - n * K);
     for (int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x; i < NK;
-         i += (int64_t)gridDim.x * VRX_BLOCK) {
-        const int64_t n = i / K;
-        const int k = (int)(i - n * K);
+         i += stride, n += step_n, k += step_k) {
+        if (k >= K) {
+            k -= K;
+            ++n;
+        }
         const int64_t j = n * B.Kt + (int64_t)rb * K + k;  // this restart's column of S / GT / W
         const int64_t rows = ase ? N : 1, pr = ase ? n : 0;
         const double* pb = psi_r;
