@@ -22,15 +22,17 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 config = sys.argv[1] if len(sys.argv) > 1 else "c3"
-prefix = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02"
+prefix = sys.argv[2] if len(sys.argv) > 2 else "profiles/r03"
 cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu", "--no-c4", "--steps", "3", "--warmup", "1",
        "--config", config]
+if config == "c5":      # BinomMixtureVB clone mode (BASELINE.json configs[4]): its own driver
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "perf", "bench_bmm.py"), "--passes-only"]
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     out = "/tmp/pmc_%s" % counter
     env = dict(os.environ, TMPDIR="/tmp")
     subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out,
-                    "-o", config, "--"] + cmd, cwd="/tmp", env=env, check=True,
+                    "-o", config, "--"] + cmd, cwd=ROOT if config == "c5" else "/tmp", env=env, check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):

@@ -2,7 +2,7 @@
 # Round profiles on the GPU box: kernel stats (c3, c2, c5), SQ counters and HBM traffic of c3.
 # usage (from the repository root, through gpurun): bash scratch/profile_round.sh r02
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/profiles_$TAG
 mkdir -p $OUT
@@ -31,4 +31,6 @@ mkdir -p /tmp/pmc_sq_all && cp -r /tmp/pmc_sq_1 /tmp/pmc_sq_2 /tmp/pmc_sq_all/ 2
 python $REPO/scratch/pmc_summary.py /tmp/pmc_sq_all > $OUT/${TAG}_c3_pmc_sq.txt
 cd $REPO && timeout 900 python scratch/collect_traffic.py c3 > $OUT/${TAG}_traffic_c3.log 2>&1
 cp profiles/traffic_c3.json $OUT/traffic_c3.json
+cd $REPO && timeout 900 python scratch/collect_traffic.py c5 > $OUT/${TAG}_traffic_c5.log 2>&1
+cp profiles/traffic_c5.json $OUT/traffic_c5.json
 ls -la $OUT

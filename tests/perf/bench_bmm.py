@@ -26,6 +26,8 @@ print(json.dumps(dict(workload="c5 BinomMixtureVB N=200 x M=200000 K=8 nnz=%d" %
       ms_per_iteration=wall / steps * 1e3, passes_ms=dict(variant=pm[0] / max(pn[0], 1), cell=pm[1] / max(pn[1], 1), dense=pm[2] / steps),
       info=dm.info(), cpu_oracle_s_per_iteration=tc, speedup=steps / wall * tc,
       elbo_rel_err_first_iteration=abs(tr1[0] - e) / abs(e), host_s=dict(generate=tg, upload=tu))))
+if "--passes-only" in sys.argv:
+    sys.exit(0)
 # the whole BinomMixtureVB.fit (10 initialisations of up to 100 iterations + the final fit), one
 # initialisation at a time against the packed batches
 for batch in ("1", "0"):

@@ -1,6 +1,6 @@
 """Build-time checks of the LDS-resident pass kernels (no GPU: hipcc cross-compiles gfx950).
 
-* Every AD/BD instance `launch_lds_one` can pick keeps its registers: no VGPR spill, no scratch
+* Every instance `launch_lds_one` can pick keeps its registers: no VGPR spill, no scratch
   (the dominant instance spilled 6 VGPRs at the 128-register budget of a 1024-thread
   workgroup).  The report is written to profiles/r03_spmm_lds_resource_usage.txt.
 * The walk of those instances waits for its stream with `s_waitcnt vmcnt(PF + 1)` while the prefetch
@@ -61,7 +61,7 @@ def test_ad_bd_instances_do_not_spill(isa):
     with open(os.path.join(ROOT, "profiles", "r03_spmm_lds_resource_usage.txt"), "w") as f:
         f.write("hipcc -Rpass-analysis=kernel-resource-usage, every vrx_spmm_lds instance "
                 "(tests/test_kernel_build_cpu.py)\n" + "\n".join(lines) + "\n")
-    for k, v in hot.items():
+    for k, v in inst.items():        # every instance, pair-word forms included
         assert v["spill"] == 0 and v["scratch"] == 0 and v["sgpr_spill"] == 0, (k, v)
         assert v["occupancy"] >= 4, (k, v)
 

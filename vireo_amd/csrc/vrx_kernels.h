@@ -571,6 +571,12 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
                     pf[i] = v;
                 }
             } else if (MODE == 1) {  // unit j0 = (w1, w2) of column j0
+                // (pair words: zero-filled rows / columns, conditional loads; the offsets are
+                //  formed per slab from an opaque copy of the thread index, as above)
+                int tid_f = threadIdx.x;
+                asm volatile("" : "+v"(tid_f));
+                const int j0 = tid_f % upr, r0 = tid_f / upr;
+                const bool pad_act = tid_f < padT;
                 const bool m0 = j0 < K;
                 const int off0 = r0 * ld + j0, step = rstep * ld;
 #pragma unroll
@@ -579,6 +585,10 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
                     pf[i] = in ? reinterpret_cast<const vrx_d2*>(src)[off0 + i * step] : vrx_d2{0.0, 0.0};
                 }
             } else {  // unit j0 = columns 2*j0, 2*j0 + 1
+                int tid_f = threadIdx.x;
+                asm volatile("" : "+v"(tid_f));
+                const int j0 = tid_f % upr, r0 = tid_f / upr;
+                const bool pad_act = tid_f < padT;
                 const bool m0 = 2 * j0 < K, m1 = 2 * j0 + 1 < K;
                 const int off0 = r0 * ld + 2 * j0, step = rstep * ld;
 #pragma unroll
