@@ -14,7 +14,7 @@ for cfg in c3 c2 c5; do
         python tests/perf/bench_bmm.py > $OUT/${TAG}_bench_${cfg}_under_rocprof.json 2> /tmp/st_$cfg.err)
   else
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$cfg -o $cfg -- \
-        python $REPO/bench.py --no-cpu --no-c4 --steps 20 --warmup 3 --config $cfg > $OUT/${TAG}_bench_${cfg}_under_rocprof.json 2> /tmp/st_$cfg.err
+        python $REPO/bench.py --no-cpu --no-c4 --steps 100 --warmup 50 --config $cfg > $OUT/${TAG}_bench_${cfg}_under_rocprof.json 2> /tmp/st_$cfg.err
   fi
   f=$(find /tmp/st_$cfg -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $OUT/${TAG}_${cfg}_kernel_stats.csv
