@@ -290,7 +290,7 @@ static int plan_items(TiledStream& t, const int32_t* bnd, int64_t n_wave, int nr
     const int want = env_int(mode == 1 ? "VIREO_LDS_BLOCKS_CELL" : "VIREO_LDS_BLOCKS_VAR",
                              env_int("VIREO_LDS_BLOCKS", std::max(1, n_cu)));
     const int n_wg = (int)std::max<int64_t>(1, std::min<int64_t>(want, visits));
-    const double stage = (double)env_int("VIREO_LDS_STAGE_TRIPS_X10", 50) / 10.0;
+    const double stage = (double)env_int("VIREO_LDS_STAGE_TRIPS_X10", 100) / 10.0;
     std::vector<double> cost((size_t)visits);
     parallel_chunks(t.n_tile, host_threads(), [&](int64_t t0, int64_t t1, int) {
         for (int64_t tl = t0; tl < t1; ++tl)
