@@ -401,7 +401,7 @@ def test_lds_resident_passes_vs_oracle(va, monkeypatch, fmt, blocks, sort):
 
 
 @pytest.mark.parametrize("top,var_form", [(2047, 0), (2048, 0), (7, 2), (2048, 2), (16383, 2),
-                                          (16384, 2), (90000, 2)])
+                                          (16384, 2), (90000, 2), (7, 3), (16384, 3), (90000, 3)])
 def test_lds_count_limit_and_tiny_shapes(va, monkeypatch, top, var_form):
     """The single-valued AD / BD words (cell stream, FORM 1; variant stream, FORM 2: the
     default) carry the top bits of the value's double and cut a count with more than three
@@ -416,7 +416,7 @@ def test_lds_count_limit_and_tiny_shapes(va, monkeypatch, top, var_form):
     monkeypatch.setenv("VIREO_LDS", "1")
     monkeypatch.setenv("VIREO_VAR_FORM", str(var_form))
     monkeypatch.setenv("VIREO_CELL_FORM", "1")     # (counts this deep would pick pair words)
-    expect_lds = var_form == 2 or top < 2048
+    expect_lds = var_form >= 2 or top < 2048
     rng = np.random.default_rng(5)
     dp = (rng.random((70, 40)) < 0.3) * rng.integers(1, 60, (70, 40))
     dp[3, 7] = top
@@ -706,9 +706,9 @@ def test_wrap_with_restart_batches(va, monkeypatch, capsys, batch):
     assert np.array_equal(np.argmax(res[batch]["ID_prob"], 1), np.argmax(res[1]["ID_prob"], 1))
 
 
-@pytest.mark.parametrize("depth,want", [(1.0, (1, 2)), (50.0, (0, 0)), (3000.0, (1, 2))])
+@pytest.mark.parametrize("depth,want", [(1.0, (1, 3)), (50.0, (0, 0)), (3000.0, (1, 3))])
 def test_stream_form_follows_count_depth(va, monkeypatch, depth, want):
-    """AD/BD words (cell form 1, variant form 2) on shallow data, one (ad, dp) pair word per
+    """AD/BD words (cell form 1, variant form 3 = virtual rows) on shallow data, one (ad, dp) pair word per
     entry where the counts are deep enough to need several AD/BD words each (clone mode) but
     still fit 11 bits, AD/BD words again beyond that; every choice matches the oracle"""
     from vireo_amd import _lib

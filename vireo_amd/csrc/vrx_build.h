@@ -35,6 +35,67 @@ struct VrxTileArgs {  // one orientation's tiled-stream geometry, by value to th
     int64_t n_wave;
 };
 
+// ------------------------------------------------------------------------------------
+// Virtual rows of the variant pass (TiledStream::virt).  The AD/BD variant pass needs two sums
+// per (variant, column): S1 over the AD counts and S2 over the BD counts of the variant's cells.
+// As 2N single-sum rows -- row 2n = the AD counts of variant n, row 2n + 1 its BD counts --
+// against the operand read as DOUBLE rows (cells 2j, 2j + 1 = the two 128-B halves of one 256-B
+// row) it is exactly the AD/BD cell pass (FORM 1): an entry of double row j with
+// (ad', dp') = (count at cell 2j, count at cell 2j + count at cell 2j + 1) gives a word against
+// the first half for cell 2j and one against the second half for cell 2j + 1.  One accumulator
+// per row instead of two, so the tiles are three times as tall as the two-phase variant pass's.
+// These kernels derive that matrix from the variant-major arrays (thread per variant).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_virt_count(int64_t n_var, const int64_t* __restrict__ rptr,
+                                                            const int32_t* __restrict__ ridx,
+                                                            const int2* __restrict__ rval,
+                                                            int64_t* __restrict__ cnt) {
+    const int64_t n = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    if (n >= n_var) return;
+    int64_t ca = 0, cb = 0;
+    int32_t ja = -1, jb = -1;  // last double row counted for the AD / BD row
+    for (int64_t e = rptr[n]; e < rptr[n + 1]; ++e) {
+        const int32_t j = ridx[e] >> 1;
+        const int2 x = rval[e];
+        if (x.x != 0 && j != ja) ++ca, ja = j;   // (BD = DP - AD may be negative on bad input:
+        if (x.y - x.x != 0 && j != jb) ++cb, jb = j;  //  the reference subtracts all the same)
+    }
+    cnt[2 * n] = ca;
+    cnt[2 * n + 1] = cb;
+}
+
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_virt_fill(int64_t n_var, const int64_t* __restrict__ rptr,
+                                                           const int32_t* __restrict__ ridx,
+                                                           const int2* __restrict__ rval,
+                                                           const int64_t* __restrict__ vptr2,
+                                                           int32_t* __restrict__ vidx, int2* __restrict__ vval) {
+    const int64_t n = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    if (n >= n_var) return;
+    int64_t oa = vptr2[2 * n] - 1, ob = vptr2[2 * n + 1] - 1;  // last written position of each row
+    int32_t ja = -1, jb = -1;
+    for (int64_t e = rptr[n]; e < rptr[n + 1]; ++e) {
+        const int32_t c = ridx[e], j = c >> 1;
+        const int2 x = rval[e];
+        const int a = x.x, b = x.y - x.x;
+        if (a != 0) {
+            if (j != ja) {
+                ++oa, ja = j;
+                vidx[oa] = j;
+                vval[oa] = make_int2(0, 0);
+            }
+            if (c & 1) vval[oa].y += a; else vval[oa] = make_int2(a, vval[oa].y + a);
+        }
+        if (b != 0) {
+            if (j != jb) {
+                ++ob, jb = j;
+                vidx[ob] = j;
+                vval[ob] = make_int2(0, 0);
+            }
+            if (c & 1) vval[ob].y += b; else vval[ob] = make_int2(b, vval[ob].y + b);
+        }
+    }
+}
+
 // number of FORM 1 entries a count becomes (build_tiled's push_value: top three significant bits
 // at a time)
 __device__ __forceinline__ int vrx_chunks(int64_t v) {

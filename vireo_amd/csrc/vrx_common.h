@@ -81,6 +81,11 @@ struct TiledStream {
     // [wg_first[b], wg_first[b + 1]): item = (tile, first slab, end slab, slot) -- a contiguous
     // run of one tile's slabs whose partial output goes to partial array `slot` (0, 1, ... in
     // slab order inside a tile).  The (tile, slab) visits are cut into n_wg runs of equal cost.
+    // virt: the stream's rows are VIRTUAL rows of the variant pass (vrx_build.h): row 2n = the AD
+    // counts of variant n, row 2n + 1 its BD counts, against the operand read as double rows
+    // (n_contract of them); the pass runs the cell pass's kernel form and leaves planar sums
+    bool virt = false;
+    int64_t n_contract = 0;   // contracted rows of THIS stream (double rows when virt)
     int n_range = 1;  // partial arrays = the most pieces any tile is cut into
     int n_wg = 0;
     DevBuf<int32_t> items;     // 4 words per item

@@ -371,23 +371,71 @@ static int plan_items(TiledStream& t, const int32_t* bnd, int64_t n_wave, int nr
     return VRX_OK;
 }
 
+// the virtual rows of the variant pass on the host (vrx_build.h: vrx_virt_count / vrx_virt_fill
+// are the same derivation on the device)
+static void derive_virtual_rows(int64_t n_var, const int64_t* rptr, const int32_t* ridx, const int2* rval,
+                                std::vector<int64_t>& vptr2, std::vector<int32_t>& vidx, std::vector<int2>& vval) {
+    vptr2.assign((size_t)(2 * n_var + 1), 0);
+    parallel_chunks(n_var, host_threads(), [&](int64_t n0, int64_t n1, int) {
+        for (int64_t n = n0; n < n1; ++n) {
+            int64_t ca = 0, cb = 0;
+            int32_t ja = -1, jb = -1;
+            for (int64_t e = rptr[n]; e < rptr[n + 1]; ++e) {
+                const int32_t j = ridx[e] >> 1;
+                if (rval[e].x != 0 && j != ja) ++ca, ja = j;
+                if (rval[e].y - rval[e].x != 0 && j != jb) ++cb, jb = j;
+            }
+            vptr2[(size_t)(2 * n + 1)] = ca;   // (counts: scanned below)
+            vptr2[(size_t)(2 * n + 2)] = cb;
+        }
+    });
+    for (int64_t r = 0; r < 2 * n_var; ++r) vptr2[(size_t)r + 1] += vptr2[(size_t)r];
+    vidx.resize((size_t)vptr2[(size_t)(2 * n_var)]);
+    vval.resize(vidx.size());
+    parallel_chunks(n_var, host_threads(), [&](int64_t n0, int64_t n1, int) {
+        for (int64_t n = n0; n < n1; ++n) {
+            int64_t oa = vptr2[(size_t)(2 * n)] - 1, ob = vptr2[(size_t)(2 * n + 1)] - 1;
+            int32_t ja = -1, jb = -1;
+            for (int64_t e = rptr[n]; e < rptr[n + 1]; ++e) {
+                const int32_t c = ridx[e], j = c >> 1;
+                const int a = rval[e].x, b = rval[e].y - rval[e].x;
+                if (a != 0) {
+                    if (j != ja) ++oa, ja = j, vidx[(size_t)oa] = j, vval[(size_t)oa] = make_int2(0, 0);
+                    if (c & 1) vval[(size_t)oa].y += a; else vval[(size_t)oa] = make_int2(a, vval[(size_t)oa].y + a);
+                }
+                if (b != 0) {
+                    if (j != jb) ++ob, jb = j, vidx[(size_t)ob] = j, vval[(size_t)ob] = make_int2(0, 0);
+                    if (c & 1) vval[(size_t)ob].y += b; else vval[(size_t)ob] = make_int2(b, vval[(size_t)ob].y + b);
+                }
+            }
+        }
+    });
+}
+
 static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const int2* val,
                        int RW, int slab_rows, bool guard, int form, int mode, hipStream_t s,
-                       int n_cu, const DevRows* dev = nullptr) {
+                       int n_cu, const DevRows* dev = nullptr, int64_t virt_rows = -1,
+                       int64_t virt_contract = -1, int64_t virt_nnz = -1) {
     constexpr int G = 64 / VRX_LDS_LPE, U = VRX_LDS_U;
     const int NR = RW / G;
     TiledStream& t = o.tiled;
+    // (virt_rows >= 0: ptr / idx / val are the VIRTUAL rows of the variant pass, vrx_build.h)
+    t.virt = virt_rows >= 0;
+    const int64_t o_n_rows = t.virt ? virt_rows : o.n_rows;
+    const int64_t o_n_contract = t.virt ? virt_contract : o.n_contract;
+    const int64_t o_nnz = t.virt ? virt_nnz : o.nnz;
+    t.n_contract = o_n_contract;
     t.form = form;
     t.rw = RW;
     t.slab_rows = slab_rows;
-    t.n_slab = (int)((o.n_contract + slab_rows - 1) / slab_rows);
+    t.n_slab = (int)((o_n_contract + slab_rows - 1) / slab_rows);
     // ---- pieces ------------------------------------------------------------------------
-    const double mean = (double)o.nnz / (double)std::max<int64_t>(o.n_rows, 1);
+    const double mean = (double)o_nnz / (double)std::max<int64_t>(o_n_rows, 1);
     const int64_t cap = std::max<int64_t>(
         64, (int64_t)(mean * (double)env_int("VIREO_LDS_SPLIT_X10", 20) / 10.0 + 0.5));
     const bool reorder = env_int("VIREO_LDS_SORT", 1) != 0;
-    std::vector<int32_t> vptr((size_t)o.n_rows + 1, 0);
-    for (int64_t r = 0; r < o.n_rows; ++r) {
+    std::vector<int32_t> vptr((size_t)o_n_rows + 1, 0);
+    for (int64_t r = 0; r < o_n_rows; ++r) {
         const int64_t len = ptr[r + 1] - ptr[r];
         const int64_t P = reorder ? std::max<int64_t>(1, (len + cap - 1) / cap) : 1;
         if ((int64_t)vptr[(size_t)r] + P >= INT32_MAX) {
@@ -396,11 +444,11 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
         }
         vptr[(size_t)r + 1] = vptr[(size_t)r] + (int32_t)P;
     }
-    const int64_t n_vrows = vptr[(size_t)o.n_rows];
+    const int64_t n_vrows = vptr[(size_t)o_n_rows];
     t.n_vrows = n_vrows;
-    t.split = n_vrows != o.n_rows;
+    t.split = n_vrows != o_n_rows;
     std::vector<int32_t> vrow_row((size_t)n_vrows);
-    for (int64_t r = 0; r < o.n_rows; ++r)
+    for (int64_t r = 0; r < o_n_rows; ++r)
         for (int32_t v = vptr[(size_t)r]; v < vptr[(size_t)r + 1]; ++v) vrow_row[(size_t)v] = (int32_t)r;
     const int64_t tile_rows = VRX_LDS_WAVES * (int64_t)RW;
     t.n_tile = (int)((n_vrows + tile_rows - 1) / tile_rows);
@@ -510,7 +558,7 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
             total += wave_len[(size_t)w];
             longest_wave = std::max(longest_wave, wave_len[(size_t)w]);
         }
-        t.pad_ratio = o.nnz > 0 ? (double)total / (double)o.nnz : 0.0;
+        t.pad_ratio = o_nnz > 0 ? (double)total / (double)o_nnz : 0.0;
         t.imbalance = total > 0 ? (double)longest_wave * (double)n_wave / (double)total : 1.0;
         if (guard && t.pad_ratio * std::max(1.0, t.imbalance / 1.5) > (double)env_int("VIREO_LDS_MAX_PAD", 3)) {
             t.bnd.release();
@@ -537,7 +585,7 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
     std::vector<std::vector<uint32_t>> wave_words((size_t)n_wave);
     auto walk = [&](int64_t w) {
         std::vector<uint32_t>& dst = wave_words[(size_t)w];
-        dst.reserve((size_t)((double)o.nnz / (double)n_wave * 2.3) + 1024);
+        dst.reserve((size_t)((double)o_nnz / (double)n_wave * 2.3) + 1024);
         const int32_t* rm = rowmap.data() + w * RW;
         std::vector<int64_t> cursor((size_t)RW);
         std::vector<uint32_t> segw[G], second;
@@ -662,7 +710,7 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
     }
     // Guard: past VIREO_LDS_MAX_PAD stream words per entry (default 3; padding x imbalance of
     // the slowest wave) the global-gather pass is the faster one, so no stream is kept.
-    t.pad_ratio = o.nnz > 0 ? (double)total / (double)o.nnz : 0.0;
+    t.pad_ratio = o_nnz > 0 ? (double)total / (double)o_nnz : 0.0;
     t.imbalance = total > 0 ? (double)longest_wave * (double)n_wave / (double)total : 1.0;
     if (guard && t.pad_ratio * std::max(1.0, t.imbalance / 1.5) > (double)env_int("VIREO_LDS_MAX_PAD", 3)) {
         t.ready = false;
@@ -749,7 +797,7 @@ static StreamForms pick_forms(int64_t nnz, const int32_t* ad, const int32_t* dp)
     const bool pairs = wpe > (double)env_int("VIREO_PAIR_WORDS_X100", 156) / 100.0;
     StreamForms f;
     f.cell = env_int("VIREO_CELL_FORM", pairs ? 0 : 1);
-    f.var = env_int("VIREO_VAR_FORM", pairs ? 0 : 2);
+    f.var = env_int("VIREO_VAR_FORM", pairs ? 0 : 3);
     f.auto_pair = pairs && !getenv("VIREO_CELL_FORM") && !getenv("VIREO_VAR_FORM");
     return f;
 }
@@ -801,10 +849,10 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
         return VRX_ERR_ARG;
     }
     const int32_t max_count = st[2];
-    if (max_count >= 2048 && forms.auto_pair) forms = StreamForms{1, 2, false};
+    if (max_count >= 2048 && forms.auto_pair) forms = StreamForms{1, 3, false};
     const int var_form = forms.var, cell_form = forms.cell;
     // (pair words hold 11-bit counts; a forced pair form leaves such data to the host builder)
-    if ((var_form != 2 || cell_form != 1) && max_count >= 2048) return VRX_OK;
+    if ((var_form < 2 || cell_form != 1) && max_count >= 2048) return VRX_OK;
     // ---- transposition: stable sort of (variant, entry) ---------------------------------------
     VRX_HIP(keys_in.alloc((size_t)nnz));
     VRX_HIP(keys_out.alloc((size_t)nnz));
@@ -874,9 +922,38 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
     rc = build_tiled(p->by_cell, colptr, nullptr, nullptr, rw_cell, slab_cell, guard, cell_form, 1, s,
                      p->n_cu, &cell_rows);
     if (rc) return rc;
-    rc = build_tiled(p->by_var, rptr.data(), nullptr, nullptr, VRX_LDS_RW_VARIANT, slab_var, guard,
-                     var_form == 2 ? 2 : 0, 0, s, p->n_cu, &var_rows);
-    if (rc) return rc;
+    if (var_form == 3) {
+        // the variant pass on virtual rows (vrx_build.h): derive them, then the AD/BD cell-pass
+        // stream (FORM 1) over 2 N rows x ceil(M / 2) double rows
+        DevBuf<int64_t> d_cnt, d_vptr2;
+        DevBuf<int32_t> d_vidx;
+        DevBuf<int2> d_vval;
+        VRX_HIP(d_cnt.alloc((size_t)(2 * n_var)));
+        const unsigned nbv = (unsigned)((n_var + VRX_BLOCK - 1) / VRX_BLOCK);
+        vrx_virt_count<<<nbv, VRX_BLOCK, 0, s>>>(n_var, d_rptr.p, d_ridx.p, d_rval.p, d_cnt.p);
+        VRX_HIP(hipGetLastError());
+        std::vector<int64_t> vptr2((size_t)(2 * n_var + 1), 0);
+        VRX_HIP(hipMemcpyAsync(vptr2.data() + 1, d_cnt.p, (size_t)(2 * n_var) * sizeof(int64_t),
+                               hipMemcpyDeviceToHost, s));
+        VRX_HIP(hipStreamSynchronize(s));
+        for (int64_t r = 0; r < 2 * n_var; ++r) vptr2[(size_t)r + 1] += vptr2[(size_t)r];
+        const int64_t vnnz = vptr2[(size_t)(2 * n_var)];
+        VRX_HIP(d_vptr2.upload(vptr2.data(), vptr2.size(), s));
+        VRX_HIP(d_vidx.alloc((size_t)std::max<int64_t>(vnnz, 1)));
+        VRX_HIP(d_vval.alloc((size_t)std::max<int64_t>(vnnz, 1)));
+        vrx_virt_fill<<<nbv, VRX_BLOCK, 0, s>>>(n_var, d_rptr.p, d_ridx.p, d_rval.p, d_vptr2.p, d_vidx.p,
+                                                d_vval.p);
+        VRX_HIP(hipGetLastError());
+        const DevRows virt_rows{d_vptr2.p, d_vidx.p, d_vval.p};
+        rc = build_tiled(p->by_var, vptr2.data(), nullptr, nullptr, VRX_LDS_RW_CELL, VRX_LDS_SLAB_BYTES / 256,
+                         guard, 1, 0, s, p->n_cu, &virt_rows, 2 * n_var, (n_cell + 1) / 2, vnnz);
+        if (rc) return rc;
+        VRX_HIP(hipStreamSynchronize(s));
+    } else {
+        rc = build_tiled(p->by_var, rptr.data(), nullptr, nullptr, VRX_LDS_RW_VARIANT, slab_var, guard,
+                         var_form == 2 ? 2 : 0, 0, s, p->n_cu, &var_rows);
+        if (rc) return rc;
+    }
     VRX_HIP(hipStreamSynchronize(s));
     if (!p->by_cell.tiled.ready || !p->by_var.tiled.ready) {  // rejected by the padding guard
         for (Orient* o : {&p->by_cell, &p->by_var}) {
@@ -1050,7 +1127,7 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
     // variant pass (whose per-range partials also cost the theta kernel a wider read) only
     // ties at 8-16 M and wins clearly at 100 M.
     const int lds = env_int("VIREO_LDS", -1);
-    if (max_count >= 2048 && forms.auto_pair) forms = StreamForms{1, 2, false};
+    if (max_count >= 2048 && forms.auto_pair) forms = StreamForms{1, 3, false};
     const int cell_form = forms.cell;  // 1: AD/BD stream (any counts)
     if ((max_count < 2048 || cell_form == 1) && lds != 0) {
         // cell pass: slabs of 512 W rows (128 KiB at K = 16); variant pass: 1024 ID rows
@@ -1063,8 +1140,17 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
                 if (rc) return rc;
             }
         }
-        const int var_form = forms.var;  // 2: AD / BD phases (any counts)
-        if ((var_form == 2 || max_count < 2048) &&
+        const int var_form = forms.var;  // 3: AD / BD virtual rows, 2: AD / BD phases (any counts)
+        if (var_form == 3 && (lds == 1 || nnz >= (int64_t)env_int("VIREO_LDS_MIN_NNZ_VAR", 32000000))) {
+            std::vector<int64_t> vptr2;
+            std::vector<int32_t> vidx;
+            std::vector<int2> vval;
+            derive_virtual_rows(n_var, rptr.data(), ridx.data(), rval.data(), vptr2, vidx, vval);
+            rc = build_tiled(p->by_var, vptr2.data(), vidx.data(), vval.data(), VRX_LDS_RW_CELL,
+                             VRX_LDS_SLAB_BYTES / 256, lds != 1, 1, 0, p->stream, p->n_cu, nullptr,
+                             2 * n_var, (n_cell + 1) / 2, (int64_t)vidx.size());
+            if (rc) return rc;
+        } else if ((var_form == 2 || max_count < 2048) &&
             (lds == 1 || nnz >= (int64_t)env_int("VIREO_LDS_MIN_NNZ_VAR", 32000000))) {
             rc = build_tiled(p->by_var, rptr.data(), ridx.data(), rval.data(), VRX_LDS_RW_VARIANT,
                              std::min(VRX_LDS_SLAB_BYTES / 128, std::max(16, env_int("VIREO_LDS_SLAB_VAR", VRX_LDS_SLAB_BYTES / 128))),
@@ -1318,7 +1404,8 @@ extern "C" int vrx_model_create(vrx_problem* p, const vrx_model_cfg* cfg, vrx_mo
     }
     hipStream_t s = p->stream;
     const size_t th = (size_t)(m->R * m->th_rows * m->th_cols);
-    VRX_HIP(m->ID.alloc((size_t)(m->M * m->Kt)));
+    VRX_HIP(m->ID.alloc((size_t)((m->M + 1) * m->Kt)));  // (+ a row: an odd M's last DOUBLE row, TiledStream::virt)
+    VRX_HIP(hipMemsetAsync(m->ID.p + (size_t)(m->M * m->Kt), 0, (size_t)m->Kt * sizeof(double), s));
     VRX_HIP(m->LID.alloc((size_t)(m->M * m->Kt)));
     VRX_HIP(m->mu.alloc(th));  // (th already counts the R restarts)
     VRX_HIP(m->sm.alloc(th));
@@ -1330,7 +1417,9 @@ extern "C" int vrx_model_create(vrx_problem* p, const vrx_model_cfg* cfg, vrx_mo
     VRX_HIP(m->PC.alloc((size_t)(p->by_cell.n_slots * m->Kt)));
     {
         const TiledStream &tv = p->by_var.tiled, &tc = p->by_cell.tiled;
-        if (lds_eligible<0>(p->by_var, m->Kt) && (tv.n_range > 1 || tv.split))
+        if (lds_eligible<0>(p->by_var, m->Kt) && tv.virt)  // planar sums of the virtual rows
+            VRX_HIP(m->RV.alloc((size_t)(tv.n_range * tv.n_vrows * m->Kt)));
+        else if (lds_eligible<0>(p->by_var, m->Kt) && (tv.n_range > 1 || tv.split))
             VRX_HIP(m->RV.alloc((size_t)(tv.n_range * tv.n_vrows * m->Kt * 2)));
         if (lds_eligible<1>(p->by_cell, m->Kt) && (tc.n_range > 1 || tc.split))
             VRX_HIP(m->RC.alloc((size_t)(tc.n_range * tc.n_vrows * m->Kt)));
@@ -1750,7 +1839,7 @@ static int launch_lds_one(const Orient& o, hipStream_t s, const double* X, int K
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         kern<<<grid, VRX_LDS_WAVES * 64, lds, s>>>(t.ent.p, t.wave_start.p, t.bnd.p, t.rowmap.p, t.items.p,
                                      t.wg_first.p, t.n_slab,
-                                     t.slab_rows, o.n_contract, t.n_vrows,
+                                     t.slab_rows, t.n_contract, t.n_vrows,
                                      X + (size_t)c0 * (f1 ? 1 : XD), kb, K, dst + (size_t)c0 * NV, ctl, R);
         VRX_HIP(hipGetLastError());
     }
@@ -1763,6 +1852,21 @@ static int launch_spmm_lds(vrx_model* m, const Orient& o, const double* X, int K
     hipStream_t s = m->p->stream;
     const TiledStream& t = o.tiled;
     constexpr int NV = MODE == 0 ? 2 : 1;
+    if (MODE == 0 && t.virt) {
+        // virtual rows: the cell pass's kernel over (variant, AD) / (variant, BD) rows and the
+        // operand as double rows; planar partial sums [slot][virtual piece][K], turned into
+        // S = (S1, S1 + S2) by the consumer (vrx_theta_partial) or by vrx_s_from_virtual
+        int rc = launch_lds_one<VRX_LDS_LPE, 1>(o, s, X, K, range_partial, m->ctl.p, m->R);
+        if (rc) return rc;
+        if (!defer_sum) {
+            const int64_t n = o.n_rows * K;
+            vrx_s_from_virtual<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
+                o.n_rows, K, t.n_vrows, t.split ? t.vptr.p : nullptr, t.npiece.p, range_partial,
+                reinterpret_cast<double2*>(out), m->ctl.p, m->R);
+            VRX_HIP(hipGetLastError());
+        }
+        return VRX_OK;
+    }
     double* dst = t.n_range == 1 && !t.split ? out : range_partial;
     int rc;
     rc = launch_lds_one<VRX_LDS_LPE, MODE>(o, s, X, K, dst, m->ctl.p, m->R);  // K < 16 leaves lanes idle
@@ -1828,7 +1932,8 @@ static int launch_spmm(vrx_model* m, const Orient& o, const double* X, int K, do
 static int variant_pass(vrx_model* m, bool defer_sum = false) {
     ProfScope ps(m, VRX_KERN_VARIANT_PASS);
     if (lds_eligible<0>(m->p->by_var, m->Kt)) {
-        m->s_pending = defer_sum && m->p->by_var.tiled.n_range > 1 && !m->p->by_var.tiled.split;
+        const TiledStream& tv = m->p->by_var.tiled;
+        m->s_pending = defer_sum && (tv.virt || (tv.n_range > 1 && !tv.split));
         return launch_spmm_lds<0>(m, m->p->by_var, m->ID.p, m->Kt, m->S.p, m->RV.p, defer_sum);
     }
     return launch_spmm<0>(m, m->p->by_var, m->ID.p, m->Kt, m->S.p, m->PV.p);
@@ -1847,6 +1952,16 @@ static int cell_pass(vrx_model* m, bool defer_sum = false) {
 // a consumer that cannot fuse the range sum forms S / logLik_ID explicitly
 static int resolve_S(vrx_model* m) {
     if (!m->s_pending) return VRX_OK;
+    const TiledStream& tv = m->p->by_var.tiled;
+    if (tv.virt) {
+        const int64_t n = m->NKt;
+        vrx_s_from_virtual<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, m->p->stream>>>(
+            m->N, m->Kt, tv.n_vrows, tv.split ? tv.vptr.p : nullptr, tv.npiece.p, m->RV.p,
+            reinterpret_cast<double2*>(m->S.p), m->ctl.p, m->R);
+        VRX_HIP(hipGetLastError());
+        m->s_pending = false;
+        return VRX_OK;
+    }
     const int64_t n = m->NKt * 2;
     vrx_sum_ranges<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, m->p->stream>>>(
         n, m->Kt * 2, m->p->by_var.tiled.npiece.p, m->RV.p, m->S.p, m->ctl.p, m->R);
@@ -1889,11 +2004,16 @@ static int theta_step(vrx_model* m, int update, bool defer_final = false) {
         m->w_valid = false;
     } else {
         if (update) {
-            const uint16_t* np = m->s_pending ? m->p->by_var.tiled.npiece.p : nullptr;
+            const TiledStream& tv = m->p->by_var.tiled;
+            if (m->s_pending && tv.virt && tv.split) {  // (pieces of long rows: the general sum first)
+                int rc = resolve_S(m);
+                if (rc) return rc;
+            }
+            const uint16_t* np = m->s_pending ? tv.npiece.p : nullptr;
             vrx_theta_partial<<<dim3(m->nb_theta, m->R), VRX_BLOCK, 0, s>>>(
                 m->NK, m->T, reinterpret_cast<double2*>(m->S.p), np,
-                reinterpret_cast<const double2*>(m->RV.p), m->GT.p, m->part_theta.p, m->batch(),
-                m->ctl.p);
+                reinterpret_cast<const double2*>(m->RV.p), m->s_pending && tv.virt ? tv.n_vrows : 0,
+                m->GT.p, m->part_theta.p, m->batch(), m->ctl.p);
             VRX_HIP(hipGetLastError());
             m->s_pending = false;
         }
@@ -2209,10 +2329,10 @@ extern "C" int vrx_model_info(vrx_model* m, int32_t* info) {
     info[7] = c.tiled.ready ? c.tiled.n_range : 0;
     info[8] = v.tiled.ready ? (int32_t)(v.tiled.pad_ratio * 1000.0 + 0.5) : 0;
     info[9] = c.tiled.ready ? (int32_t)(c.tiled.pad_ratio * 1000.0 + 0.5) : 0;
-    info[10] = v.tiled.ready ? (int32_t)(v.tiled.n_vrows - v.n_rows) : 0;
+    info[10] = v.tiled.ready ? (int32_t)(v.tiled.n_vrows - (v.tiled.virt ? 2 : 1) * v.n_rows) : 0;
     info[11] = c.tiled.ready ? (int32_t)(c.tiled.n_vrows - c.n_rows) : 0;
     info[12] = c.tiled.ready ? c.tiled.form : 0;
-    info[13] = v.tiled.ready ? v.tiled.form : 0;
+    info[13] = v.tiled.ready ? (v.tiled.virt ? 3 : v.tiled.form) : 0;  // 3: AD/BD virtual rows
     info[14] = m->R;
     info[15] = 0;
     return VRX_OK;

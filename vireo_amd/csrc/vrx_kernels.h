@@ -990,6 +990,33 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_ranges(int64_t n, int width
     out[i] = s;
 }
 
+// S = (S1, S1 + S2) from the planar partial sums of the virtual rows (TiledStream::virt):
+// partial[slot][piece v][Kt]; row 2 n + kind of the virtual matrix is the pieces
+// [vptr[2 n + kind], vptr[2 n + kind + 1]) (vptr == null: one piece each, v = the row), piece v
+// has a term in the first npiece[v] arrays.  Terms in (slot, piece) order, like vrx_sum_pieces.
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_s_from_virtual(
+    int64_t N, int Kt, int64_t n_vrows, const int32_t* __restrict__ vptr, const uint16_t* __restrict__ npiece,
+    const double* __restrict__ partial, double2* __restrict__ S, const int32_t* __restrict__ ctl, int n_batch) {
+    if (vrx_all_stopped(ctl, n_batch)) return;
+    const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    if (i >= N * Kt) return;
+    const int64_t n = i / Kt;
+    const int c = (int)(i - n * Kt);
+    double sk[2];
+    for (int kind = 0; kind < 2; ++kind) {
+        const int64_t row = 2 * n + kind;
+        const int64_t v0 = vptr ? vptr[row] : row, v1 = vptr ? vptr[row + 1] : row + 1;
+        int most = 0;
+        for (int64_t v = v0; v < v1; ++v) most = max(most, (int)npiece[v]);
+        double t = 0.0;
+        for (int r = 0; r < most; ++r)
+            for (int64_t v = v0; v < v1; ++v)
+                if (r < npiece[v]) t += partial[((int64_t)r * n_vrows + v) * Kt + c];
+        sk[kind] = t;
+    }
+    S[i] = make_double2(sk[0], sk[0] + sk[1]);
+}
+
 // Second stage for rows that were split over several segments: in-order sum of the slots.
 // VPE = values per element (2 for the variant pass, 1 for the cell pass).
 template <int VPE>
@@ -1131,8 +1158,8 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_final(int n_part, int T, 
 // LDS-resident variant pass left in `ranges` (npiece[variant] of them; fused here to save a launch).
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_partial(
     int64_t NK, int T, double2* S, const uint16_t* __restrict__ npiece,
-    const double2* __restrict__ ranges, const double* __restrict__ GT, double* __restrict__ part,
-    VrxBatch B, const int32_t* __restrict__ ctl) {
+    const double2* __restrict__ ranges, int64_t n_virtual, const double* __restrict__ GT,
+    double* __restrict__ part, VrxBatch B, const int32_t* __restrict__ ctl) {
     const int rb = blockIdx.y;
     if (ctl[rb * VRX_CTL_WORDS + VRX_CTL_STOP]) return;
     const int64_t NKt = NK * B.R;
@@ -1153,7 +1180,31 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_partial(
         }
         const int64_t j = B.R == 1 ? i : n * B.Kt + (int64_t)rb * B.K + k;
         double2 s;
-        if (npiece) {  // S is the in-order sum of the partial arrays that hold the variant
+        if (npiece && n_virtual > 0) {
+            // virtual rows (TiledStream::virt): planar partial sums [slot][2 n + kind][Kt], the AD
+            // row's into S1, the BD row's into S2, each over its own number of slots; SS = S1 + S2
+            const double* P = reinterpret_cast<const double*>(ranges);
+            const int64_t col = B.R == 1 ? k : (int64_t)rb * B.K + k;
+            double sk[2];
+#pragma unroll
+            for (int kind = 0; kind < 2; ++kind) {
+                const int64_t v = 2 * n + kind;
+                const int nr = npiece[v];
+                const double* src = P + v * B.Kt + col;
+                double t = 0.0;
+                for (int r0 = 0; r0 < nr; r0 += 8) {
+                    double x[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) x[u] = r0 + u < nr ? src[(int64_t)(r0 + u) * n_virtual * B.Kt] : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (r0 + u < nr) t += x[u];
+                }
+                sk[kind] = t;
+            }
+            s = make_double2(sk[0], sk[0] + sk[1]);
+            S[j] = s;
+        } else if (npiece) {  // S is the in-order sum of the partial arrays that hold the variant
             const int n_range = npiece[n];
             s = make_double2(0.0, 0.0);
             for (int r0 = 0; r0 < n_range; r0 += 8) {  // (loads of 8 ranges in flight together)

@@ -117,7 +117,7 @@ class DeviceRestarts:
         if batch is None:
             info = self.dm.info()
             ad_bd = (not info["lds_cell"] and not info["lds_variant"]) or (
-                info["cell_form"] == 1 and info["var_form"] == 2)
+                info["cell_form"] == 1 and info["var_form"] in (2, 3))
             batch = restart_batch(template.n_donor, n_owned, counts.nnz, wide=ad_bd)
         self.batch = int(batch)
         self.db = None
