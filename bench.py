@@ -137,10 +137,15 @@ def c2_leg(device, steps=200):
         N, M, K, int(w["rowidx"].size), steps), us_per_restart_iteration={})
     for R in (1, 4, 16):
         db = DeviceBatch(counts, _lib.KIND_VIREO, K, R)
+        # (the reference's default priors: uniform ID / GT, theta Beta(0.3, 29.7), (3, 3), (29.7, 0.3))
+        db.set_prior(np.full((1, K), 1.0 / K), np.full((1, K, 3), 1.0 / 3),
+                     np.array([[0.3, 3.0, 29.7]]), np.array([[29.7, 3.0, 0.3]]))
         for r in range(R):
             db.set_restart(r, rng.random((M, K)), rng.random((N, K, 3)), mu, sm, raw=True)
         db.run_iters(10)
-        _, ms = db.run_iters(steps)
+        tr, ms = db.run_iters(steps)
+        if not np.all(np.isfinite(tr)):
+            raise RuntimeError("c2 leg: a non-finite ELBO in the timed iterations")
         out["us_per_restart_iteration"]["n_batch=%d" % R] = round(ms / steps / R * 1e3, 2)
         db.close()
     return out

@@ -112,6 +112,24 @@ def test_trace_and_warm_restart(va):
     print("max rel ELBO err %.3e" % np.max(np.abs(m.ELBO_ / g["ELBO_"] - 1)))
 
 
+def test_fused_cell_softmax_equals_separate_kernels(va, monkeypatch):
+    """small problems run the cell pass with the softmax and the cells' ELBO terms in its epilogue
+    (vrx_spmm FUSE = 1): the posteriors are the separate kernels' bit for bit, the ELBO differs only
+    by the grouping of its partial sums"""
+    AD, DP = gold.c1()
+    fits = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("VIREO_FUSE_SOFTMAX", fuse)
+        np.random.seed(2)
+        m = va.Vireo(n_var=AD.shape[0], n_cell=AD.shape[1], n_donor=4)
+        m.fit(AD, DP, min_iter=5, max_iter=15, delay_fit_theta=3, verbose=False)
+        fits[fuse] = (np.array(m.ELBO_), m.ID_prob.copy(), m.GT_prob.copy())
+    assert len(fits["0"][0]) == len(fits["1"][0])
+    assert np.array_equal(fits["0"][1], fits["1"][1])
+    assert np.array_equal(fits["0"][2], fits["1"][2])
+    close(fits["1"][0], fits["0"][0], rtol=1e-13)
+
+
 @pytest.mark.parametrize("tag,kw", [("ase", dict(ASE_mode=True)),
                                     ("fixsum", dict(fix_beta_sum=True)),
                                     ("notheta", dict(learn_theta=False))])

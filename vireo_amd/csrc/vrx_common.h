@@ -113,6 +113,7 @@ struct Orient {
     DevBuf<int32_t> seg_len;
     DevBuf<int32_t> seg_dst;
     int64_t n_multi = 0, n_slots = 0;
+    int64_t n_empty = 0;  // rows without entries (no segment: their output is the zero fill)
     DevBuf<int32_t> multi_row;
     DevBuf<int32_t> multi_ptr;  // n_multi + 1 slot offsets
 };

@@ -177,7 +177,10 @@ static int build_orient(Orient& o, int64_t n_rows, int64_t n_contract, const int
     std::vector<int> row_tile;
     for (int64_t r = 0; r < n_rows; ++r) {
         const int64_t lo = ptr[r], hi = ptr[r + 1];
-        if (hi <= lo) continue;  // empty row: its output stays 0 (buffers are zero-filled)
+        if (hi <= lo) {  // empty row: its output stays 0 (buffers are zero-filled)
+            ++o.n_empty;
+            continue;
+        }
         row_segs.clear();
         row_tile.clear();
         int64_t at = lo;
@@ -1304,6 +1307,7 @@ struct vrx_model {
     // reductions
     int nb_theta = 0, nb_nk = 0, nb_cell = 0, nb_throws = 0, n_th_part = 1;
     int nb_gt = 0;               // blocks (= KL_GT partials) of the grid-stride vrx_gt_update
+    int n_cell_part = 0;         // cell partials of the kernel that ran last (softmax or fused cell pass)
     bool theta_pending = false;  // stage-1 partials wait for the finalisation inside vrx_gt_update
     DevBuf<double> part_theta, part_gt, part_cell, part_th;
     DevBuf<double> d_elbo, d_parts;
@@ -1434,7 +1438,8 @@ extern "C" int vrx_model_create(vrx_problem* p, const vrx_model_cfg* cfg, vrx_mo
     m->nb_throws = (int)((m->N + VRX_BLOCK - 1) / VRX_BLOCK);
     m->nb_theta = std::min(m->nb_nk, p->n_cu * 4);
     m->nb_gt = std::min(m->nb_nk, p->n_cu * 8);
-    VRX_HIP(m->part_cell.alloc((size_t)m->R * m->nb_cell * 2));
+    m->n_cell_part = m->nb_cell;
+    VRX_HIP(m->part_cell.alloc((size_t)m->R * std::max<int64_t>(m->nb_cell, p->by_cell.n_seg / VRX_WAVES + 1) * 2));
     VRX_HIP(m->part_gt.alloc((size_t)m->R * m->nb_nk));
     VRX_HIP(hipMemsetAsync(m->part_gt.p, 0, (size_t)m->R * m->nb_nk * sizeof(double), s));
     if (cfg->kind == VRX_KIND_VIREO) {
@@ -1749,17 +1754,29 @@ extern "C" int vrx_model_set_prior(vrx_model* m, const double* ID_prior, int64_t
 // ------------------------------------------------------------------------------------
 template <int LPE, int CPL, int MODE>
 static void launch_spmm_fmt(const Orient& o, dim3 grid, hipStream_t s, const double* X, int K,
-                            double* out, double* partial, const int32_t* ctl, int R) {
-#define VRX_GO(F)                                                                              \
-    vrx_spmm<LPE, CPL, MODE, F><<<grid, VRX_BLOCK, 0, s>>>(o.n_seg, o.seg_begin.p, o.seg_len.p, \
-                                                           o.seg_dst.p, o.ent.p, X, K, out,    \
-                                                           partial, ctl, R)
+                            double* out, double* partial, const int32_t* ctl, int R,
+                            const VrxCellFuse* fuse = nullptr) {
+#define VRX_GO(F, FU)                                                                           \
+    vrx_spmm<LPE, CPL, MODE, F, FU><<<grid, VRX_BLOCK, 0, s>>>(                                 \
+        o.n_seg, o.seg_begin.p, o.seg_len.p, o.seg_dst.p, o.ent.p, X, K, out, partial, ctl, R,  \
+        fuse ? *fuse : VrxCellFuse{})
+    if constexpr (MODE == 1 && CPL == 1) {
+        if (fuse) {  // cell pass + softmax + ELBO partials in one launch (vrx_kernels.h: FUSE = 1)
+            if (o.fmt == VRX_FMT_P32)
+                VRX_GO(VRX_FMT_P32, 1);
+            else if (o.fmt == VRX_FMT_P64)
+                VRX_GO(VRX_FMT_P64, 1);
+            else
+                VRX_GO(VRX_FMT_WIDE, 1);
+            return;
+        }
+    }
     if (o.fmt == VRX_FMT_P32)
-        VRX_GO(VRX_FMT_P32);
+        VRX_GO(VRX_FMT_P32, 0);
     else if (o.fmt == VRX_FMT_P64)
-        VRX_GO(VRX_FMT_P64);
+        VRX_GO(VRX_FMT_P64, 0);
     else
-        VRX_GO(VRX_FMT_WIDE);
+        VRX_GO(VRX_FMT_WIDE, 0);
 #undef VRX_GO
 }
 
@@ -1891,7 +1908,7 @@ static int launch_spmm_lds(vrx_model* m, const Orient& o, const double* X, int K
 
 template <int MODE>
 static int launch_spmm(vrx_model* m, const Orient& o, const double* X, int K, double* out,
-                       double* partial) {
+                       double* partial, const VrxCellFuse* fuse = nullptr) {
     if (o.n_seg == 0) return VRX_OK;
     hipStream_t s = m->p->stream;
     // lanes per entry x columns per lane: 16 B per lane wherever the layout allows
@@ -1910,11 +1927,11 @@ static int launch_spmm(vrx_model* m, const Orient& o, const double* X, int K, do
         }
     } else {
         switch (lpe) {
-            case 1: launch_spmm_fmt<1, 1, MODE>(o, grid, s, X, K, out, partial, m->ctl.p, m->R); break;
-            case 2: launch_spmm_fmt<2, 1, MODE>(o, grid, s, X, K, out, partial, m->ctl.p, m->R); break;
-            case 4: launch_spmm_fmt<4, 1, MODE>(o, grid, s, X, K, out, partial, m->ctl.p, m->R); break;
-            case 8: launch_spmm_fmt<8, 1, MODE>(o, grid, s, X, K, out, partial, m->ctl.p, m->R); break;
-            default: launch_spmm_fmt<16, 1, MODE>(o, grid, s, X, K, out, partial, m->ctl.p, m->R); break;
+            case 1: launch_spmm_fmt<1, 1, MODE>(o, grid, s, X, K, out, partial, m->ctl.p, m->R, fuse); break;
+            case 2: launch_spmm_fmt<2, 1, MODE>(o, grid, s, X, K, out, partial, m->ctl.p, m->R, fuse); break;
+            case 4: launch_spmm_fmt<4, 1, MODE>(o, grid, s, X, K, out, partial, m->ctl.p, m->R, fuse); break;
+            case 8: launch_spmm_fmt<8, 1, MODE>(o, grid, s, X, K, out, partial, m->ctl.p, m->R, fuse); break;
+            default: launch_spmm_fmt<16, 1, MODE>(o, grid, s, X, K, out, partial, m->ctl.p, m->R, fuse); break;
         }
     }
     VRX_HIP(hipGetLastError());
@@ -1947,6 +1964,31 @@ static int cell_pass(vrx_model* m, bool defer_sum = false) {
         return launch_spmm_lds<1>(m, m->p->by_cell, m->W.p, m->Kt, m->LID.p, m->RC.p, defer_sum);
     }
     return launch_spmm<1>(m, m->p->by_cell, m->W.p, m->Kt, m->LID.p, m->PC.p);
+}
+
+// Small problems (gather kernels, one restart, K <= 16, every cell exactly one segment -- none
+// split, none without entries):
+// the cell pass's waves hold complete logLik_ID rows, so the softmax and the cells' ELBO terms
+// ride in its epilogue -- one launch less per iteration (c2: ~4 us of ~37).
+static bool cell_softmax_fusable(const vrx_model* m) {
+    const int on = env_int("VIREO_FUSE_SOFTMAX", 1);  // (read per call: the tests switch it)
+    const Orient& o = m->p->by_cell;
+    return on && m->R == 1 && m->Kt <= 16 && o.n_seg > 0 && o.n_multi == 0 && o.n_empty == 0 &&
+           !lds_eligible<1>(o, m->Kt);
+}
+
+static int cell_pass_softmax(vrx_model* m) {
+    ProfScope ps(m, VRX_KERN_CELL_PASS);
+    const Orient& o = m->p->by_cell;
+    VrxCellFuse F;
+    F.logq = m->logq_id.p;
+    F.id_mode = m->id_mode;
+    F.logq_uni = -std::log((double)m->K);
+    F.ID = m->ID.p;
+    F.part = m->part_cell.p;
+    m->n_cell_part = (int)(o.n_seg / VRX_WAVES);
+    m->l_pending = false;
+    return launch_spmm<1>(m, o, m->W.p, m->Kt, m->LID.p, m->PC.p, &F);
 }
 
 // a consumer that cannot fuse the range sum forms S / logLik_ID explicitly
@@ -2069,7 +2111,7 @@ static VrxElboIn elbo_inputs(vrx_model* m) {
     e.cell_part = m->part_cell.p;
     e.gt_part = m->part_gt.p;
     e.th_part = m->part_th.p;
-    e.n_cell_part = m->nb_cell;
+    e.n_cell_part = m->n_cell_part;  // (of the kernel that formed them last)
     e.n_gt_part = m->cfg.kind == VRX_KIND_VIREO ? m->nb_gt : 0;
     e.n_th_part = m->n_th_part;
     e.elbo = m->d_elbo.p;
@@ -2092,6 +2134,7 @@ static int softmax_step(vrx_model* m, int update) {
     const double lu = -std::log((double)m->K);
     const uint16_t* nr = m->l_pending ? m->p->by_cell.tiled.npiece.p : nullptr;  // fused sum of the partials
     m->l_pending = false;
+    m->n_cell_part = m->nb_cell;
 #define VRX_SM_CASE(KPV)                                                                        \
     case KPV:                                                                                   \
         vrx_cell_softmax<KPV><<<dim3(m->nb_cell, m->R), VRX_BLOCK, 0, s>>>(                     \
@@ -2145,8 +2188,12 @@ static int enqueue_iteration(vrx_model* m, bool do_theta, const VrxStopRule& rul
             if ((rc = gt_step(m, 0))) return rc;
         }
     }
-    if ((rc = cell_pass(m, true))) return rc;  // range sum fused into the softmax kernel
-    if ((rc = softmax_step(m, 1))) return rc;
+    if (cell_softmax_fusable(m)) {
+        if ((rc = cell_pass_softmax(m))) return rc;
+    } else {
+        if ((rc = cell_pass(m, true))) return rc;  // range sum fused into the softmax kernel
+        if ((rc = softmax_step(m, 1))) return rc;
+    }
     return elbo_step(m, rule);                 // ELBO + the stop rule, on the device
 }
 

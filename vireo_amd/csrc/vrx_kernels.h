@@ -39,9 +39,15 @@ constexpr int VRX_MAXT = 8;  // max genotype classes handled by the dense kernel
 // ------------------------------------------------------------------------------------
 enum { VRX_CTL_STOP = 0, VRX_CTL_IT = 1, VRX_CTL_WARN = 2, VRX_CTL_WORDS = 4 };  // per restart
 __device__ __forceinline__ bool vrx_all_stopped(const int32_t* ctl, int R) {
-    for (int r = 0; r < R; ++r)
-        if (!ctl[r * VRX_CTL_WORDS + VRX_CTL_STOP]) return false;
-    return true;
+    if (R == 1) return ctl[VRX_CTL_STOP] != 0;
+    if (R <= 64) {  // lane r reads restart r's word: one round trip for the whole batch
+        const int r = (int)(threadIdx.x & 63);
+        const int v = r < R ? ctl[r * VRX_CTL_WORDS + VRX_CTL_STOP] : 1;
+        return __builtin_amdgcn_ballot_w64(v == 0) == 0;
+    }
+    bool all = true;
+    for (int r = 0; r < R; ++r) all = all && ctl[r * VRX_CTL_WORDS + VRX_CTL_STOP] != 0;
+    return all;
 }
 // Restart batches.  A model may hold R restarts of the same problem (vireo_wrap.py:64-87 runs
 // them one after the other): the dense operands then carry R * K columns -- ID_prob [M][R][K],
@@ -72,13 +78,18 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// Sum NV values per thread over the 256-thread block; thread 0 writes out[0..NV).
+// Sum NV values per thread over the 256-thread block; thread 0 writes out[0..NV).  `period`,
+// `live`: only the values with i % period < live are summed (the others are written as 0) --
+// the theta sums are laid out [2][VRX_MAXT] and T = 3 of the VRX_MAXT classes exist, and a
+// wave reduction is 12 cross-lane moves of latency per value.
 template <int NV>
-__device__ __forceinline__ void block_sum_store(const double (&v)[NV], double* out) {
+__device__ __forceinline__ void block_sum_store(const double (&v)[NV], double* out, int period = NV,
+                                                int live = NV) {
     __shared__ double sm[NV * VRX_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
+        if (i % period >= live) continue;  // (uniform)
         double r = wave_sum(v[i]);
         if (lane == 0) sm[i * VRX_WAVES + wave] = r;
     }
@@ -87,8 +98,10 @@ __device__ __forceinline__ void block_sum_store(const double (&v)[NV], double* o
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             double r = 0.0;
+            if (i % period < live) {
 #pragma unroll
-            for (int w = 0; w < VRX_WAVES; ++w) r += sm[i * VRX_WAVES + w];
+                for (int w = 0; w < VRX_WAVES; ++w) r += sm[i * VRX_WAVES + w];
+            }
             out[i] = r;
         }
     }
@@ -246,24 +259,45 @@ __device__ __forceinline__ void vrx_spmm_batch(const VrxWords<FMT>& e, int nh, i
     }
 }
 
-template <int LPE, int CPL, int MODE, int FMT>
+// FUSE = 1 (cell pass of ONE restart, K <= 16, every row a single segment): the wave that holds a
+// cell's complete logLik_ID row also takes its softmax and the cell's ELBO terms -- vrx_cell_softmax's
+// arithmetic on the LPE lanes of group 0 -- so a small problem's iteration is one launch shorter
+// (each launch costs it ~4-5 us) and logLik_ID is not re-read.
+struct VrxCellFuse {  // by value
+    const double* logq;  // id_mode 1: one row of K; 2: (M, K)
+    int id_mode;
+    double logq_uni;
+    double* ID;
+    double* part;  // [gridDim.x][2]: (sum L p, sum p (log p - log q)) of the block's cells
+};
+
+template <int LPE, int CPL, int MODE, int FMT, int FUSE = 0>
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_spmm(
     int64_t n_seg, const int64_t* __restrict__ seg_begin, const int32_t* __restrict__ seg_len,
     const int32_t* __restrict__ seg_dst, const uint32_t* __restrict__ ent,
     const double* __restrict__ X, int K, double* __restrict__ out, double* __restrict__ partial,
-    const int32_t* __restrict__ ctl, int n_batch) {
+    const int32_t* __restrict__ ctl, int n_batch, VrxCellFuse F) {
     static_assert(LPE * CPL <= 16 && (MODE == 0 || CPL == 1), "layout");
-    if (vrx_all_stopped(ctl, n_batch)) return;
+    static_assert(FUSE == 0 || (MODE == 1 && CPL == 1), "the fused epilogue is the cell pass's");
+    // (the stop words and the segment record are read TOGETHER: a kernel of a small problem is a
+    //  chain of dependent memory round trips of ~1 us each, and an early return on the stop
+    //  word alone would put one more in front of every launch)
     const int lane = threadIdx.x & 63;
     const int64_t seg = (int64_t)blockIdx.x * VRX_WAVES + (threadIdx.x >> 6);
-    if (seg >= n_seg) return;
-    const int len = seg_len[seg];
-    if (len < 0) return;  // padding of the XCD-aware launch order
+    const bool in_range = seg < n_seg;
+    const int len_raw = in_range ? seg_len[seg] : -1;
+    const int64_t b = (in_range ? seg_begin[seg] : 0) + lane;
+    const int d = in_range ? seg_dst[seg] : 0;
+    const bool stopped = vrx_all_stopped(ctl, n_batch);
+    // (len < 0: padding of the XCD-aware launch order; the fused epilogue ends in a block sum,
+    //  so its idle waves stay until then)
+    if (stopped || (FUSE == 0 && len_raw < 0)) return;
+    const bool act = len_raw >= 0;
+    const int len = act ? len_raw : 0;
     const int g = lane / LPE, kl = lane % LPE;
     const int k = (blockIdx.y * LPE + kl) * CPL;
     const bool kok = k < K;
     const uint32_t kc = kok ? k : K - CPL;  // padded lanes re-read the last columns, never store
-    const int64_t b = seg_begin[seg] + lane;
     double a1[CPL], a2[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) a1[c] = a2[c] = 0.0;
@@ -283,8 +317,8 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_spmm(
             a1[c] += __shfl_xor(a1[c], s, 64);
             if (MODE == 0) a2[c] += __shfl_xor(a2[c], s, 64);
         }
-    if (g == 0 && kok) {
-        const int d = seg_dst[seg];
+    const bool own = act && g == 0 && kok;
+    if (own) {
         double* base = d >= 0 ? out : partial;
         const int64_t row = d >= 0 ? d : -(int64_t)d - 1;
 #pragma unroll
@@ -294,6 +328,28 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_spmm(
             else
                 base[row * K + k + c] = a1[c];
         }
+    }
+    if (FUSE == 1) {  // (d >= 0 for every segment: the host fuses only when no row is split)
+        const double L = a1[0];
+        const double lq = !own || F.id_mode == 0 ? F.logq_uni
+                                                 : (F.id_mode == 2 ? F.logq[(int64_t)d * K + k] : F.logq[k]);
+        const double x0 = own ? L + lq : -__builtin_inf();
+        double mx = x0;
+#pragma unroll
+        for (int s = 1; s < LPE; s <<= 1) mx = fmax(mx, __shfl_xor(mx, s, 64));
+        double sum = own ? exp(x0 - mx) : 0.0;
+#pragma unroll
+        for (int s = 1; s < LPE; s <<= 1) sum += __shfl_xor(sum, s, 64);
+        double acc[2] = {0.0, 0.0};
+        if (own) {
+            const double x = x0 - mx;
+            const double p = exp(x) / sum;
+            const double lp = x - log(sum);
+            F.ID[(int64_t)d * K + k] = p;
+            acc[0] = L * p;
+            if (p > 0.0) acc[1] = p * (lp - lq);
+        }
+        block_sum_store<2>(acc, F.part + (int64_t)blockIdx.x * 2);
     }
 }
 
@@ -1070,16 +1126,37 @@ __device__ __forceinline__ double vrx_theta_row(int T, int update, int fix_sum, 
 __device__ __forceinline__ void vrx_theta_final_block(int n_part, int T, int update, int fix_sum,
                                                       const double* part, const double* prior1,
                                                       const double* prior2, double* mu, double* sm,
-                                                      double* psi, double* kl_out) {
+                                                      double* psi, double* kl_out, int stop) {
     __shared__ double tot[2 * VRX_MAXT];
     double acc[2 * VRX_MAXT];
 #pragma unroll
     for (int t = 0; t < 2 * VRX_MAXT; ++t) acc[t] = 0.0;
+    // (the partials -- four strides in flight together -- and the Beta parameters are requested
+    //  before the caller's stop word is tested: one memory round trip instead of three)
     if (update)
-        for (int b = threadIdx.x; b < n_part; b += VRX_BLOCK)
+        for (int b0 = threadIdx.x; b0 < n_part; b0 += 4 * VRX_BLOCK) {
+            double v[4][2 * VRX_MAXT];
 #pragma unroll
-            for (int t = 0; t < 2 * VRX_MAXT; ++t) acc[t] += part[(int64_t)b * 2 * VRX_MAXT + t];
-    block_sum_store<2 * VRX_MAXT>(acc, tot);
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < 2 * VRX_MAXT; ++t)
+                    v[u][t] = b0 + u * VRX_BLOCK < n_part && t % VRX_MAXT < T
+                                  ? part[(int64_t)(b0 + u * VRX_BLOCK) * 2 * VRX_MAXT + t] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (b0 + u * VRX_BLOCK < n_part)
+#pragma unroll
+                    for (int t = 0; t < 2 * VRX_MAXT; ++t) acc[t] += v[u][t];
+        }
+    double in_mu = 0.0, in_sm = 0.0, in_p1 = 0.0, in_p2 = 0.0;
+    if (threadIdx.x < T) {
+        in_mu = mu[threadIdx.x];
+        in_sm = sm[threadIdx.x];
+        in_p1 = prior1[threadIdx.x];
+        in_p2 = prior2[threadIdx.x];
+    }
+    if (stop) return;
+    block_sum_store<2 * VRX_MAXT>(acc, tot, VRX_MAXT, T);
     __syncthreads();
     // The 9 special-function values per genotype class (3 digammas, 6 log-gammas) are the
     // whole cost of this kernel: spread them over 9*T threads, combine in thread 0 in the
@@ -1088,10 +1165,10 @@ __device__ __forceinline__ void vrx_theta_final_block(int n_part, int T, int upd
     __shared__ double sf[VRX_MAXT][9];   // psi(s1) psi(s2) psi(s12) lg(q1) lg(q2) lg(q12) lg(s1) lg(s2) lg(s12)
     if (threadIdx.x < T) {
         const int t = threadIdx.x;
-        double m = mu[t], s = sm[t];
+        double m = in_mu, s = in_sm;
         if (update) {
-            const double t1 = prior1[t] + tot[t];
-            const double t2 = prior2[t] + tot[VRX_MAXT + t];
+            const double t1 = in_p1 + tot[t];
+            const double t2 = in_p2 + tot[VRX_MAXT + t];
             m = t1 / (t1 + t2);
             if (!fix_sum) s = t1 + t2;
             mu[t] = m;
@@ -1148,9 +1225,9 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_final(int n_part, int T, 
                                                              double* kl_out,
                                                              const int32_t* __restrict__ ctl) {
     const int r = blockIdx.x;  // one block per restart of the batch
-    if (ctl[r * VRX_CTL_WORDS + VRX_CTL_STOP]) return;
+    const int stop = ctl[r * VRX_CTL_WORDS + VRX_CTL_STOP];
     vrx_theta_final_block(n_part, T, update, fix_sum, part + (int64_t)r * n_part * 2 * VRX_MAXT, prior1,
-                          prior2, mu + r * T, sm + r * T, psi + r * 3 * T, kl_out + r);
+                          prior2, mu + r * T, sm + r * T, psi + r * 3 * T, kl_out + r, stop);
 }
 
 // stage 1 (shared theta): per-block partial sums of S1*GT_t and S2*GT_t over all (n,k).
@@ -1161,7 +1238,7 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_partial(
     const double2* __restrict__ ranges, int64_t n_virtual, const double* __restrict__ GT,
     double* __restrict__ part, VrxBatch B, const int32_t* __restrict__ ctl) {
     const int rb = blockIdx.y;
-    if (ctl[rb * VRX_CTL_WORDS + VRX_CTL_STOP]) return;
+    const int stop = ctl[rb * VRX_CTL_WORDS + VRX_CTL_STOP];
     const int64_t NKt = NK * B.R;
     double acc[2 * VRX_MAXT];
 #pragma unroll
@@ -1170,15 +1247,28 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_partial(
     const int64_t stride = (int64_t)gridDim.x * VRX_BLOCK;
     const int64_t step_n = stride / B.K;
     const int step_k = (int)(stride - step_n * B.K);
-    int64_t n = ((int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x) / B.K;
-    int k = (int)(((int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x) - n * B.K);
-    for (int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x; i < NK;
-         i += stride, n += step_n, k += step_k) {
+    const int64_t i0 = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    int64_t n = i0 / B.K;
+    int k = (int)(i0 - n * B.K);
+    // the first element's operands travel together with the stop word (one round trip, not two)
+    const bool pre = npiece == nullptr && i0 < NK;
+    double2 s_pre = make_double2(0.0, 0.0);
+    double g_pre[VRX_MAXT];
+    if (pre) {
+        const int64_t j = B.R == 1 ? i0 : n * B.Kt + (int64_t)rb * B.K + k;
+        s_pre = S[j];
+#pragma unroll
+        for (int t = 0; t < VRX_MAXT; ++t)
+            if (t < T) g_pre[t] = GT[j * T + t];
+    }
+    if (stop) return;
+    for (int64_t i = i0; i < NK; i += stride, n += step_n, k += step_k) {
         if (k >= B.K) {
             k -= B.K;
             ++n;
         }
         const int64_t j = B.R == 1 ? i : n * B.Kt + (int64_t)rb * B.K + k;
+        const bool first = pre && i == i0;
         double2 s;
         if (npiece && n_virtual > 0) {
             // virtual rows (TiledStream::virt): planar partial sums [slot][2 n + kind][Kt], the AD
@@ -1221,18 +1311,18 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_partial(
             }
             S[j] = s;
         } else {
-            s = S[j];
+            s = first ? s_pre : S[j];
         }
         const double s1 = s.x, s2 = s.y - s.x;
 #pragma unroll
         for (int t = 0; t < VRX_MAXT; ++t)
             if (t < T) {
-                const double g = GT[j * T + t];
+                const double g = first ? g_pre[t] : GT[j * T + t];
                 acc[t] += s1 * g;
                 acc[VRX_MAXT + t] += s2 * g;
             }
     }
-    block_sum_store<2 * VRX_MAXT>(acc, part + ((int64_t)rb * gridDim.x + blockIdx.x) * 2 * VRX_MAXT);
+    block_sum_store<2 * VRX_MAXT>(acc, part + ((int64_t)rb * gridDim.x + blockIdx.x) * 2 * VRX_MAXT, VRX_MAXT, T);
 }
 
 // ASE mode: one theta row per variant (vireo_model.py:82,:177 axis=1).  Thread per variant.
@@ -1315,42 +1405,78 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_gt_update(
     VrxThetaFuse F, VrxBatch B, const int32_t* __restrict__ ctl) {
 #pragma clang fp contract(off)
     const int rb = blockIdx.y;
-    if (ctl[rb * VRX_CTL_WORDS + VRX_CTL_STOP]) return;
-    __shared__ double th_ms[2 * VRX_MAXT], th_psi[3 * VRX_MAXT], th_kl[1];
+    const int stop = ctl[rb * VRX_CTL_WORDS + VRX_CTL_STOP];
+    __shared__ double th_tot[2 * VRX_MAXT], th_ms[VRX_MAXT][2], th_psi[3 * VRX_MAXT], th_lg[VRX_MAXT][6];
     const double* psi_r = psi + (int64_t)rb * 3 * (ase ? N : 1) * T;
-    if (F.on) {
-        if ((int)threadIdx.x < T) {
-            th_ms[threadIdx.x] = F.mu[rb * T + threadIdx.x];
-            th_ms[VRX_MAXT + threadIdx.x] = F.sm[rb * T + threadIdx.x];
-        }
-        __syncthreads();
-        vrx_theta_final_block(F.n_part, T, 1, F.fix_sum, F.part + (int64_t)rb * F.n_part * 2 * VRX_MAXT,
-                              F.prior1, F.prior2, th_ms, th_ms + VRX_MAXT, th_psi, th_kl);
-        __syncthreads();
-        if (blockIdx.x == 0) {  // the one writer of the new state
-            if ((int)threadIdx.x < T) {
-                F.mu[rb * T + threadIdx.x] = th_ms[threadIdx.x];
-                F.sm[rb * T + threadIdx.x] = th_ms[VRX_MAXT + threadIdx.x];
-            }
-            if ((int)threadIdx.x < 3 * T) F.psi[rb * 3 * T + threadIdx.x] = th_psi[threadIdx.x];
-            if (threadIdx.x == 0) F.kl_out[rb] = th_kl[0];
-        }
-        psi_r = th_psi;
-    }
-    double kl[1] = {0.0};
     // (variant, donor) of this thread's elements without a 64-bit division per element: one at
     // the start, then steps of the grid stride
     const int64_t stride = (int64_t)gridDim.x * VRX_BLOCK;
     const int64_t step_n = stride / K;
     const int step_k = (int)(stride - step_n * K);
-    int64_t n = ((int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x) / K;
-    int k = (int)(((int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x) - n * K);
-    for (int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x; i < NK;
-         i += stride, n += step_n, k += step_k) {
+    const int64_t i0 = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    int64_t n = i0 / K;
+    int k = (int)(i0 - n * K);
+    // Everything the kernel reads first is requested before the stop word is tested (a small
+    // problem's kernel is a chain of ~1 us memory round trips: this makes them one): the
+    // first element's S, and for the fused theta finalisation the stage-1 partials and the
+    // current / prior Beta parameters.
+    const bool pre = learn && i0 < NK;
+    double2 s_pre = make_double2(0.0, 0.0);
+    if (pre) s_pre = S[n * B.Kt + (int64_t)rb * K + k];
+    double th_acc[2 * VRX_MAXT], th_in[4] = {0.0, 0.0, 0.0, 0.0};
+    if (F.on) {
+        const double* part = F.part + (int64_t)rb * F.n_part * 2 * VRX_MAXT;
+#pragma unroll
+        for (int t = 0; t < 2 * VRX_MAXT; ++t) th_acc[t] = 0.0;
+        for (int b = threadIdx.x; b < F.n_part; b += VRX_BLOCK)
+#pragma unroll
+            for (int t = 0; t < 2 * VRX_MAXT; ++t)
+                if (t % VRX_MAXT < T) th_acc[t] += part[(int64_t)b * 2 * VRX_MAXT + t];
+        if ((int)threadIdx.x < T) {
+            th_in[0] = F.mu[rb * T + threadIdx.x];
+            th_in[1] = F.sm[rb * T + threadIdx.x];
+            th_in[2] = F.prior1[threadIdx.x];
+            th_in[3] = F.prior2[threadIdx.x];
+        }
+    }
+    if (stop) return;
+    if (F.on) {
+        // vrx_theta_final_block's arithmetic, identical in every block (same sums in the same
+        // order); only block 0 needs KL_theta -- its log-gammas wait until after the element loop
+        block_sum_store<2 * VRX_MAXT>(th_acc, th_tot, VRX_MAXT, T);
+        __syncthreads();
+        if ((int)threadIdx.x < T) {
+            const int t = threadIdx.x;
+            const double t1 = th_in[2] + th_tot[t];
+            const double t2 = th_in[3] + th_tot[VRX_MAXT + t];
+            const double mn = t1 / (t1 + t2);
+            const double sn = F.fix_sum ? th_in[1] : t1 + t2;
+            th_ms[t][0] = mn;
+            th_ms[t][1] = sn;
+            if (blockIdx.x == 0) {  // the one writer of the new state
+                F.mu[rb * T + t] = mn;
+                F.sm[rb * T + t] = sn;
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < 3 * T) {
+            const int t = threadIdx.x / 3, jj = threadIdx.x % 3;
+            const double mn = th_ms[t][0], sn = th_ms[t][1];
+            const double s1 = mn * sn, s2 = (1.0 - mn) * sn;
+            const double d = vrx_digamma(jj == 0 ? s1 : jj == 1 ? s2 : s1 + s2);
+            th_psi[jj * T + t] = d;
+            if (blockIdx.x == 0) F.psi[rb * 3 * T + jj * T + t] = d;
+        }
+        __syncthreads();
+        psi_r = th_psi;
+    }
+    double kl[1] = {0.0};
+    for (int64_t i = i0; i < NK; i += stride, n += step_n, k += step_k) {
         if (k >= K) {
             k -= K;
             ++n;
         }
+        const bool first = pre && i == i0;
         const int64_t j = n * B.Kt + (int64_t)rb * K + k;  // this restart's column of S / GT / W
         const int64_t rows = ase ? N : 1, pr = ase ? n : 0;
         const double* pb = psi_r;
@@ -1364,7 +1490,7 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_gt_update(
                 lq[t] = gt_mode == 0 ? logq_uni
                                      : (gt_mode == 1 ? logq[k * T + t] : logq[i * T + t]);
         if (learn) {
-            const double2 s = S[j];
+            const double2 s = first ? s_pre : S[j];
             const double s1 = s.x, ss = s.y, s2 = ss - s1;
             double L[VRX_MAXT];
             double mx = -__builtin_inf();
@@ -1408,7 +1534,30 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_gt_update(
             }
         vrx_store_w(W, wform, n, rb * K + k, B.Kt, w1, w2, wa);
     }
-    block_sum_store<1>(kl, kl_part + (int64_t)rb * gridDim.x + blockIdx.x);
+    if (F.on && blockIdx.x == 0) {  // KL_theta: 6 log-gammas per class on wave 1, combined below
+        const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+        if (wv == 1 && ln < 6 * T) {
+            const int t = ln / 6, jj = ln % 6;
+            const double mn = th_ms[t][0], sn = th_ms[t][1];
+            const double s1 = mn * sn, s2 = (1.0 - mn) * sn, q1 = F.prior1[t], q2 = F.prior2[t];
+            th_lg[t][jj] = lgamma(jj == 0 ? q1 : jj == 1 ? q2 : jj == 2 ? q1 + q2 : jj == 3 ? s1 : jj == 4 ? s2 : s1 + s2);
+        }
+    }
+    block_sum_store<1>(kl, kl_part + (int64_t)rb * gridDim.x + blockIdx.x);  // (synchronises the block)
+    if (F.on && blockIdx.x == 0 && threadIdx.x == 0) {
+        double klt = 0.0;  // same order as vrx_theta_final_block
+        for (int t = 0; t < T; ++t) {
+            const double mn = th_ms[t][0], sn = th_ms[t][1];
+            const double s1 = mn * sn, s2 = (1.0 - mn) * sn, q1 = F.prior1[t], q2 = F.prior2[t];
+            const double d1 = th_psi[t], d2 = th_psi[T + t], ds = th_psi[2 * T + t];
+            const double cq = (th_lg[t][0] + th_lg[t][1] - th_lg[t][2]) - (q1 - 1.0) * d1 -
+                              (q2 - 1.0) * d2 + ((q1 + q2) - 2.0) * ds;
+            const double cp = (th_lg[t][3] + th_lg[t][4] - th_lg[t][5]) - (s1 - 1.0) * d1 -
+                              (s2 - 1.0) * d2 + ((s1 + s2) - 2.0) * ds;
+            klt += cq - cp;
+        }
+        F.kl_out[rb] = klt;
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1520,6 +1669,8 @@ struct VrxElboIn {  // by value; per restart r: partial arrays r * n_*_part on, 
     int64_t trace_stride;
 };
 
+// All first loads -- the stop word, the previous ELBO, and the first sweep of each partial array --
+// are requested together: the block is otherwise five dependent memory round trips long.
 __device__ __forceinline__ void vrx_elbo_final_block(const double* cell_part, int n_cell_part,
                                                      const double* gt_part, int n_gt_part,
                                                      const double* th_part, int n_th_part,
@@ -1527,10 +1678,30 @@ __device__ __forceinline__ void vrx_elbo_final_block(const double* cell_part, in
                                                      const VrxStopRule& rule, int32_t* ctl) {
     __shared__ double tot[4];
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const int stop = ctl[VRX_CTL_STOP];
+    const bool judge = rule.active && rule.it > rule.min_iter;
+    double prev = 0.0;
+    if (threadIdx.x == 0 && judge) prev = elbo_out[rule.it - 1];
     // the loads of 8 strides are issued together (one memory round trip instead of 8), the
     // additions keep the order of the plain strided loop
     constexpr int UN = 8;
-    for (int b0 = threadIdx.x; b0 < n_cell_part; b0 += UN * VRX_BLOCK) {
+    const int tid = threadIdx.x;
+    double2 vc[UN];
+    double vg[UN], vt[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+        const int b = tid + u * VRX_BLOCK;
+        vc[u] = b < n_cell_part ? reinterpret_cast<const double2*>(cell_part)[b] : make_double2(0.0, 0.0);
+        vg[u] = b < n_gt_part ? gt_part[b] : 0.0;
+        vt[u] = b < n_th_part ? th_part[b] : 0.0;
+    }
+    if (stop) return;
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+        acc[0] += vc[u].x;
+        acc[1] += vc[u].y;
+    }
+    for (int b0 = tid + UN * VRX_BLOCK; b0 < n_cell_part; b0 += UN * VRX_BLOCK) {
         double2 v[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
@@ -1544,8 +1715,10 @@ __device__ __forceinline__ void vrx_elbo_final_block(const double* cell_part, in
             acc[1] += v[u].y;
         }
     }
-    auto strided = [&](const double* p, int n, double& a) {
-        for (int b0 = threadIdx.x; b0 < n; b0 += UN * VRX_BLOCK) {
+    auto strided = [&](const double* p, int n, const double (&v0)[UN], double& a) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) a += v0[u];
+        for (int b0 = tid + UN * VRX_BLOCK; b0 < n; b0 += UN * VRX_BLOCK) {
             double v[UN];
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
@@ -1556,8 +1729,8 @@ __device__ __forceinline__ void vrx_elbo_final_block(const double* cell_part, in
             for (int u = 0; u < UN; ++u) a += v[u];
         }
     };
-    strided(gt_part, n_gt_part, acc[2]);
-    strided(th_part, n_th_part, acc[3]);
+    strided(gt_part, n_gt_part, vg, acc[2]);
+    strided(th_part, n_th_part, vt, acc[3]);
     block_sum_store<4>(acc, tot);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1566,8 +1739,7 @@ __device__ __forceinline__ void vrx_elbo_final_block(const double* cell_part, in
 #pragma unroll
         for (int i = 0; i < 4; ++i) parts_out[i] = tot[i];
         // the stop rule of _fit_VB / _fit_BV (vireo_model.py:266-274, bmm_model.py:190-199)
-        if (rule.active && rule.it > rule.min_iter) {
-            const double prev = elbo_out[rule.it - 1];
+        if (judge) {
             if (cur < prev - 1e-6) {
                 ctl[VRX_CTL_WARN] |= 1;
             } else if (rule.it == rule.max_iter - 1) {
@@ -1583,12 +1755,10 @@ __device__ __forceinline__ void vrx_elbo_final_block(const double* cell_part, in
 
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_elbo_final(VrxElboIn e, VrxStopRule rule, int32_t* ctl) {
     const int r = blockIdx.x;  // one block per restart of the batch
-    ctl += r * VRX_CTL_WORDS;
-    if (ctl[VRX_CTL_STOP]) return;
     vrx_elbo_final_block(e.cell_part + (int64_t)r * e.n_cell_part * 2, e.n_cell_part,
                          e.gt_part + (int64_t)r * e.n_gt_part, e.n_gt_part,
                          e.th_part + (int64_t)r * e.n_th_part, e.n_th_part,
-                         e.elbo + r * e.trace_stride, e.parts + r * 4, rule, ctl);
+                         e.elbo + r * e.trace_stride, e.parts + r * 4, rule, ctl + r * VRX_CTL_WORDS);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1608,13 +1778,17 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_cell_softmax(
     const double* __restrict__ logq, int id_mode, double logq_uni, double* __restrict__ ID,
     double* __restrict__ part, VrxBatch B, const int32_t* __restrict__ ctl) {
     const int rb = blockIdx.y;
-    if (ctl[rb * VRX_CTL_WORDS + VRX_CTL_STOP]) return;
+    const int stop = ctl[rb * VRX_CTL_WORDS + VRX_CTL_STOP];
     const int64_t cell = ((int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x) / KP;
     const int kl = threadIdx.x % KP;
     double acc[2] = {0.0, 0.0};
     const bool live = cell < M;
     const int64_t row0 = (live ? cell : 0) * (int64_t)B.Kt + (int64_t)rb * K;  // this restart's K columns
     double* Lr = LID + row0;
+    // (the lane's first column travels together with the stop word: one round trip, not two)
+    const bool pre = live && npiece == nullptr && kl < K;
+    const double L_pre = pre ? Lr[kl] : 0.0;
+    if (stop) return;
     const int n_range = live && npiece ? npiece[cell] : 0;
     if (n_range > 0)
         for (int k = kl; k < K; k += KP) {
@@ -1636,19 +1810,19 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_cell_softmax(
     const double* qr = id_mode == 2 ? logq + (live ? cell : 0) * (int64_t)K : logq;
     double mx = -__builtin_inf();
     if (live)
-        for (int k = kl; k < K; k += KP) mx = fmax(mx, Lr[k] + (id_mode ? qr[k] : logq_uni));
+        for (int k = kl; k < K; k += KP) mx = fmax(mx, (pre && k == kl ? L_pre : Lr[k]) + (id_mode ? qr[k] : logq_uni));
 #pragma unroll
     for (int s = 1; s < KP; s <<= 1) mx = fmax(mx, __shfl_xor(mx, s, 64));
     double sum = 0.0;
     if (live && update)
-        for (int k = kl; k < K; k += KP) sum += exp(Lr[k] + (id_mode ? qr[k] : logq_uni) - mx);
+        for (int k = kl; k < K; k += KP) sum += exp((pre && k == kl ? L_pre : Lr[k]) + (id_mode ? qr[k] : logq_uni) - mx);
 #pragma unroll
     for (int s = 1; s < KP; s <<= 1) sum += __shfl_xor(sum, s, 64);
     if (live) {
         const double lsum = update ? log(sum) : 0.0;
         double* Ir = ID + row0;
         for (int k = kl; k < K; k += KP) {
-            const double L = Lr[k];
+            const double L = pre && k == kl ? L_pre : Lr[k];
             const double lq = id_mode ? qr[k] : logq_uni;
             double p, lp;
             if (update) {
