@@ -2052,7 +2052,8 @@ static int theta_step(vrx_model* m, int update, bool defer_final = false) {
                 if (rc) return rc;
             }
             const uint16_t* np = m->s_pending ? tv.npiece.p : nullptr;
-            vrx_theta_partial<<<dim3(m->nb_theta, m->R), VRX_BLOCK, 0, s>>>(
+            auto* kern = m->T == 3 ? vrx_theta_partial<3> : vrx_theta_partial<VRX_MAXT>;
+            kern<<<dim3(m->nb_theta, m->R), VRX_BLOCK, 0, s>>>(
                 m->NK, m->T, reinterpret_cast<double2*>(m->S.p), np,
                 reinterpret_cast<const double2*>(m->RV.p), m->s_pending && tv.virt ? tv.n_vrows : 0,
                 m->GT.p, m->part_theta.p, m->batch(), m->ctl.p);
@@ -2097,7 +2098,8 @@ static int gt_step(vrx_model* m, int learn) {
         F.kl_out = m->part_th.p;
         m->theta_pending = false;
     }
-    vrx_gt_update<<<dim3(m->nb_gt, m->R), VRX_BLOCK, 0, m->p->stream>>>(
+    auto* kern = m->T == 3 ? vrx_gt_update<3> : vrx_gt_update<VRX_MAXT>;
+    kern<<<dim3(m->nb_gt, m->R), VRX_BLOCK, 0, m->p->stream>>>(
         m->NK, m->K, m->T, learn, m->cfg.ase_mode, m->N, reinterpret_cast<const double2*>(m->S.p),
         m->psi.p, m->logq_gt.p, m->gt_mode, -std::log((double)m->T), m->GT.p, m->W.p, m->wform,
         m->part_gt.p, F, m->batch(), m->ctl.p);

@@ -1233,11 +1233,13 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_final(int n_part, int T, 
 // stage 1 (shared theta): per-block partial sums of S1*GT_t and S2*GT_t over all (n,k).
 // npiece != null: S has not been formed yet -- it is the in-order sum of the partial arrays the
 // LDS-resident variant pass left in `ranges` (npiece[variant] of them; fused here to save a launch).
+template <int TT>  // genotype classes: 3 exactly (no per-class branches), or VRX_MAXT = any T
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_partial(
     int64_t NK, int T, double2* S, const uint16_t* __restrict__ npiece,
     const double2* __restrict__ ranges, int64_t n_virtual, const double* __restrict__ GT,
     double* __restrict__ part, VrxBatch B, const int32_t* __restrict__ ctl) {
     const int rb = blockIdx.y;
+    const int Tn = TT == VRX_MAXT ? T : TT;
     const int stop = ctl[rb * VRX_CTL_WORDS + VRX_CTL_STOP];
     const int64_t NKt = NK * B.R;
     double acc[2 * VRX_MAXT];
@@ -1258,8 +1260,8 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_partial(
         const int64_t j = B.R == 1 ? i0 : n * B.Kt + (int64_t)rb * B.K + k;
         s_pre = S[j];
 #pragma unroll
-        for (int t = 0; t < VRX_MAXT; ++t)
-            if (t < T) g_pre[t] = GT[j * T + t];
+        for (int t = 0; t < TT; ++t)
+            if (t < Tn) g_pre[t] = GT[j * T + t];
     }
     if (stop) return;
     for (int64_t i = i0; i < NK; i += stride, n += step_n, k += step_k) {
@@ -1315,8 +1317,8 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_partial(
         }
         const double s1 = s.x, s2 = s.y - s.x;
 #pragma unroll
-        for (int t = 0; t < VRX_MAXT; ++t)
-            if (t < T) {
+        for (int t = 0; t < TT; ++t)
+            if (t < Tn) {
                 const double g = first ? g_pre[t] : GT[j * T + t];
                 acc[t] += s1 * g;
                 acc[VRX_MAXT + t] += s2 * g;
@@ -1398,6 +1400,7 @@ struct VrxThetaFuse {  // by value
 };
 
 // Grid-stride over the (variant, donor) pairs: gridDim.x blocks, gridDim.x KL partials.
+template <int TT>  // genotype classes: 3 exactly (no per-class branches), or VRX_MAXT = any T
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_gt_update(
     int64_t NK, int K, int T, int learn, int ase, int64_t N, const double2* __restrict__ S,
     const double* psi, const double* __restrict__ logq, int gt_mode, double logq_uni,
@@ -1405,6 +1408,7 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_gt_update(
     VrxThetaFuse F, VrxBatch B, const int32_t* __restrict__ ctl) {
 #pragma clang fp contract(off)
     const int rb = blockIdx.y;
+    const int Tn = TT == VRX_MAXT ? T : TT;
     const int stop = ctl[rb * VRX_CTL_WORDS + VRX_CTL_STOP];
     __shared__ double th_tot[2 * VRX_MAXT], th_ms[VRX_MAXT][2], th_psi[3 * VRX_MAXT], th_lg[VRX_MAXT][6];
     const double* psi_r = psi + (int64_t)rb * 3 * (ase ? N : 1) * T;
@@ -1485,8 +1489,8 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_gt_update(
         const double* ps = pb + (2 * rows + pr) * T;
         double g[VRX_MAXT], lq[VRX_MAXT];
 #pragma unroll
-        for (int t = 0; t < VRX_MAXT; ++t)
-            if (t < T)
+        for (int t = 0; t < TT; ++t)
+            if (t < Tn)
                 lq[t] = gt_mode == 0 ? logq_uni
                                      : (gt_mode == 1 ? logq[k * T + t] : logq[i * T + t]);
         if (learn) {
@@ -1495,39 +1499,39 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_gt_update(
             double L[VRX_MAXT];
             double mx = -__builtin_inf();
 #pragma unroll
-            for (int t = 0; t < VRX_MAXT; ++t)
-                if (t < T) {
+            for (int t = 0; t < TT; ++t)
+                if (t < Tn) {
                     L[t] = (s1 * p1[t] + s2 * p2[t] - ss * ps[t]) + lq[t];
                     mx = fmax(mx, L[t]);
                 }
             double sum = 0.0;
 #pragma unroll
-            for (int t = 0; t < VRX_MAXT; ++t)
-                if (t < T) {
+            for (int t = 0; t < TT; ++t)
+                if (t < Tn) {
                     L[t] -= mx;
                     g[t] = exp(L[t]);
                     sum += g[t];
                 }
             const double lsum = log(sum);
 #pragma unroll
-            for (int t = 0; t < VRX_MAXT; ++t)
-                if (t < T) {
+            for (int t = 0; t < TT; ++t)
+                if (t < Tn) {
                     g[t] = g[t] / sum;
                     GT[j * T + t] = g[t];
                     if (g[t] > 0.0) kl[0] += g[t] * ((L[t] - lsum) - lq[t]);
                 }
         } else {
 #pragma unroll
-            for (int t = 0; t < VRX_MAXT; ++t)
-                if (t < T) {
+            for (int t = 0; t < TT; ++t)
+                if (t < Tn) {
                     g[t] = GT[j * T + t];
                     if (g[t] > 0.0) kl[0] += g[t] * (log(g[t]) - lq[t]);
                 }
         }
         double w1 = 0.0, w2 = 0.0, wa = 0.0;
 #pragma unroll
-        for (int t = 0; t < VRX_MAXT; ++t)
-            if (t < T) {
+        for (int t = 0; t < TT; ++t)
+            if (t < Tn) {
                 w1 += g[t] * (p1[t] - p2[t]);
                 w2 += g[t] * (p2[t] - ps[t]);
                 wa += g[t] * (p1[t] - ps[t]);
