@@ -7,7 +7,8 @@ section) over `python bench.py --no-cpu --no-c4 --steps 3 --warmup 1`.  Units: b
 KiB.  gfx950 correction from the guide: FETCH_SIZE reports exactly half of the bytes of wide
 (16 B / lane) coalesced streaming reads -- every read of both passes -- so it is doubled;
 WRITE_SIZE is taken as is.  The record carries the hash of the kernel sources it was measured on;
-bench.py quotes it only when that hash matches its own build."""
+bench.py quotes it only when that hash matches its own build.  Keys: vrx_spmm_lds<0> = the variant
+pass, vrx_spmm_lds<1> = the cell pass."""
 import collections
 import csv
 import glob
@@ -34,11 +35,20 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out,
                     "-o", config, "--"] + cmd, cwd=ROOT if config == "c5" else "/tmp", env=env, check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    # The two passes may be the SAME instantiation (the variant pass over virtual rows runs the cell
+    # pass's kernel), so they are told apart by dispatch order: every iteration launches the
+    # variant pass, then the cell pass (checked against the MODE template argument where it differs).
+    rows = []
     for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             m = re.match(r"void vrx_spmm_lds<\d+, (\d)", r["Kernel_Name"])
             if m and r["Counter_Name"] == counter:
-                vals["vrx_spmm_lds<%s>" % m.group(1)][counter].append(float(r["Counter_Value"]))
+                rows.append((int(r["Dispatch_Id"]), int(m.group(1)), float(r["Counter_Value"])))
+    rows.sort()
+    for i, (_, mode, v) in enumerate(rows):
+        which = "cell" if i % 2 else "variant"
+        assert mode == 1 or which == "variant", "dispatch order is not variant, cell, variant, ..."
+        vals["vrx_spmm_lds<%d>" % (which == "cell")][counter].append(v)
 kernels = {}
 for k, c in vals.items():
     fetch = sum(c["FETCH_SIZE"]) / max(len(c["FETCH_SIZE"]), 1)

@@ -87,3 +87,26 @@ def test_random_case_vs_oracle(va, monkeypatch, seed):
     close(dev.GT_prob, ref.GT_prob)
     close(dev.beta_mu, ref.beta_mu)
     close(dev.beta_sum, ref.beta_sum)
+
+
+@pytest.mark.parametrize("T,lds", [(2, "0"), (2, "1"), (4, "0"), (5, "1")])
+def test_other_genotype_class_counts(va, monkeypatch, T, lds):
+    """n_GT != 3 runs the dense kernels' general instantiation (the T = 3 one has no per-class
+    branches): same comparison as the sweep above"""
+    from vireo_amd.counts import DeviceCounts
+    AD, DP, K, rng = draw_case(100 + T)
+    N, M = AD.shape
+    monkeypatch.setenv("VIREO_LDS", lds)
+    counts = DeviceCounts(AD, DP)
+    np.random.seed(T)
+    ref = O.vireo_new(M, N, K, n_GT=T)
+    np.random.seed(T)
+    dev = va.Vireo(n_cell=M, n_var=N, n_donor=K, n_GT=T)
+    O.vireo_fit(ref, AD, DP, min_iter=2, max_iter=6, delay_fit_theta=1)
+    dev.fit(counts, None, min_iter=2, max_iter=6, delay_fit_theta=1, verbose=False)
+    assert len(dev.ELBO_) == len(ref.ELBO_)
+    close(dev.ELBO_, ref.ELBO_)
+    close(dev.ID_prob, ref.ID_prob)
+    close(dev.GT_prob, ref.GT_prob)
+    close(dev.beta_mu, ref.beta_mu)
+    close(dev.beta_sum, ref.beta_sum)
