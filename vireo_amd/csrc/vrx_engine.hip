@@ -1450,8 +1450,10 @@ extern "C" int vrx_model_create(vrx_problem* p, const vrx_model_cfg* cfg, vrx_mo
     } else {
         m->n_th_part = m->nb_nk;
     }
-    VRX_HIP(m->part_th.alloc((size_t)m->R * m->n_th_part));
-    VRX_HIP(hipMemsetAsync(m->part_th.p, 0, (size_t)m->R * m->n_th_part * sizeof(double), s));
+    // (clone mode with the range sum fused into vrx_bmm_theta runs 16 lanes per element: 16x the blocks)
+    const size_t th_cap = (size_t)m->R * (cfg->kind == VRX_KIND_VIREO ? m->n_th_part : (m->NK * 16 + VRX_BLOCK - 1) / VRX_BLOCK + 1);
+    VRX_HIP(m->part_th.alloc(th_cap));
+    VRX_HIP(hipMemsetAsync(m->part_th.p, 0, th_cap * sizeof(double), s));
     VRX_HIP(m->d_elbo.alloc((size_t)m->R * kMaxTrace));
     VRX_HIP(m->ctl.alloc((size_t)m->R * VRX_CTL_WORDS));
     VRX_HIP(hipMemsetAsync(m->ctl.p, 0, (size_t)m->R * VRX_CTL_WORDS * sizeof(int32_t), s));
@@ -2028,15 +2030,22 @@ static int theta_step(vrx_model* m, int update, bool defer_final = false) {
     ProfScope ps(m, VRX_KERN_DENSE);
     hipStream_t s = m->p->stream;
     const auto& c = m->cfg;
-    if (c.kind == VRX_KIND_BMM || c.ase_mode) {
-        int rc = resolve_S(m);  // only the shared-theta kernel fuses the range sum
+    const TiledStream& tvar = m->p->by_var.tiled;
+    const bool bmm_fuse = c.kind == VRX_KIND_BMM && update && m->s_pending && !tvar.virt && !tvar.split;
+    if ((c.kind == VRX_KIND_BMM || c.ase_mode) && !bmm_fuse) {
+        int rc = resolve_S(m);  // (the ASE kernel does not fuse the range sum)
         if (rc) return rc;
     }
     if (c.kind == VRX_KIND_BMM) {
-        vrx_bmm_theta<<<dim3(m->nb_nk, m->R), VRX_BLOCK, 0, s>>>(
-            m->NK, update, c.fix_beta_sum, reinterpret_cast<const double2*>(m->S.p), m->prior1.p,
+        // (fused range sum: 16 lanes per element; the KL partials are zero-filled past nb_nk blocks' worth)
+        const unsigned nb = bmm_fuse ? (unsigned)((m->NK * 16 + VRX_BLOCK - 1) / VRX_BLOCK) : (unsigned)m->nb_nk;
+        m->n_th_part = (int)nb;
+        vrx_bmm_theta<<<dim3(nb, m->R), VRX_BLOCK, 0, s>>>(
+            m->NK, update, c.fix_beta_sum, reinterpret_cast<double2*>(m->S.p),
+            bmm_fuse ? tvar.npiece.p : nullptr, reinterpret_cast<const double2*>(m->RV.p), m->prior1.p,
             m->prior2.p, m->prior_rows == 1 ? 0 : 1, m->mu.p, m->sm.p, m->W.p, m->K, m->wform,
             m->part_th.p, m->batch(), m->ctl.p);
+        if (bmm_fuse) m->s_pending = false;
         m->w_valid = true;
     } else if (c.ase_mode) {
         vrx_theta_ase<<<dim3(m->nb_throws, m->R), VRX_BLOCK, 0, s>>>(

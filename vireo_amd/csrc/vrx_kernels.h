@@ -337,13 +337,14 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_spmm(
         double mx = x0;
 #pragma unroll
         for (int s = 1; s < LPE; s <<= 1) mx = fmax(mx, __shfl_xor(mx, s, 64));
-        double sum = own ? exp(x0 - mx) : 0.0;
+        const double e0 = own ? exp(x0 - mx) : 0.0;
+        double sum = e0;
 #pragma unroll
         for (int s = 1; s < LPE; s <<= 1) sum += __shfl_xor(sum, s, 64);
         double acc[2] = {0.0, 0.0};
         if (own) {
             const double x = x0 - mx;
-            const double p = exp(x) / sum;
+            const double p = e0 / sum;
             const double lp = x - log(sum);
             F.ID[(int64_t)d * K + k] = p;
             acc[0] = L * p;
@@ -1627,8 +1628,13 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_doublet_w(
 // get_E_logLik (:118-130) and the KL_theta partial of get_ELBO (:166-172).
 // Thread per (variant, clone).  update == 0: derive W / KL from the current beta only.
 // ------------------------------------------------------------------------------------
+// npiece != null: S has not been formed yet -- it is the in-order sum of the npiece[variant]
+// partial arrays the LDS-resident variant pass left in `ranges` (as in vrx_theta_partial; clone
+// mode has few variants and long rows: c5 cuts its one tile into 196 pieces).
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_bmm_theta(int64_t NK, int update, int fix_sum,
-                                                           const double2* __restrict__ S,
+                                                           double2* __restrict__ S,
+                                                           const uint16_t* __restrict__ npiece,
+                                                           const double2* __restrict__ ranges,
                                                            const double* __restrict__ prior1,
                                                            const double* __restrict__ prior2,
                                                            int prior_full, double* mu, double* sm,
@@ -1640,13 +1646,45 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_bmm_theta(int64_t NK, int updat
     if (ctl[rb * VRX_CTL_WORDS + VRX_CTL_STOP]) return;
     mu += (int64_t)rb * NK;
     sm += (int64_t)rb * NK;
-    const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    // npiece: LP = 16 lanes per element, lane `sub` adds the pieces sub, sub + 16, ... (all its
+    // loads in flight at once), then a fixed butterfly over the 16 lanes: a chain of 196 pieces
+    // is 13 loads deep instead of 196
+    const int LP = npiece ? 16 : 1;
+    const int64_t gt = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    const int64_t i = gt / LP;
+    const int sub = (int)(gt - i * LP);
     double kl[1] = {0.0};
-    if (i < NK) {
+    const bool live = i < NK;
+    double2 a = make_double2(0.0, 0.0);
+    if (update && npiece) {  // (whole 16-lane groups take this branch together)
+        const int64_t ic = live ? i : 0;
+        const int64_t j = vrx_col(B, ic, rb);
+        const int n_range = live ? npiece[ic / K] : 0;
+        const int64_t NKt = NK * B.R;
+        for (int r0 = sub; r0 < n_range; r0 += 16 * 16) {
+            double2 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                v[u] = r0 + u * 16 < n_range ? ranges[(int64_t)(r0 + u * 16) * NKt + j] : make_double2(0.0, 0.0);
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (r0 + u * 16 < n_range) {
+                    a.x += v[u].x;
+                    a.y += v[u].y;
+                }
+        }
+#pragma unroll
+        for (int sft = 1; sft < 16; sft <<= 1) {
+            a.x += __shfl_xor(a.x, sft, 64);
+            a.y += __shfl_xor(a.y, sft, 64);
+        }
+        if (live && sub == 0) S[j] = a;
+    }
+    if (live && sub == 0) {
         const double q1 = prior1[prior_full ? i : 0], q2 = prior2[prior_full ? i : 0];
         double m = mu[i], s = sm[i];
         if (update) {
-            const double2 a = S[vrx_col(B, i, rb)];
+            if (!npiece) a = S[vrx_col(B, i, rb)];
             const double t1 = a.x + q1;
             const double t2 = (a.y - a.x) + q2;
             m = t1 / (t1 + t2);
@@ -1817,9 +1855,13 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_cell_softmax(
         for (int k = kl; k < K; k += KP) mx = fmax(mx, (pre && k == kl ? L_pre : Lr[k]) + (id_mode ? qr[k] : logq_uni));
 #pragma unroll
     for (int s = 1; s < KP; s <<= 1) mx = fmax(mx, __shfl_xor(mx, s, 64));
-    double sum = 0.0;
+    double sum = 0.0, e_first = 0.0;  // (the lane's first exponential is reused below: same argument)
     if (live && update)
-        for (int k = kl; k < K; k += KP) sum += exp((pre && k == kl ? L_pre : Lr[k]) + (id_mode ? qr[k] : logq_uni) - mx);
+        for (int k = kl; k < K; k += KP) {
+            const double e = exp((pre && k == kl ? L_pre : Lr[k]) + (id_mode ? qr[k] : logq_uni) - mx);
+            if (k == kl) e_first = e;
+            sum += e;
+        }
 #pragma unroll
     for (int s = 1; s < KP; s <<= 1) sum += __shfl_xor(sum, s, 64);
     if (live) {
@@ -1831,7 +1873,7 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_cell_softmax(
             double p, lp;
             if (update) {
                 const double x = (L + lq) - mx;
-                p = exp(x) / sum;
+                p = (k == kl ? e_first : exp(x)) / sum;
                 lp = x - lsum;
                 Ir[k] = p;
             } else {
