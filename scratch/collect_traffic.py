@@ -37,7 +37,7 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     # The two passes may be the SAME instantiation (the variant pass over virtual rows runs the cell
     # pass's kernel), so they are told apart by dispatch order: every iteration launches the
-    # variant pass, then the cell pass (checked against the MODE template argument where it differs).
+    # variant pass, then the cell pass (where the MODE template argument differs, it decides).
     rows = []
     for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
@@ -45,9 +45,9 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             if m and r["Counter_Name"] == counter:
                 rows.append((int(r["Dispatch_Id"]), int(m.group(1)), float(r["Counter_Value"])))
     rows.sort()
+    by_mode = any(mode == 0 for _, mode, _ in rows)  # (two instantiations: the name tells)
     for i, (_, mode, v) in enumerate(rows):
-        which = "cell" if i % 2 else "variant"
-        assert mode == 1 or which == "variant", "dispatch order is not variant, cell, variant, ..."
+        which = ("cell" if mode else "variant") if by_mode else ("cell" if i % 2 else "variant")
         vals["vrx_spmm_lds<%d>" % (which == "cell")][counter].append(v)
 kernels = {}
 for k, c in vals.items():
