@@ -1,15 +1,17 @@
 #!/usr/bin/env python
 """bench.py -- EM iterations/sec of the Vireo VB hot path on MI355X (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K=100] [--warmup W=50] [--config c3|mid|c2] [--no-cpu] [--no-c4]
+  python bench.py [--gpus N] [--steps K=200] [--warmup W=600] [--config c3|mid|c2] [--no-cpu] [--no-c4]
 
 A step is ONE full coordinate-ascent iteration (theta update, GT update, ID update, ELBO:
 vireoSNP/utils/vireo_model.py:257-264) over the synthetic AD/DP of SURVEY.md 8(d), inputs
 and state already resident in HBM.  Default workload = BASELINE.json configs[2]
 (N=100k variants x M=50k cells, K=16, ~2 % nnz), the configuration the metric is quoted on.
-W warm-up iterations run without the theta update (the protocol's delay_fit_theta=3), the K
-timed ones with it.  (The defaults time 100 iterations after 50: from an idle GPU the first
-~30 ms run ~3 % slower -- clocks -- which a 3-iteration warm-up left inside the timed region;
+The W warm-up iterations are the protocol's start (delay_fit_theta=3: the first three without the
+theta update, so every kernel of the timed iterations has been launched once), the K timed ones
+all run with it.  (The defaults time 200 iterations after 600: the GPU sits idle through the
+~20 s of host-side input generation and its clocks take ~0.4 s of work to come back -- after
+50 warm-up iterations the timed run was still 3.5 % slower than its own four repeats;
 `ms_per_step_repeats` shows the spread.)  N > 1 (launched by torch.distributed.run, one rank per GPU): every
 rank holds the problem and iterates its own restart (vireo_wrap's restart shard, weak
 scaling); the per-restart ELBOs are all-gathered over RCCL.  Rank 0 prints ONE JSON line.
@@ -207,8 +209,8 @@ def c5_leg(device, steps=50):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=600)
     ap.add_argument("--config", default="c3")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity leg")
     ap.add_argument("--no-c4", action="store_true", help="skip the n_init=32 restart-shard leg")
@@ -265,7 +267,7 @@ def main():
     dm.set_prior(host.ID_prior, host.GT_prior, host.theta_s1_prior, host.theta_s2_prior)
 
     if args.warmup > 0:
-        dm.run_iters(args.warmup, theta_from_iter=10 ** 9)
+        dm.run_iters(args.warmup, theta_from_iter=PROTOCOL["delay_fit_theta"])
     comm.barrier()
     t0 = time.perf_counter()
     trace, ms_dev = dm.run_iters(args.steps, theta_from_iter=0)   # syncs the stream
