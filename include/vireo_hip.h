@@ -211,12 +211,14 @@ int vrx_problem_cell_loglik(vrx_problem* p, int64_t n_col, int64_t n_class,
 /* which kernels this model's passes run: info[0]/[1] = 1 if the variant/cell pass is
  * LDS-resident (vrx_spmm_lds) else 0 (vrx_spmm, global gathers); info[2]/[3] = entry format
  * of the variant/cell orientation (0: 4 B, 1: 8 B, 2: 12 B per non-zero); info[4]/[5] =
- * L2 tiles of the variant/cell orientation; info[6]/[7] = contracted ranges of the
- * LDS-resident variant/cell pass; info[8]/[9] = its stream words (padding included) per 1000
- * non-zeros; info[10]/[11] = extra row pieces (long rows are cut into interleaved pieces);
- * info[12] = form of the LDS-resident cell stream (0: (ad, dp) pairs, 1: single-valued AD / BD
- * entries); info[13] = form of the variant stream (0: pairs, 2: AD entries then BD entries per
- * round); info[14] = restarts in the model (n_batch); info[15] reserved (0).  The forms follow
+ * L2 tiles of the variant/cell orientation; info[6]/[7] = partial arrays of the LDS-resident
+ * variant/cell pass (the most pieces its work list cuts a tile into); info[8]/[9] = its stream
+ * words (padding included) per 1000 non-zeros; info[10]/[11] = extra row pieces (long rows are
+ * cut into interleaved pieces); info[12] = form of the LDS-resident cell stream (0: (ad, dp)
+ * pairs, 1: single-valued AD / BD entries); info[13] = form of the variant stream (0: pairs,
+ * 2: AD entries then BD entries per round, 3: AD / BD entries as 2N single-accumulator virtual
+ * rows -- the cell pass's kernel); info[14] = restarts in the model (n_batch); info[15]
+ * reserved (0).  The forms follow
  * the depth of the data: AD/BD words unless a count needs so many of them (> 1.56 words per
  * entry, estimated at vrx_problem_create) that one pair word per entry is cheaper. */
 int vrx_model_info(vrx_model* m, int32_t* info16);

@@ -966,6 +966,9 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
             o->tiled.bnd.release();
             o->tiled.rowmap.release();
             o->tiled.vptr.release();
+            o->tiled.items.release();
+            o->tiled.wg_first.release();
+            o->tiled.npiece.release();
             o->tiled.ready = false;
         }
         return VRX_OK;
