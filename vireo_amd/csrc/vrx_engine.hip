@@ -455,6 +455,29 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
         for (int32_t v = vptr[(size_t)r]; v < vptr[(size_t)r + 1]; ++v) vrow_row[(size_t)v] = (int32_t)r;
     const int64_t tile_rows = VRX_LDS_WAVES * (int64_t)RW;
     t.n_tile = (int)((n_vrows + tile_rows - 1) / tile_rows);
+    // Coarse shapes (clone mode: a few hundred variants, 10^5 cells): the (tile, slab) visits
+    // are what the work list deals to the CUs, and a visit is not divisible.
+    //  * fewer visits than CUs: shorter slabs, until every CU has one (c5 variant pass: ONE tile
+    //    of 200 variants x 196 slabs of 1024 cells left 60 CUs idle -> 256 slabs of 784);
+    //  * one or two slabs: the rows are spread over as many tiles as make whole rounds of CUs --
+    //    the pieces are dealt round-robin to the waves anyway, only the number of tiles changes
+    //    (c5 cell pass: 196 full tiles of 1024 cells -> 256 tiles of 782).
+    if (n_cu > 0 && env_int("VIREO_LDS_FILL_CUS", 1) != 0) {
+        auto spread_tiles = [&]() {  // (tiles must keep >= 4 rows per wave on average)
+            const int64_t visits = (int64_t)t.n_tile * t.n_slab, rounds = (visits + n_cu - 1) / n_cu;
+            const int64_t nt = rounds * n_cu / t.n_slab;
+            if (nt > t.n_tile && nt * VRX_LDS_WAVES * G <= std::max<int64_t>(n_vrows, 1) * 4) t.n_tile = (int)nt;
+        };
+        if (t.n_slab <= 2) spread_tiles();
+        if ((int64_t)t.n_tile * t.n_slab < n_cu) {
+            const int64_t want = (n_cu + t.n_tile - 1) / t.n_tile;
+            const int64_t sr = std::min<int64_t>(slab_rows, std::max<int64_t>(64, ((o_n_contract + want - 1) / want + 15) / 16 * 16));
+            slab_rows = (int)sr;
+            t.slab_rows = slab_rows;
+            t.n_slab = (int)((o_n_contract + slab_rows - 1) / slab_rows);
+            if ((int64_t)t.n_tile * t.n_slab < n_cu) spread_tiles();
+        }
+    }
     const int64_t n_wave = (int64_t)t.n_tile * VRX_LDS_WAVES;
     const int PH = form == 2 ? 2 : 1;  // phases of a round (form 2: AD entries, then BD entries)
     const int64_t per_wave = (int64_t)t.n_slab * NR * PH + 1;
@@ -751,7 +774,8 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
 // per CU (plan_items); a visit is not divisible, so with one or two slabs (few variants: clone
 // mode) the busiest CU gets ceil(visits / CUs) of them, and the shorter tile wins when that
 // rounds up less (200 k cells, one slab: 261 tiles of 768 rows = 2 visits on the busiest CU,
-// 391 tiles of 512 rows = 2 shorter ones).
+// 391 tiles of 512 rows = 2 shorter ones).  (build_tiled then spreads the rows over whole
+// rounds of CUs, VIREO_LDS_FILL_CUS.)
 static int pick_rw_cell(int64_t n_var, int64_t n_cell, int n_cu, int cell_form) {
     const int tall = cell_form == 1 ? VRX_LDS_RW_CELL : VRX_LDS_RW_CELL_PAIR;
     const int slab = VRX_LDS_SLAB_BYTES / 256;
