@@ -30,7 +30,8 @@ if config == "c5":      # BinomMixtureVB clone mode (BASELINE.json configs[4]): 
     cmd = [sys.executable, os.path.join(ROOT, "tests", "perf", "bench_bmm.py"), "--passes-only"]
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-    out = "/tmp/pmc_%s" % counter
+    out = "/tmp/pmc_%s_%s" % (config, counter)   # (one directory per config and counter, emptied first)
+    subprocess.run(["rm", "-rf", out], check=False)
     env = dict(os.environ, TMPDIR="/tmp")
     subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out,
                     "-o", config, "--"] + cmd, cwd=ROOT if config == "c5" else "/tmp", env=env, check=True,
