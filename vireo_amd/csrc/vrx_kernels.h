@@ -72,9 +72,67 @@ struct VrxStopRule {  // by value to the ELBO kernel
 // ------------------------------------------------------------------------------------
 // wave / block reductions (fixed butterfly order => deterministic)
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+typedef int vrx_i2 __attribute__((ext_vector_type(2)));
+// value of lane ^ S for the steps DPP can express EXACTLY (1, 2: quad permutations; 8: rotation of
+// the 16-lane row by 8): a VALU move instead of a trip through the LDS crossbar
+template <int S>
+__device__ __forceinline__ double vrx_lane_xor_exact(double v) {
+    static_assert(S == 1 || S == 2 || S == 8, "exact DPP steps");
+    constexpr int ctrl = S == 1 ? 0xB1 : S == 2 ? 0x4E : 0x128;
+    const vrx_i2 b = __builtin_bit_cast(vrx_i2, v);
+    vrx_i2 r;
+    r.x = __builtin_amdgcn_update_dpp(0, b.x, ctrl, 0xf, 0xf, true);
+    r.y = __builtin_amdgcn_update_dpp(0, b.y, ctrl, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, r);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {  // butterfly 32, 16, ... 1: the order is part of the results
+    v += __shfl_xor(v, 32, 64);
+    v += __shfl_xor(v, 16, 64);
+    v += vrx_lane_xor_exact<8>(v);
+    v += __shfl_xor(v, 4, 64);
+    v += vrx_lane_xor_exact<2>(v);
+    v += vrx_lane_xor_exact<1>(v);
+    return v;
+}
+
+// Partner value of an ASCENDING butterfly step (s = 1, 2, 4, ...) by DPP -- a VALU move instead of
+// a trip through the LDS crossbar (ds_bpermute).  Steps 1 and 2 are exact lane ^ S permutations
+// of a quad; steps 4 and 8 take lane 7 - l / 15 - l of the row, which holds the same value as lane
+// l ^ S once the steps below have run (all lanes of an S-group are equal by then) -- so the results
+// are bit for bit those of the __shfl_xor butterfly.  S >= 16 crosses rows: __shfl_xor.
+template <int S>
+__device__ __forceinline__ double vrx_butterfly_partner(double v) {
+    if constexpr (S >= 16) {
+        return __shfl_xor(v, S, 64);
+    } else {
+        constexpr int ctrl = S == 1 ? 0xB1 : S == 2 ? 0x4E : S == 4 ? 0x141 : 0x140;
+        const vrx_i2 b = __builtin_bit_cast(vrx_i2, v);
+        vrx_i2 r;
+        r.x = __builtin_amdgcn_update_dpp(0, b.x, ctrl, 0xf, 0xf, true);
+        r.y = __builtin_amdgcn_update_dpp(0, b.y, ctrl, 0xf, 0xf, true);
+        return __builtin_bit_cast(double, r);
+    }
+}
+// max / sum over the W (a power of two <= 64) lanes of an aligned group, every lane gets the result
+template <int W>
+__device__ __forceinline__ double vrx_group_max(double v) {
+    if constexpr (W > 1) v = fmax(v, vrx_butterfly_partner<1>(v));
+    if constexpr (W > 2) v = fmax(v, vrx_butterfly_partner<2>(v));
+    if constexpr (W > 4) v = fmax(v, vrx_butterfly_partner<4>(v));
+    if constexpr (W > 8) v = fmax(v, vrx_butterfly_partner<8>(v));
+    if constexpr (W > 16) v = fmax(v, vrx_butterfly_partner<16>(v));
+    if constexpr (W > 32) v = fmax(v, vrx_butterfly_partner<32>(v));
+    return v;
+}
+template <int W>
+__device__ __forceinline__ double vrx_group_sum(double v) {
+    if constexpr (W > 1) v += vrx_butterfly_partner<1>(v);
+    if constexpr (W > 2) v += vrx_butterfly_partner<2>(v);
+    if constexpr (W > 4) v += vrx_butterfly_partner<4>(v);
+    if constexpr (W > 8) v += vrx_butterfly_partner<8>(v);
+    if constexpr (W > 16) v += vrx_butterfly_partner<16>(v);
+    if constexpr (W > 32) v += vrx_butterfly_partner<32>(v);
     return v;
 }
 
@@ -335,12 +393,10 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_spmm(
                                                  : (F.id_mode == 2 ? F.logq[(int64_t)d * K + k] : F.logq[k]);
         const double x0 = own ? L + lq : -__builtin_inf();
         double mx = x0;
-#pragma unroll
-        for (int s = 1; s < LPE; s <<= 1) mx = fmax(mx, __shfl_xor(mx, s, 64));
+        mx = vrx_group_max<LPE>(mx);
         const double e0 = own ? exp(x0 - mx) : 0.0;
         double sum = e0;
-#pragma unroll
-        for (int s = 1; s < LPE; s <<= 1) sum += __shfl_xor(sum, s, 64);
+        sum = vrx_group_sum<LPE>(sum);
         double acc[2] = {0.0, 0.0};
         if (own) {
             const double x = x0 - mx;
@@ -1673,11 +1729,8 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_bmm_theta(int64_t NK, int updat
                     a.y += v[u].y;
                 }
         }
-#pragma unroll
-        for (int sft = 1; sft < 16; sft <<= 1) {
-            a.x += __shfl_xor(a.x, sft, 64);
-            a.y += __shfl_xor(a.y, sft, 64);
-        }
+        a.x = vrx_group_sum<16>(a.x);
+        a.y = vrx_group_sum<16>(a.y);
         if (live && sub == 0) S[j] = a;
     }
     if (live && sub == 0) {
@@ -1853,8 +1906,7 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_cell_softmax(
     double mx = -__builtin_inf();
     if (live)
         for (int k = kl; k < K; k += KP) mx = fmax(mx, (pre && k == kl ? L_pre : Lr[k]) + (id_mode ? qr[k] : logq_uni));
-#pragma unroll
-    for (int s = 1; s < KP; s <<= 1) mx = fmax(mx, __shfl_xor(mx, s, 64));
+    mx = vrx_group_max<KP>(mx);
     double sum = 0.0, e_first = 0.0;  // (the lane's first exponential is reused below: same argument)
     if (live && update)
         for (int k = kl; k < K; k += KP) {
@@ -1862,8 +1914,7 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_cell_softmax(
             if (k == kl) e_first = e;
             sum += e;
         }
-#pragma unroll
-    for (int s = 1; s < KP; s <<= 1) sum += __shfl_xor(sum, s, 64);
+    sum = vrx_group_sum<KP>(sum);
     if (live) {
         const double lsum = update ? log(sum) : 0.0;
         double* Ir = ID + row0;
