@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 constexpr int VRX_BLOCK = 256;  // 4 wavefronts
 constexpr int VRX_WAVES = VRX_BLOCK / 64;
@@ -73,24 +74,33 @@ struct VrxStopRule {  // by value to the ELBO kernel
 // wave / block reductions (fixed butterfly order => deterministic)
 // ------------------------------------------------------------------------------------
 typedef int vrx_i2 __attribute__((ext_vector_type(2)));
-// value of lane ^ S for the steps DPP can express EXACTLY (1, 2: quad permutations; 8: rotation of
-// the 16-lane row by 8): a VALU move instead of a trip through the LDS crossbar
+// value of lane ^ S for the steps DPP can express EXACTLY -- 1, 2: quad permutations; 8: rotation
+// of the 16-lane row by 8; 4: lane 7 - l of the half row (= l ^ 7), then the quad reversed
+// (^ 3) -- VALU moves instead of a trip through the LDS crossbar (ds_bpermute).  16 and 32
+// cross rows: __shfl_xor.
 template <int S>
 __device__ __forceinline__ double vrx_lane_xor_exact(double v) {
-    static_assert(S == 1 || S == 2 || S == 8, "exact DPP steps");
-    constexpr int ctrl = S == 1 ? 0xB1 : S == 2 ? 0x4E : 0x128;
-    const vrx_i2 b = __builtin_bit_cast(vrx_i2, v);
-    vrx_i2 r;
-    r.x = __builtin_amdgcn_update_dpp(0, b.x, ctrl, 0xf, 0xf, true);
-    r.y = __builtin_amdgcn_update_dpp(0, b.y, ctrl, 0xf, 0xf, true);
-    return __builtin_bit_cast(double, r);
+    if constexpr (S >= 16) {
+        return __shfl_xor(v, S, 64);
+    } else {
+        constexpr int ctrl = S == 1 ? 0xB1 : S == 2 ? 0x4E : S == 4 ? 0x141 : 0x128;
+        const vrx_i2 b = __builtin_bit_cast(vrx_i2, v);
+        vrx_i2 r;
+        r.x = __builtin_amdgcn_update_dpp(0, b.x, ctrl, 0xf, 0xf, true);
+        r.y = __builtin_amdgcn_update_dpp(0, b.y, ctrl, 0xf, 0xf, true);
+        if constexpr (S == 4) {
+            r.x = __builtin_amdgcn_update_dpp(0, r.x, 0x1B, 0xf, 0xf, true);  // quad_perm [3,2,1,0]
+            r.y = __builtin_amdgcn_update_dpp(0, r.y, 0x1B, 0xf, 0xf, true);
+        }
+        return __builtin_bit_cast(double, r);
+    }
 }
 
 __device__ __forceinline__ double wave_sum(double v) {  // butterfly 32, 16, ... 1: the order is part of the results
-    v += __shfl_xor(v, 32, 64);
-    v += __shfl_xor(v, 16, 64);
+    v += vrx_lane_xor_exact<32>(v);
+    v += vrx_lane_xor_exact<16>(v);
     v += vrx_lane_xor_exact<8>(v);
-    v += __shfl_xor(v, 4, 64);
+    v += vrx_lane_xor_exact<4>(v);
     v += vrx_lane_xor_exact<2>(v);
     v += vrx_lane_xor_exact<1>(v);
     return v;
@@ -368,13 +378,22 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_spmm(
     }
     if (off < len)
         vrx_spmm_batch<LPE, CPL, MODE, FMT, true>(nxt, len - off, g, kc, (uint32_t)K, X, a1, a2);
+    auto fold = [&](auto s_tag) {  // (steps 1 ... 8 by DPP: vrx_lane_xor_exact)
+        constexpr int S = decltype(s_tag)::value;
+        if constexpr (S >= LPE) {
 #pragma unroll
-    for (int s = LPE; s < 64; s <<= 1)
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-            a1[c] += __shfl_xor(a1[c], s, 64);
-            if (MODE == 0) a2[c] += __shfl_xor(a2[c], s, 64);
+            for (int c = 0; c < CPL; ++c) {
+                a1[c] += vrx_lane_xor_exact<S>(a1[c]);
+                if (MODE == 0) a2[c] += vrx_lane_xor_exact<S>(a2[c]);
+            }
         }
+    };
+    fold(std::integral_constant<int, 1>());
+    fold(std::integral_constant<int, 2>());
+    fold(std::integral_constant<int, 4>());
+    fold(std::integral_constant<int, 8>());
+    fold(std::integral_constant<int, 16>());
+    fold(std::integral_constant<int, 32>());
     const bool own = act && g == 0 && kok;
     if (own) {
         double* base = d >= 0 ? out : partial;
