@@ -456,6 +456,38 @@ def test_lds_count_limit_and_tiny_shapes(va, monkeypatch, top, var_form):
     close(dev.GT_prob, ref.GT_prob)
 
 
+@pytest.mark.parametrize("N,M,K,top,fill", [(50, 40000, 5, 6, "1"), (50, 40000, 5, 6, "0"),
+                                             (300, 30000, 16, 90, "1"), (25000, 60, 8, 6, "1")])
+def test_coarse_shapes_fill_the_cus(va, monkeypatch, N, M, K, top, fill):
+    """few variants x many cells (clone-mode shapes) and the transpose: the LDS-resident passes
+    shorten their slabs / spread their tiles until every CU has a (tile, slab) visit
+    (VIREO_LDS_FILL_CUS; AD/BD words over virtual rows for the shallow counts, pair words for the
+    deep ones) -- same results as with full slabs and tiles, and as the oracle"""
+    from vireo_amd import _lib
+    from vireo_amd.counts import DeviceCounts
+    from vireo_amd.engine import DeviceModel
+    monkeypatch.setenv("VIREO_LDS", "1")
+    monkeypatch.setenv("VIREO_LDS_FILL_CUS", fill)
+    rng = np.random.default_rng(N + M)
+    dp = (rng.random((N, M)) < 0.25) * rng.integers(1, top + 1, (N, M))
+    ad = rng.binomial(dp, rng.choice([0.03, 0.5, 0.96], (N, 1)))
+    AD, DP = csc_matrix(ad), csc_matrix(dp)
+    counts = DeviceCounts(AD, DP)
+    info = DeviceModel(counts, _lib.KIND_VIREO, K).info()
+    assert info["lds_variant"] and info["lds_cell"]
+    np.random.seed(4)
+    ref = O.vireo_new(M, N, K)
+    np.random.seed(4)
+    dev = va.Vireo(n_var=N, n_cell=M, n_donor=K)
+    O.vireo_fit(ref, AD, DP, min_iter=2, max_iter=5, delay_fit_theta=1)
+    dev.fit(counts, None, min_iter=2, max_iter=5, delay_fit_theta=1, verbose=False)
+    assert len(dev.ELBO_) == len(ref.ELBO_)
+    close(dev.ELBO_, ref.ELBO_)
+    close(dev.ID_prob, ref.ID_prob)
+    close(dev.GT_prob, ref.GT_prob)
+    close(dev.beta_mu, ref.beta_mu)
+
+
 @pytest.mark.parametrize("shape", ["row", "full"])
 def test_nonuniform_id_prior_vs_oracle(va, shape):
     """ID_prior as one broadcast row (set_prior with a 1-D array, vireo_model.py:122-125) and
