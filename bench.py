@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- EM iterations/sec of the Vireo VB hot path on MI355X (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K=200] [--warmup W=600] [--config c3|mid|c2] [--no-cpu] [--no-c4]
+  python bench.py [--gpus N] [--steps K=200] [--warmup W=50] [--config c3|mid|c2] [--no-cpu] [--no-c4]
 
 A step is ONE full coordinate-ascent iteration (theta update, GT update, ID update, ELBO:
 vireoSNP/utils/vireo_model.py:257-264) over the synthetic AD/DP of SURVEY.md 8(d), inputs
@@ -9,10 +9,12 @@ and state already resident in HBM.  Default workload = BASELINE.json configs[2]
 (N=100k variants x M=50k cells, K=16, ~2 % nnz), the configuration the metric is quoted on.
 The W warm-up iterations are the protocol's start (delay_fit_theta=3: the first three without the
 theta update, so every kernel of the timed iterations has been launched once), the K timed ones
-all run with it.  (The defaults time 200 iterations after 600: the GPU sits idle through the
-~20 s of host-side input generation and its clocks take ~0.4 s of work to come back -- after
-50 warm-up iterations the timed run was still 3.5 % slower than its own four repeats;
-`ms_per_step_repeats` shows the spread.)  N > 1 (launched by torch.distributed.run, one rank per GPU): every
+all run with it.  The GPU legs this run executes anyway (c2, c5's GPU half, the two
+whole-protocol parity fits, the c4 restart search) come BEFORE the timed region and are listed in
+`preceded_by`: the chip used to idle through ~20 s of host-side input generation right before a
+16-ms timed window (driver flags --steps 20 --warmup 5), which then ran 10-15 % slower than its
+own repeats; the CPU-oracle legs run after it.  `ms_per_step_repeats` shows the spread.
+N > 1 (launched by torch.distributed.run, one rank per GPU): every
 rank holds the problem and iterates its own restart (vireo_wrap's restart shard, weak
 scaling); the per-restart ELBOs are all-gathered over RCCL.  Rank 0 prints ONE JSON line.
 
@@ -153,12 +155,13 @@ def c2_leg(device, steps=200):
     return out
 
 
-def c5_leg(device, steps=50):
+def c5_gpu_leg(device, steps=50):
     """BASELINE.json configs[4]: BinomMixtureVB clone mode, N=200 variants x M=200k cells, K=8
     clones (bmm_model.py:178-201: one iteration = theta update, E[log lik], ID update, ELBO).
-    Iterations/s with inputs and state resident, the first iterations against the oracle, and
-    the HBM roofline on SURVEY.md 8(d)'s 0.89 GB per iteration."""
-    from oracle import vireo_oracle as O
+    Iterations/s with inputs and state resident and the HBM roofline on SURVEY.md 8(d)'s 0.89 GB
+    per iteration.  (The GPU half; `c5_cpu_leg` checks its first iterations against the oracle
+    after the timed region of the headline.)"""
+    from oracle import vireo_oracle as O          # (the generator only; the checker runs in c5_cpu_leg)
     from vireo_amd import _lib
     from vireo_amd.bmm_model import BinomMixtureVB
     from vireo_amd.counts import DeviceCounts
@@ -171,7 +174,7 @@ def c5_leg(device, steps=50):
     host = BinomMixtureVB(n_var=N, n_cell=M, n_donor=K)
     dm = DeviceModel(counts, _lib.KIND_BMM, K)
     host._push(dm)
-    first, _ = dm.run_iters(3)                       # the first iterations: checked below
+    first, _ = dm.run_iters(3)                       # the first iterations: checked in c5_cpu_leg
     t0 = time.perf_counter()
     dm.run_iters(steps)
     wall = time.perf_counter() - t0
@@ -180,6 +183,27 @@ def c5_leg(device, steps=50):
     pm, pn = dm.profile_read()
     info = dm.info()
     dm.close()
+    counts.close()
+    # SURVEY.md 8(d): 2 x 12 B per entry + the dense operands once per producer / consumer
+    bytes_it = 2 * 12 * nnz + 8 * (2 * M * K + 2 * N * K * 3)
+    ms_it = wall / steps * 1e3
+    out = dict(workload="c5: BinomMixtureVB N=%d x M=%d, K=%d, nnz=%d (SURVEY.md 8d generator, "
+                        "seed 0); %d iterations" % (N, M, K, nnz, steps),
+               ms_per_iteration=ms_it, iterations_per_s=1e3 / ms_it,
+               passes_ms={"variant_pass": pm[0] / max(pn[0], 1), "cell_pass": pm[1] / max(pn[1], 1),
+                          "dense_kernels": pm[2] / steps},
+               algorithmic_bytes_per_iteration=bytes_it,
+               roofline_frac=bytes_it / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS,
+               kernel_info=info)
+    return out, (AD, DP, first)
+
+
+def c5_cpu_leg(out, data):
+    """the oracle's first three clone-mode iterations (1 core) beside the GPU's"""
+    from oracle import vireo_oracle as O
+    AD, DP, first = data
+    N, M = AD.shape
+    K = 8
     np.random.seed(1)
     ref = O.bmm_new(M, N, K)
     ref_elbo = []
@@ -190,27 +214,18 @@ def c5_leg(device, steps=50):
         O.bmm_id_step(ref, L)
         ref_elbo.append(O.bmm_elbo(ref, L))
     t_cpu = (time.perf_counter() - t0) / 3
-    # SURVEY.md 8(d): 2 x 12 B per entry + the dense operands once per producer / consumer
-    bytes_it = 2 * 12 * nnz + 8 * (2 * M * K + 2 * N * K * 3)
-    ms_it = wall / steps * 1e3
-    return dict(workload="c5: BinomMixtureVB N=%d x M=%d, K=%d, nnz=%d (SURVEY.md 8d generator, "
-                         "seed 0); %d iterations" % (N, M, K, nnz, steps),
-                ms_per_iteration=ms_it, iterations_per_s=1e3 / ms_it,
-                passes_ms={"variant_pass": pm[0] / max(pn[0], 1), "cell_pass": pm[1] / max(pn[1], 1),
-                           "dense_kernels": pm[2] / steps},
-                algorithmic_bytes_per_iteration=bytes_it,
-                roofline_frac=bytes_it / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                kernel_info=info,
-                elbo_rel_err_first_iterations=[float("%.3g" % (abs(a - b) / abs(b)))
-                                               for a, b in zip(first, ref_elbo)],
-                cpu_oracle_s_per_iteration=t_cpu, cpu_cores=1)
+    out["elbo_rel_err_first_iterations"] = [float("%.3g" % (abs(a - b) / abs(b)))
+                                            for a, b in zip(first, ref_elbo)]
+    out["cpu_oracle_s_per_iteration"] = t_cpu
+    out["cpu_cores"] = 1
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=600)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="c3")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity leg")
     ap.add_argument("--no-c4", action="store_true", help="skip the n_init=32 restart-shard leg")
@@ -257,11 +272,51 @@ def main():
                                       device=local)
     t_up = time.perf_counter() - t_up
 
+    # ---- GPU legs that the run executes anyway, BEFORE the timed region ---------------------
+    # (the timed K iterations used to open on a chip that had idled through ~20 s of
+    # host-side input generation; the driver's --steps 20 --warmup 5 window is 16 ms, far less
+    # than the clocks need to come back.  Nothing is added to the warm-up: `warmup` stays what
+    # the flag says.  The legs are named in the JSON line, `preceded_by`.)
+    preceded_by = []
+    c4 = c2 = c5 = None
+    c5_data = None
+    parity_gpu = None
+    solo = rank == 0 and world == 1
+    if solo and not args.no_c4 and args.config == "c3":
+        c2 = c2_leg(local)
+        preceded_by.append("c2 leg (3 x 210 iterations of the N=10k x M=5k problem)")
+        c5, c5_data = c5_gpu_leg(local)
+        preceded_by.append("c5 leg, GPU half (103 clone-mode iterations)")
+    if solo and not args.no_cpu:     # (N = 1 only: the other ranks would wait)
+        # whole-protocol parity, GPU half: the same fit the CPU oracle runs after the timed region
+        np.random.seed(1)
+        dev = Vireo(n_var=N, n_cell=M, n_donor=K)
+        tg = time.perf_counter()
+        gtrace = dev._fit_VB(counts, None, verbose=False, **PROTOCOL)   # ELBO[:it], no constant
+        tg = time.perf_counter() - tg
+        # how far a 1e-13 relative perturbation of the initial ID_prob (the size of the GPU/CPU
+        # difference over the first iterations) moves the trace on the GPU itself: the first
+        # iterations leave a symmetric, unstable state (posteriors uniform to ~3e-7), and
+        # rounding-order differences are amplified while the clusters form; no two
+        # implementations can agree better mid-trace than this self-sensitivity
+        np.random.seed(1)
+        pert = Vireo(n_var=N, n_cell=M, n_donor=K)
+        pert.ID_prob = pert.ID_prob * (1.0 + 1e-13 * np.random.default_rng(7).standard_normal(pert.ID_prob.shape))
+        ptrace = pert._fit_VB(counts, None, verbose=False, **PROTOCOL)
+        self_rel = (np.abs(ptrace - gtrace) / np.abs(gtrace) if len(ptrace) == len(gtrace) else None)
+        del pert
+        parity_gpu = (dev, gtrace, self_rel, tg)
+        preceded_by.append("whole-protocol parity fits on the GPU (2 x %d iterations)" % (len(gtrace) + 1))
+
     # model init of the timing protocol: one np.random.seed, then sequential constructor
-    # draws (vireo_wrap.py:53-71); rank r iterates restart r.
+    # draws (vireo_wrap.py:53-71); rank r iterates restart r.  (Drawn before the c4 leg so that
+    # nothing but the 45-MB upload of this state separates that leg from the timed region.)
     np.random.seed(1)
     for _ in range(rank + 1):
         host = Vireo(n_var=N, n_cell=M, n_donor=K)
+    if not args.no_c4 and args.config == "c3":
+        c4 = c4_leg(counts, K, comm)
+        preceded_by.append("c4 leg (vireo_wrap n_init=32 on the same data: ~0.6 s of fits)")
     dm = DeviceModel(counts, _lib.KIND_VIREO, K, n_gt=T)
     dm.set_state(host.ID_prob, host.GT_prob, host.beta_mu, host.beta_sum)
     dm.set_prior(host.ID_prior, host.GT_prior, host.theta_s1_prior, host.theta_s2_prior)
@@ -293,33 +348,14 @@ def main():
     kinfo = dm.info()
     dm.close()
 
-    c4 = c2 = c5 = None
-    if not args.no_c4 and args.config == "c3":
-        c4 = c4_leg(counts, K, comm)
-        if rank == 0 and world == 1:
-            c2 = c2_leg(local)
-            c5 = c5_leg(local)
-
-    # whole-protocol parity + CPU baseline (rank 0): the same fit on the GPU and on the oracle
+    # ---- CPU legs (rank 0): the oracle beside the GPU results formed above --------------------
+    if c5 is not None:
+        c5 = c5_cpu_leg(c5, c5_data)
+        del c5_data
     parity = None
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:     # (N = 1 only: the other ranks would wait)
-        np.random.seed(1)
-        dev = Vireo(n_var=N, n_cell=M, n_donor=K)
-        tg = time.perf_counter()
-        gtrace = dev._fit_VB(counts, None, verbose=False, **PROTOCOL)   # ELBO[:it], no constant
-        tg = time.perf_counter() - tg
-        # how far a 1e-13 relative perturbation of the initial ID_prob (the size of the GPU/CPU
-        # difference over the first iterations) moves the trace on the GPU itself: the first
-        # iterations leave a symmetric, unstable state (posteriors uniform to ~3e-7), and
-        # rounding-order differences are amplified while the clusters form; no two
-        # implementations can agree better mid-trace than this self-sensitivity
-        np.random.seed(1)
-        pert = Vireo(n_var=N, n_cell=M, n_donor=K)
-        pert.ID_prob = pert.ID_prob * (1.0 + 1e-13 * np.random.default_rng(7).standard_normal(pert.ID_prob.shape))
-        ptrace = pert._fit_VB(counts, None, verbose=False, **PROTOCOL)
-        self_rel = (np.abs(ptrace - gtrace) / np.abs(gtrace) if len(ptrace) == len(gtrace) else None)
-        del pert
+    if parity_gpu is not None:
+        dev, gtrace, self_rel, tg = parity_gpu
         dt, st, ctrace, it_cpu = cpu_protocol_leg(w, K, seed=1)
         n_cpu = len(ctrace)
         same_len = len(gtrace) == n_cpu
@@ -342,6 +378,15 @@ def main():
                            oracle_vs_exact_per_iteration=[float("%.3g" % x) for x in e_cpu],
                            gpu_vs_exact_max=float(e_gpu.max()), oracle_vs_exact_max=float(e_cpu.max()),
                            assignments_equal_exact=bool(np.array_equal(dev.ID_prob.argmax(1), g["assign"])))
+                if "ID_prob" in g.files:    # (round 4) the end-state posteriors of the protocol
+                    xi, xg = g["ID_prob"], g["GT_prob_sample"]
+                    sl = slice(None, None, int(g["GT_stride"]))
+                    arb["end_state"] = dict(
+                        id_prob_max_abs_gpu_vs_exact=float(np.max(np.abs(dev.ID_prob - xi))),
+                        id_prob_max_abs_oracle_vs_exact=float(np.max(np.abs(st.ID_prob - xi))),
+                        gt_prob_sample_max_abs_gpu_vs_exact=float(np.max(np.abs(dev.GT_prob[sl] - xg))),
+                        gt_prob_sample_max_abs_oracle_vs_exact=float(np.max(np.abs(st.GT_prob[sl] - xg))),
+                        gt_sample="every %d-th variant" % int(g["GT_stride"]))
         parity = dict(protocol="_fit_VB(min_iter=5, max_iter=20, delay_fit_theta=3) from "
                                "np.random.seed(1): ELBO[:it] without the binomial constant",
                       iterations_gpu=len(gtrace), iterations_cpu=n_cpu,
@@ -422,6 +467,7 @@ def main():
                          "whole_iteration": {"algorithmic_bytes": B["total"],
                                              "achieved_GBs": B["total"] / (wall_max / args.steps) / 1e9,
                                              "frac": B["total"] / (wall_max / args.steps) / 1e9 / HBM_PEAK_GBS}},
+            "preceded_by": preceded_by,
             "cpu_baseline": cpu,
             "parity": parity,
             "c4": c4,

@@ -13,7 +13,9 @@ noise is ~1e-3 of float64's, i.e. ~1e-8 relative on the ELBO at the worst iterat
 
 Run in the build container (about 15 minutes, ~12 GB):  python tests/golden/make_c3_arbiter.py
 Output: tests/golden/c3_protocol_longdouble.npz -- the ELBO trace (without the binomial
-constant, like ``_fit_VB``'s), the iteration count, the final assignments.  The GPU test
+constant, like ``_fit_VB``'s), the iteration count, the final assignments, and (round 4) the
+END-STATE POSTERIORS the protocol leaves (vireo_model.py:198-199, :218-219): the whole final
+``ID_prob`` and every 97th variant's ``GT_prob`` rows, rounded to float64.  The GPU test
 (tests/test_gpu_fullsize.py) and bench.py compare |GPU - exact| with |oracle - exact|.
 
 The update equations are those of the reference (cited inline); only the arithmetic differs, and
@@ -33,6 +35,7 @@ sys.path.insert(0, os.path.join(HERE, "..", ".."))
 from vireo_amd import synth                     # noqa: E402  (the generator only: host NumPy)
 
 LD = np.longdouble
+GT_STRIDE = 97          # GT_prob rows kept: variants 0, 97, 194, ... (1031 x K x T doubles at c3)
 mpmath.mp.dps = 40
 
 
@@ -130,7 +133,9 @@ def main(config="c3", out_name="c3_protocol_longdouble"):
     lo = (kept - hi.astype(LD)).astype(np.float64)
     np.savez_compressed(os.path.join(HERE, out_name + ".npz"), elbo_hi=hi, elbo_lo=lo, n_iter=np.int64(it),
                         assign=ID.argmax(1).astype(np.int8), theta_mu=mu.astype(np.float64),
-                        theta_sum=sm.astype(np.float64), nnz=np.int64(AD.nnz))
+                        theta_sum=sm.astype(np.float64), nnz=np.int64(AD.nnz),
+                        ID_prob=ID.astype(np.float64), GT_stride=np.int64(GT_STRIDE),
+                        GT_prob_sample=GT[::GT_STRIDE].astype(np.float64))
     print("saved %s: %d kept iterations, %.0f s" % (out_name, it, time.time() - t0))
 
 

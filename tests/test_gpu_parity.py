@@ -784,6 +784,44 @@ def test_stream_form_follows_count_depth(va, monkeypatch, depth, want):
     close(m.ID_prob, st.ID_prob, rtol=1e-6, atol=1e-12)
 
 
+@pytest.mark.parametrize("build", ["device", "host"])
+def test_deep_counts_with_one_beyond_pair_words(va, monkeypatch, build):
+    """deep counts make the estimate choose (ad, dp) pair words, ONE count >= 2048
+    does not fit them, so the builder falls back to AD/BD words -- and must then also build the cell
+    stream with the tile height of THAT form (96 rows per wave, not the pair form's 64; more than
+    two slabs of variants so that the short tile is not chosen either way).  Both builders, same
+    streams, the fit against the oracle."""
+    from vireo_amd import _lib
+    from vireo_amd.counts import DeviceCounts
+    from vireo_amd.engine import DeviceModel
+    monkeypatch.setenv("VIREO_LDS", "1")
+    rng = np.random.default_rng(77)
+    N, M, K = 1300, 700, 6
+    mask = rng.random((N, M)) < 0.04
+    DPd = (1 + rng.poisson(40.0, (N, M))) * mask
+    DPd[1111, 5] = 2048
+    DPd[17, 600] = 5000
+    ADd = rng.binomial(DPd, rng.choice([0.02, 0.5, 0.97], (N, 1)))
+    AD, DP = csc_matrix(ADd), csc_matrix(DPd)
+    monkeypatch.setenv("VIREO_BUILD", build)
+    counts = DeviceCounts(AD, DP)
+    monkeypatch.setenv("VIREO_BUILD", "host")
+    host = DeviceCounts(AD, DP)
+    dh, dd = host.digest(), counts.digest()
+    for k in (0, 1, 2, 3, 4, 6, 7, 8, 9, 10):
+        assert dh[k] == dd[k], "digest %d differs" % k
+    info = DeviceModel(counts, _lib.KIND_VIREO, K).info()
+    assert (info["cell_form"], info["var_form"]) == (1, 3) and info["lds_cell"] and info["lds_variant"]
+    np.random.seed(3)
+    m = va.Vireo(n_var=N, n_cell=M, n_donor=K)
+    st = O.vireo_new(M, N, K, ID_prob_init=m.ID_prob.copy(), GT_prob_init=m.GT_prob.copy())
+    m.fit(counts, None, min_iter=3, max_iter=8, verbose=False)
+    O.vireo_fit(st, AD, DP, max_iter=8, min_iter=3)
+    close(m.ELBO_, st.ELBO_, rtol=1e-9)
+    close(m.ID_prob, st.ID_prob, rtol=1e-6, atol=1e-12)
+    close(m.GT_prob, st.GT_prob, rtol=1e-6, atol=1e-12)
+
+
 @pytest.mark.parametrize("data", ["mito", "clone"])
 def test_bmm_fit_with_batched_initialisations(va, monkeypatch, capsys, data):
     """BinomMixtureVB.fit runs its n_init short fits side by side in one device model

@@ -462,3 +462,38 @@ def test_one_ahead_iterator_hands_over_items_errors_and_early_exits():
     while threading.active_count() > n0 and time.time() - t0 < 5:
         time.sleep(0.05)
     assert threading.active_count() <= n0
+
+
+def test_tcp_comm_three_ranks():
+    """tests/tcp_comm.py (the host-side communicator of tests/test_gpu_shard.py): all-gather in
+    rank order, broadcast from any root, barrier -- three ranks as threads of this process."""
+    import socket
+    import threading
+    from tests.tcp_comm import TcpComm
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    world, out, errs = 3, {}, []
+
+    def rank_main(r):
+        try:
+            c = TcpComm(r, world, port, timeout=30.0)
+            got = c.allgather(np.array([r + 0.5, -r]))
+            big = np.arange(6.0).reshape(2, 3) * (r + 1)
+            b1 = c.bcast(big, 1)
+            b0 = c.bcast(np.full(4, float(r)), 0)
+            c.barrier()
+            out[r] = (got, b1, b0)
+            c.close()
+        except Exception as e:      # noqa: BLE001
+            errs.append((r, e))
+
+    ths = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    [t.start() for t in ths]
+    [t.join(60) for t in ths]
+    assert not errs, errs
+    for r in range(world):
+        got, b1, b0 = out[r]
+        assert np.array_equal(got, [0.5, 0, 1.5, -1, 2.5, -2])
+        assert np.array_equal(b1, np.arange(6.0).reshape(2, 3) * 2) and b1.shape == (2, 3)
+        assert np.array_equal(b0, np.zeros(4))

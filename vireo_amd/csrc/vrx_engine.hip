@@ -876,7 +876,12 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
         return VRX_ERR_ARG;
     }
     const int32_t max_count = st[2];
-    if (max_count >= 2048 && forms.auto_pair) forms = StreamForms{1, 3, false};
+    if (max_count >= 2048 && forms.auto_pair) {
+        // the estimate chose pair words but a count does not fit them: AD/BD words after all, and
+        // the cell tile height that belongs to THAT form (the caller picked rw_cell for pairs)
+        forms = StreamForms{1, 3, false};
+        rw_cell = pick_rw_cell(n_var, n_cell, p->n_cu, forms.cell);
+    }
     const int var_form = forms.var, cell_form = forms.cell;
     // (pair words hold 11-bit counts; a forced pair form leaves such data to the host builder)
     if ((var_form < 2 || cell_form != 1) && max_count >= 2048) return VRX_OK;
@@ -1341,6 +1346,12 @@ struct vrx_model {
     DevBuf<int32_t> ctl;  // device-side loop control (VRX_CTL_*)
     DevBuf<double> snapID, snapGT, snapTh;  // vrx_model_snapshot
     bool snap_valid = false;
+    // vrx_model_stage_raw: the NEXT restart's raw draws, uploaded on a copy stream while this
+    // one fits (two buffers; staged[b] / consumed[b] order the copy against its consumer)
+    DevBuf<double> stageID[2], stageGT[2];
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t staged[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
+    hipEvent_t polled[2] = {nullptr, nullptr};  // vrx_model_fit's pipelined polls
     double* h_pin = nullptr;  // pinned staging for scalar read-backs
     int wform = 0;            // layout of W: 0 (W1, W2) pairs, 1 planar (Wa | Wb) rows (FORM 1)
     bool w_valid = false;     // W matches (GT, psi) on the device
@@ -1360,6 +1371,12 @@ struct vrx_model {
         for (auto e : ev) (void)hipEventDestroy(e);
         if (t0) (void)hipEventDestroy(t0);
         if (t1) (void)hipEventDestroy(t1);
+        for (int b = 0; b < 2; ++b) {
+            if (staged[b]) (void)hipEventDestroy(staged[b]);
+            if (consumed[b]) (void)hipEventDestroy(consumed[b]);
+            if (polled[b]) (void)hipEventDestroy(polled[b]);
+        }
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
     }
 };
 
@@ -1553,6 +1570,71 @@ extern "C" int vrx_model_set_state_raw(vrx_model* m, const double* ID_raw, const
     }
     if ((rc = h2d(m, m->mu, beta_mu, (size_t)(m->R * m->th_rows * m->th_cols)))) return rc;
     if ((rc = h2d(m, m->sm, beta_sum, (size_t)(m->R * m->th_rows * m->th_cols)))) return rc;
+    VRX_HIP(hipStreamSynchronize(s));
+    m->w_valid = false;
+    return VRX_OK;
+}
+
+// ---- staged uploads (vireo_wrap.py:64-87: the restarts run one after the other) -------------
+// The raw constructor draws of restart i + 1 (45 MB at c3) travel to the device WHILE restart i
+// fits: vrx_model_stage_reserve (once, from the thread that owns the model) makes two staging
+// buffers, a copy stream and the events; vrx_model_stage_raw may then be called from a SECOND host
+// thread concurrently with vrx_model_fit on the same model -- it touches nothing but its staging
+// buffer and the copy stream; vrx_model_set_state_staged (owner thread) normalises the buffer into
+// the model's state on the compute stream.  Results are those of vrx_model_set_state_raw, bitwise.
+extern "C" int vrx_model_stage_reserve(vrx_model* m) {
+    VRX_REQUIRE(m, "vrx_model_stage_reserve: null model");
+    VRX_REQUIRE(m->R == 1 && m->cfg.kind == VRX_KIND_VIREO, "vrx_model_stage_reserve: single Vireo models only");
+    if (m->copy_stream) return VRX_OK;
+    VRX_HIP(hipSetDevice(m->p->device));
+    for (int b = 0; b < 2; ++b) {
+        VRX_HIP(m->stageID[b].alloc((size_t)(m->M * m->K)));
+        VRX_HIP(m->stageGT[b].alloc((size_t)m->NK * m->T));
+        VRX_HIP(hipEventCreateWithFlags(&m->staged[b], hipEventDisableTiming));
+        VRX_HIP(hipEventCreateWithFlags(&m->consumed[b], hipEventDisableTiming));
+    }
+    VRX_HIP(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
+    return VRX_OK;
+}
+
+extern "C" int vrx_model_stage_raw(vrx_model* m, int32_t buf, const double* ID_raw, const double* GT_raw) {
+    VRX_REQUIRE(m && ID_raw && GT_raw, "vrx_model_stage_raw: null argument");
+    VRX_REQUIRE(buf == 0 || buf == 1, "vrx_model_stage_raw: buffer %d", buf);
+    VRX_REQUIRE(m->copy_stream, "vrx_model_stage_raw: call vrx_model_stage_reserve first");
+    VRX_HIP(hipSetDevice(m->p->device));
+    hipStream_t c = m->copy_stream;
+    // (the buffer's previous content has been normalised into the state: consumed[buf] was
+    //  recorded behind that; an event never recorded counts as complete)
+    VRX_HIP(hipStreamWaitEvent(c, m->consumed[buf], 0));
+    VRX_HIP(hipMemcpyAsync(m->stageID[buf].p, ID_raw, m->stageID[buf].n * sizeof(double), hipMemcpyHostToDevice, c));
+    VRX_HIP(hipMemcpyAsync(m->stageGT[buf].p, GT_raw, m->stageGT[buf].n * sizeof(double), hipMemcpyHostToDevice, c));
+    VRX_HIP(hipEventRecord(m->staged[buf], c));
+    VRX_HIP(hipStreamSynchronize(c));  // (the host arrays may be reused by the caller)
+    return VRX_OK;
+}
+
+extern "C" int vrx_model_set_state_staged(vrx_model* m, int32_t buf, const double* beta_mu,
+                                          const double* beta_sum) {
+    VRX_REQUIRE(m, "vrx_model_set_state_staged: null model");
+    VRX_REQUIRE(buf == 0 || buf == 1, "vrx_model_set_state_staged: buffer %d", buf);
+    VRX_REQUIRE(m->copy_stream, "vrx_model_set_state_staged: nothing was staged");
+    if (m->K > 128 || m->T > 128) {
+        vrx_set_error("vrx_model_set_state_staged: more than 128 columns (normalise on the host)");
+        return VRX_ERR_UNSUPPORTED;
+    }
+    VRX_HIP(hipSetDevice(m->p->device));
+    hipStream_t s = m->p->stream;
+    int rc;
+    VRX_HIP(hipStreamWaitEvent(s, m->staged[buf], 0));
+    VRX_HIP(hipMemcpyAsync(m->ID.p, m->stageID[buf].p, m->stageID[buf].n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    VRX_HIP(hipMemcpyAsync(m->GT.p, m->stageGT[buf].p, m->stageGT[buf].n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    VRX_HIP(hipEventRecord(m->consumed[buf], s));
+    vrx_normalize_rows<<<(unsigned)((m->M + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(m->M, m->K, m->ID.p);
+    VRX_HIP(hipGetLastError());
+    vrx_normalize_rows<<<(unsigned)((m->NK + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(m->NK, m->T, m->GT.p);
+    VRX_HIP(hipGetLastError());
+    if ((rc = h2d(m, m->mu, beta_mu, (size_t)(m->th_rows * m->th_cols)))) return rc;
+    if ((rc = h2d(m, m->sm, beta_sum, (size_t)(m->th_rows * m->th_cols)))) return rc;
     VRX_HIP(hipStreamSynchronize(s));
     m->w_valid = false;
     return VRX_OK;
@@ -1851,6 +1933,7 @@ template <int LPE, int MODE>
 static auto lds_kernel(int K, int ld, bool strided, int rw, int form) {
     // AD/BD forms: flat rows, or whole 16-B units (even K and row stride), or element-wise
     const int pad = K == 16 && !strided ? 0 : ((K | ld) & 1) == 0 ? 2 : 1;
+    // (the caller has checked rw against the heights compiled for this mode and form: lds_rw_ok)
     if (MODE == 1 && form == 1) {
         return rw == VRX_LDS_RW_CELL_SHORT ? lds_kernel_form1<VRX_LDS_RW_CELL_SHORT>(pad)
                                            : lds_kernel_form1<VRX_LDS_RW_CELL>(pad);
@@ -1865,10 +1948,21 @@ static auto lds_kernel(int K, int ld, bool strided, int rw, int form) {
     return lds_kernel_rw<LPE, MODE, MODE == 1 ? VRX_LDS_RW_CELL_PAIR : VRX_LDS_RW_VARIANT>(K, strided);
 }
 
+// the tile heights a kernel instance exists for: a stream built with any other height would be
+// walked with the wrong rows-per-wave (bnd / rowmap strides) -- refuse instead of defaulting
+template <int MODE>
+static bool lds_rw_ok(int rw, int form) {
+    if (MODE == 1 && form == 1) return rw == VRX_LDS_RW_CELL || rw == VRX_LDS_RW_CELL_SHORT;
+    if (MODE == 0) return rw == VRX_LDS_RW_VARIANT;
+    return rw == VRX_LDS_RW_CELL_PAIR || rw == VRX_LDS_RW_CELL_SHORT;
+}
+
 template <int LPE, int MODE>
 static int launch_lds_one(const Orient& o, hipStream_t s, const double* X, int K, double* dst,
                           const int32_t* ctl, int R) {
     const TiledStream& t = o.tiled;
+    VRX_REQUIRE(lds_rw_ok<MODE>(t.rw, t.form),
+                "LDS pass: no kernel instance for %d rows per wave (mode %d, form %d)", t.rw, MODE, t.form);
     constexpr int XD = MODE == 1 ? 2 : 1, NV = MODE == 0 ? 2 : 1;
     const unsigned grid = (unsigned)t.n_wg;  // persistent: one workgroup per CU walks its items
     // operands wider than 16 columns go through in blocks of 16 (the stream is re-read per
@@ -2265,11 +2359,17 @@ extern "C" int vrx_model_fit(vrx_model* m, int32_t max_iter, int32_t min_iter, d
     // the rule can fire at (min_iter + 1); a kernel launched after the stop returns at once, so
     // an overshoot costs launches, not work.
     static const int batch = std::max(1, env_int("VIREO_FIT_BATCH", 4));
-    int32_t* hctl = reinterpret_cast<int32_t*>(m->h_pin);
+    // Polls are PIPELINED: batch b + 1 is enqueued before the host waits for the control words
+    // batch b left, so the device never idles between batches (a 20-iteration restart used to
+    // pay five drained queues).  VIREO_FIT_PIPELINE=0: wait before enqueuing, as before.
+    static const int pipeline = env_int("VIREO_FIT_PIPELINE", 1);
     const int R = m->R;  // elbo_trace [R][max_iter], it_out [R], warn_flags [R]
-    int it = 0, next = 0;
-    bool stopped = false;
-    while (next < max_iter && !stopped) {
+    // two pinned read-back buffers of R * VRX_CTL_WORDS <= 64 words inside h_pin (64 doubles)
+    int32_t* hbuf[2] = {reinterpret_cast<int32_t*>(m->h_pin), reinterpret_cast<int32_t*>(m->h_pin) + 64};
+    for (int b = 0; b < 2; ++b)
+        if (!m->polled[b]) VRX_HIP(hipEventCreateWithFlags(&m->polled[b], hipEventDisableTiming));
+    int it = 0, next = 0, nb = 0;
+    auto enqueue_batch = [&]() -> int {  // iterations [next, upto) + the read-back of their control words
         const int upto = std::min(max_iter, next == 0 ? std::max(min_iter + 2, batch) : next + batch);
         for (it = next; it < upto; ++it) {
             VrxStopRule rule;
@@ -2280,15 +2380,33 @@ extern "C" int vrx_model_fit(vrx_model* m, int32_t max_iter, int32_t min_iter, d
             rule.eps = eps;
             const bool do_theta = m->cfg.kind == VRX_KIND_VIREO && m->cfg.learn_theta &&
                                   it >= delay_fit_theta;
-            if ((rc = enqueue_iteration(m, do_theta, rule))) return rc;
+            int rc2;
+            if ((rc2 = enqueue_iteration(m, do_theta, rule))) return rc2;
         }
         next = upto;
-        VRX_HIP(hipMemcpyAsync(hctl, m->ctl.p, (size_t)R * VRX_CTL_WORDS * sizeof(int32_t),
+        VRX_HIP(hipMemcpyAsync(hbuf[nb & 1], m->ctl.p, (size_t)R * VRX_CTL_WORDS * sizeof(int32_t),
                                hipMemcpyDeviceToHost, s));
-        VRX_HIP(hipStreamSynchronize(s));
-        stopped = true;  // the batch runs until its last restart has stopped
+        VRX_HIP(hipEventRecord(m->polled[nb & 1], s));
+        ++nb;
+        return VRX_OK;
+    };
+    if ((rc = enqueue_batch())) return rc;
+    int32_t* hctl = hbuf[0];
+    for (int b = 0;; ++b) {  // b: the batch whose control words are read next
+        if (pipeline && next < max_iter)
+            if ((rc = enqueue_batch())) return rc;  // (no-ops if batch b turns out to have stopped)
+        VRX_HIP(hipEventSynchronize(m->polled[b & 1]));
+        hctl = hbuf[b & 1];
+        bool stopped = true;  // the batch runs until its last restart has stopped
         for (int r = 0; r < R; ++r) stopped = stopped && hctl[r * VRX_CTL_WORDS + VRX_CTL_STOP] != 0;
+        if (stopped) break;
+        if (b + 1 == nb) {  // nothing in flight behind batch b
+            if (next >= max_iter) break;
+            if ((rc = enqueue_batch())) return rc;
+        }
     }
+    // (a batch enqueued behind the one that stopped changes nothing: its kernels return at once,
+    //  the control words are final; the sync below drains it)
     bool any_stop = false;
     for (int r = 0; r < R; ++r) {
         const int32_t* c = hctl + r * VRX_CTL_WORDS;

@@ -182,17 +182,22 @@ void mt_poly_reduce(uint64_t* r, int top_bit, const MtPoly& phi) {
     }
 }
 
-// g(x) = x^(624 * regens) mod phi(x), cached per `regens`
-const MtPoly* mt_jump_poly(uint64_t regens) {
+// g(x) = x^(624 * regens) mod phi(x), cached per `regens` (a few entries: a job skips by one or
+// two distinct lengths; the result is handed out by value so that trimming cannot dangle)
+bool mt_jump_poly(uint64_t regens, MtPoly* res) {
     static std::mutex mu;
     static std::map<uint64_t, MtPoly> cache;
+    constexpr size_t kCacheCap = 16;  // 2.5 KB each
     {
         std::lock_guard<std::mutex> lk(mu);
         auto it = cache.find(regens);
-        if (it != cache.end()) return &it->second;
+        if (it != cache.end()) {
+            *res = it->second;
+            return true;
+        }
     }
     const MtPoly& phi = mt_char_poly();
-    if (!phi.bit(MT_DEG)) return nullptr;  // (Berlekamp-Massey did not find degree 19937)
+    if (!phi.bit(MT_DEG)) return false;  // (Berlekamp-Massey did not find degree 19937)
     // E = 624 * regens, square-and-multiply from the top bit: g <- g^2 (bit spreading), g <- g x
     unsigned __int128 E = (unsigned __int128)regens * 624u;
     int top = 0;
@@ -231,7 +236,10 @@ const MtPoly* mt_jump_poly(uint64_t regens) {
     MtPoly out;
     for (int j = 0; j < MT_PW; ++j) out.w[j] = g[(size_t)j];
     std::lock_guard<std::mutex> lk(mu);
-    return &cache.emplace(regens, out).first->second;
+    if (cache.size() >= kCacheCap) cache.erase(cache.begin());
+    cache.emplace(regens, out);
+    *res = out;
+    return true;
 }
 
 // key <- g(T) key  (the window 624 * regens steps further on; the low 31 bits of key[0] are
@@ -283,9 +291,9 @@ static int mt_skip(uint32_t* key624, int32_t* pos, int64_t n, int64_t thr) {
             //  depends on `words` alone, so that equal skips share one cached polynomial)
             const int64_t jump = words / MT_N - 2;
             if (jump >= thr) {
-                const MtPoly* g = mt_jump_poly((uint64_t)jump);
-                if (g) {
-                    mt_apply_poly(*g, key624);
+                MtPoly g;
+                if (mt_jump_poly((uint64_t)jump, &g)) {
+                    mt_apply_poly(g, key624);
                     words -= jump * (int64_t)MT_N;
                 }
             }

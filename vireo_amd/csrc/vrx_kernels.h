@@ -39,6 +39,11 @@ constexpr int VRX_MAXT = 8;  // max genotype classes handled by the dense kernel
 //  c3, 41 -> 49 us per iteration at c2.)
 // ------------------------------------------------------------------------------------
 enum { VRX_CTL_STOP = 0, VRX_CTL_IT = 1, VRX_CTL_WARN = 2, VRX_CTL_WORDS = 4 };  // per restart
+// PRECONDITION (also of wave_sum and the vrx_group_* DPP reductions below): called with ALL 64
+// lanes of the wave active and converged -- the R <= 64 form reads restart r's word on lane r
+// and ballots, and DPP moves read 0 from inactive lanes (bound_ctrl).  Every call site is at kernel
+// entry / outside divergent control flow; a call behind a divergent early return would report
+// "all stopped" for restarts whose lanes have left.
 __device__ __forceinline__ bool vrx_all_stopped(const int32_t* ctl, int R) {
     if (R == 1) return ctl[VRX_CTL_STOP] != 0;
     if (R <= 64) {  // lane r reads restart r's word: one round trip for the whole batch
@@ -1203,6 +1208,9 @@ __device__ __forceinline__ void vrx_theta_final_block(int n_part, int T, int upd
                                                       const double* part, const double* prior1,
                                                       const double* prior2, double* mu, double* sm,
                                                       double* psi, double* kl_out, int stop) {
+// (as in vrx_gt_update, which inlines this finalisation for small problems: the two paths must
+//  round alike whichever one nb_theta selects -- no FMA contraction, like the reference's NumPy)
+#pragma clang fp contract(off)
     __shared__ double tot[2 * VRX_MAXT];
     double acc[2 * VRX_MAXT];
 #pragma unroll

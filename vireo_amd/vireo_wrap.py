@@ -105,6 +105,7 @@ def _one_ahead(gen, depth=1):
         try:
             for item in gen:
                 if not hand_over(item):
+                    gen.close()         # (its `finally` runs here, on this thread, not at collection)
                     return
             hand_over(done)
         except BaseException as e:      # noqa: BLE001 -- handed to the consumer
@@ -155,18 +156,20 @@ def _search(counts, plan, comm, max_iter_init, delay_fit_theta, kwargs, restarts
         the other ranks' restarts are consumed without being formed -- runs of them in ONE skip
         (far skips are a jump of the generator: vrx_mt19937_random_sample, cached per length)"""
         per_restart = (n_cell * K if ID0 is None else 0) + (n_var * K * T if GT0 is None else 0)
-        foreign = 0
-        for im in range(plan.n_init):
-            if im in mine:
-                if foreign:
-                    stream.skip(foreign * per_restart)
-                    foreign = 0
-                yield (im, stream.rand(n_cell, K) if ID0 is None else None,
-                       stream.rand(n_var, K, T) if GT0 is None else None)
-            else:
-                foreign += 1
-        if foreign:        # (the global stream ends where the reference's would)
-            stream.skip(foreign * per_restart)
+        consumed = 0          # restarts whose draws the global stream has passed
+        try:
+            for im in range(plan.n_init):
+                if im in mine:
+                    if im > consumed:
+                        stream.skip((im - consumed) * per_restart)
+                    consumed = im + 1
+                    yield (im, stream.rand(n_cell, K) if ID0 is None else None,
+                           stream.rand(n_var, K, T) if GT0 is None else None)
+        finally:
+            # the global stream ends where the reference's would (all n_init constructors run
+            # before the first fit, vireo_wrap.py:66-71) -- also when the consumer stops early
+            if consumed < plan.n_init:
+                stream.skip((plan.n_init - consumed) * per_restart)
 
     local = {}
     t_search = time.perf_counter()
