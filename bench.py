@@ -33,6 +33,8 @@ Besides the headline value the line carries
   c2, c5        BASELINE.json configs[1] (launch-bound small problem) and configs[4]
                 (BinomMixtureVB clone mode) on the driver's clock: us / ms per iteration,
                 c5 with its roofline fraction and the first iterations against the oracle.
+  c3_skew       c3's shape with heavy-tailed (log-normal) coverage / depth -- real-data-shaped
+                input -- on the same kernels: ms per iteration, padding, row pieces, imbalance.
   ms_per_step_repeats   the timed K iterations repeated four more times (min / median / max).
 """
 import argparse
@@ -153,6 +155,57 @@ def c2_leg(device, steps=200):
         out["us_per_restart_iteration"]["n_batch=%d" % R] = round(ms / steps / R * 1e3, 2)
         db.close()
     return out
+
+
+def c3_skew_leg(device, K, uniform_ms, steps=100):
+    """c3's shape with heavy-tailed coverage / depth (synth.C3_SKEW, log-normal sigma 1.0 / 0.7:
+    what real cellSNP matrices look like, io_utils.py:42-59) on this build's kernels: ms per
+    iteration in steady state (after 50 warm-up iterations) beside the uniform generator's, the
+    stream padding, the pieces long rows are cut into, the wave imbalance."""
+    from vireo_amd import _lib, synth
+    from vireo_amd.counts import DeviceCounts
+    from vireo_amd.engine import DeviceModel
+    from vireo_amd.vireo_model import Vireo
+    N, M, _, dens = synth.CONFIGS["c3"]
+    w = synth.donor_workload(N, M, K, dens, seed=0, skew=synth.C3_SKEW)
+    nnz = int(w["rowidx"].size)
+    rows = np.bincount(w["rowidx"], minlength=N)
+    cols = np.diff(w["colptr"])
+    max_count = int(w["dp"].max())
+    counts = DeviceCounts.from_merged(w["shape"], w["colptr"], w["rowidx"], w["ad"], w["dp"], device=device)
+    del w
+    np.random.seed(1)
+    host = Vireo(n_var=N, n_cell=M, n_donor=K)
+    dm = DeviceModel(counts, _lib.KIND_VIREO, K, n_gt=3)
+    dm.set_state(host.ID_prob, host.GT_prob, host.beta_mu, host.beta_sum)
+    dm.set_prior(host.ID_prior, host.GT_prior, host.theta_s1_prior, host.theta_s2_prior)
+    dm.run_iters(50, theta_from_iter=PROTOCOL["delay_fit_theta"])
+    t0 = time.perf_counter()
+    tr, _ = dm.run_iters(steps, theta_from_iter=0)
+    ms_it = (time.perf_counter() - t0) / steps * 1e3
+    if not np.all(np.isfinite(tr)):
+        raise RuntimeError("c3_skew leg: a non-finite ELBO in the timed iterations")
+    dm.profile(True)
+    dm.run_iters(steps, theta_from_iter=0)
+    pm, pn = dm.profile_read()
+    info = dm.info()
+    dm.close()
+    counts.close()
+    B = algorithmic_bytes(N, M, K, 3, nnz)
+    return dict(workload="c3 shape, log-normal coverage / depth (sigma %.1f / %.1f): nnz=%d, entries per "
+                         "variant %d..%d (median %d), per cell %d..%d (median %d), largest count %d; "
+                         "%d iterations after 50" % (synth.C3_SKEW + (nnz, rows.min(), rows.max(), np.median(rows),
+                                                     cols.min(), cols.max(), np.median(cols), max_count, steps)),
+                ms_per_iteration=ms_it, iterations_per_s=1e3 / ms_it,
+                ms_per_iteration_uniform_c3=uniform_ms,
+                ratio_to_uniform_per_nonzero=(ms_it / nnz) / (uniform_ms[0] / uniform_ms[1]),
+                passes_ms={"variant_pass": pm[0] / max(pn[0], 1), "cell_pass": pm[1] / max(pn[1], 1),
+                           "dense_kernels": pm[2] / steps},
+                whole_iteration_roofline_frac=B["total"] / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                pad_variant=info["pad_variant"], pad_cell=info["pad_cell"],
+                extra_pieces_variant=info["extra_pieces_variant"], extra_pieces_cell=info["extra_pieces_cell"],
+                imbalance_variant=info["imbalance_variant"], imbalance_cell=info["imbalance_cell"],
+                lds_passes=bool(info["lds_variant"] and info["lds_cell"]), kernel_info=info)
 
 
 def c5_gpu_leg(device, steps=50):
@@ -287,39 +340,47 @@ def main():
         preceded_by.append("c2 leg (3 x 210 iterations of the N=10k x M=5k problem)")
         c5, c5_data = c5_gpu_leg(local)
         preceded_by.append("c5 leg, GPU half (103 clone-mode iterations)")
-    if solo and not args.no_cpu:     # (N = 1 only: the other ranks would wait)
-        # whole-protocol parity, GPU half: the same fit the CPU oracle runs after the timed region
-        np.random.seed(1)
-        dev = Vireo(n_var=N, n_cell=M, n_donor=K)
-        tg = time.perf_counter()
-        gtrace = dev._fit_VB(counts, None, verbose=False, **PROTOCOL)   # ELBO[:it], no constant
-        tg = time.perf_counter() - tg
-        # how far a 1e-13 relative perturbation of the initial ID_prob (the size of the GPU/CPU
-        # difference over the first iterations) moves the trace on the GPU itself: the first
-        # iterations leave a symmetric, unstable state (posteriors uniform to ~3e-7), and
-        # rounding-order differences are amplified while the clusters form; no two
-        # implementations can agree better mid-trace than this self-sensitivity
-        np.random.seed(1)
-        pert = Vireo(n_var=N, n_cell=M, n_donor=K)
-        pert.ID_prob = pert.ID_prob * (1.0 + 1e-13 * np.random.default_rng(7).standard_normal(pert.ID_prob.shape))
-        ptrace = pert._fit_VB(counts, None, verbose=False, **PROTOCOL)
-        self_rel = (np.abs(ptrace - gtrace) / np.abs(gtrace) if len(ptrace) == len(gtrace) else None)
-        del pert
-        parity_gpu = (dev, gtrace, self_rel, tg)
-        preceded_by.append("whole-protocol parity fits on the GPU (2 x %d iterations)" % (len(gtrace) + 1))
-
     # model init of the timing protocol: one np.random.seed, then sequential constructor
-    # draws (vireo_wrap.py:53-71); rank r iterates restart r.  (Drawn before the c4 leg so that
-    # nothing but the 45-MB upload of this state separates that leg from the timed region.)
+    # draws (vireo_wrap.py:53-71); rank r iterates restart r.
     np.random.seed(1)
     for _ in range(rank + 1):
         host = Vireo(n_var=N, n_cell=M, n_donor=K)
-    if not args.no_c4 and args.config == "c3":
-        c4 = c4_leg(counts, K, comm)
-        preceded_by.append("c4 leg (vireo_wrap n_init=32 on the same data: ~0.6 s of fits)")
     dm = DeviceModel(counts, _lib.KIND_VIREO, K, n_gt=T)
     dm.set_state(host.ID_prob, host.GT_prob, host.beta_mu, host.beta_sum)
     dm.set_prior(host.ID_prior, host.GT_prior, host.theta_s1_prior, host.theta_s2_prior)
+    # (the timed model is resident before the c4 leg: at N > 1, where no parity fits follow, only
+    #  the tail of that leg -- the winner's download / broadcast -- separates its fits from the warm-up)
+    if not args.no_c4 and args.config == "c3":
+        c4 = c4_leg(counts, K, comm)
+        preceded_by.append("c4 leg (vireo_wrap n_init=32 on the same data: ~0.6 s of fits)")
+
+    if solo and not args.no_cpu:     # (N = 1 only: the other ranks would wait)
+        # Whole-protocol parity, GPU half: the same fit the CPU oracle runs after the timed region,
+        # and the same fit from an initial ID_prob perturbed by 1e-13 relative (the size of the
+        # GPU/CPU difference over the first iterations): the first iterations leave a symmetric,
+        # unstable state (posteriors uniform to ~3e-7) and rounding-order differences are
+        # amplified while the clusters form; no two implementations can agree better mid-trace
+        # than this self-sensitivity.
+        # The two fits are Vireo._fit_VB taken apart -- device model + upload first, the fit
+        # itself here, the download after the timed region -- so that the LAST thing the chip does
+        # before the warm-up is 2 x 20 iterations of this very workload with no host work in
+        # between: on this part a 5-ms pause (one 45-MB upload) is enough for the clocks to drop,
+        # and the next ~15 ms then run ~10 % slow (scratch/gap_probe.py).
+        np.random.seed(1)
+        dev = Vireo(n_var=N, n_cell=M, n_donor=K)
+        np.random.seed(1)
+        pert = Vireo(n_var=N, n_cell=M, n_donor=K)
+        pert.ID_prob = pert.ID_prob * (1.0 + 1e-13 * np.random.default_rng(7).standard_normal(pert.ID_prob.shape))
+        dev_dm, _ = dev._device_model(counts, None)
+        pert_dm, _ = pert._device_model(counts, None)
+        fit_args = (PROTOCOL["max_iter"], PROTOCOL["min_iter"], 1e-2, PROTOCOL["delay_fit_theta"])
+        tg = time.perf_counter()
+        gfull, git, _ = dev_dm.fit(*fit_args)
+        tg = time.perf_counter() - tg
+        pfull, pit, _ = pert_dm.fit(*fit_args)
+        parity_gpu = (dev, dev_dm, gfull[:git], pert_dm, pfull[:pit], tg)
+        preceded_by.append("whole-protocol parity fits on the GPU (2 x %d iterations; their "
+                           "results are downloaded after the timed region)" % (git + 1))
 
     if args.warmup > 0:
         dm.run_iters(args.warmup, theta_from_iter=PROTOCOL["delay_fit_theta"])
@@ -348,6 +409,10 @@ def main():
     kinfo = dm.info()
     dm.close()
 
+    c3_skew = None
+    if solo and not args.no_c4 and args.config == "c3":
+        c3_skew = c3_skew_leg(local, K, (float(np.median(repeats)), nnz))
+
     # ---- CPU legs (rank 0): the oracle beside the GPU results formed above --------------------
     if c5 is not None:
         c5 = c5_cpu_leg(c5, c5_data)
@@ -355,7 +420,11 @@ def main():
     parity = None
     cpu = None
     if parity_gpu is not None:
-        dev, gtrace, self_rel, tg = parity_gpu
+        dev, dev_dm, gtrace, pert_dm, ptrace, tg = parity_gpu
+        dev._pull(dev_dm, want_GT=True)
+        dev_dm.close()
+        pert_dm.close()
+        self_rel = (np.abs(ptrace - gtrace) / np.abs(gtrace) if len(ptrace) == len(gtrace) else None)
         dt, st, ctrace, it_cpu = cpu_protocol_leg(w, K, seed=1)
         n_cpu = len(ctrace)
         same_len = len(gtrace) == n_cpu
@@ -473,6 +542,7 @@ def main():
             "c4": c4,
             "c2": c2,
             "c5": c5,
+            "c3_skew": c3_skew,
             "ms_per_step_repeats": {"runs": [round(x, 4) for x in repeats],
                                     "min": round(min(repeats), 4), "median": round(float(np.median(repeats)), 4),
                                     "max": round(max(repeats), 4),

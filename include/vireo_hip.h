@@ -105,6 +105,17 @@ int vrx_model_set_state(vrx_model* m, const double* ID_prob, const double* GT_pr
  * left untouched.  <= 128 columns. */
 int vrx_model_set_state_raw(vrx_model* m, const double* ID_raw, const double* GT_raw,
                             const double* beta_mu, const double* beta_sum);
+/* Staged uploads for back-to-back restarts (vireo_wrap.py:64-87 constructs and fits n_init models
+ * one after the other): the raw draws of restart i + 1 travel to the device while restart i fits.
+ * stage_reserve: once, from the thread that owns the model (single Vireo models): two staging
+ * buffers, a copy stream.  stage_raw: buffer buf (0 | 1) <- the raw draws; MAY BE CALLED FROM A SECOND
+ * HOST THREAD while vrx_model_fit runs on the same model (it touches only the staging buffer and the
+ * copy stream; it returns when the host arrays may be reused).  set_state_staged: the model's
+ * state <- normalised buffer buf (+ beta_mu / beta_sum, NULL = untouched): the same bits as
+ * vrx_model_set_state_raw from the same draws. */
+int vrx_model_stage_reserve(vrx_model* m);
+int vrx_model_stage_raw(vrx_model* m, int32_t buf, const double* ID_raw, const double* GT_raw);
+int vrx_model_set_state_staged(vrx_model* m, int32_t buf, const double* beta_mu, const double* beta_sum);
 /* restore == 0: save (ID_prob, GT_prob, beta_mu, beta_sum) in a device-side slot;
  * restore != 0: bring them back.  The best restart so far (vireo_wrap.py:90-91) stays in HBM. */
 int vrx_model_snapshot(vrx_model* m, int32_t restore);
@@ -218,7 +229,7 @@ int vrx_problem_cell_loglik(vrx_problem* p, int64_t n_col, int64_t n_class,
  * pairs, 1: single-valued AD / BD entries); info[13] = form of the variant stream (0: pairs,
  * 2: AD entries then BD entries per round, 3: AD / BD entries as 2N single-accumulator virtual
  * rows -- the cell pass's kernel); info[14] = restarts in the model (n_batch); info[15]
- * reserved (0).  The forms follow
+ * = longest / mean wave stream of the tiled streams x 1000 (variant: low 16 bits, cell: high 16).  The forms follow
  * the depth of the data: AD/BD words unless a count needs so many of them (> 1.56 words per
  * entry, estimated at vrx_problem_create) that one pair word per entry is cheaper. */
 int vrx_model_info(vrx_model* m, int32_t* info16);

@@ -82,6 +82,61 @@ def test_config3_fit_properties_and_one_step_parity(va):
     assert np.array_equal(m.ID_prob.argmax(1), st.ID_prob.argmax(1))
 
 
+def test_config3_heavy_tailed_data(va):
+    """c3's shape with log-normal coverage / depth (synth.C3_SKEW: what real cellSNP matrices look
+    like, io_utils.py:42-59; the uniform SURVEY.md 8(d) generator is the kernels' best case): the
+    LDS-resident passes are taken (long rows cut into pieces), a whole fit is bitwise repeatable,
+    and ONE oracle iteration from the fitted state equals one GPU iteration from it."""
+    from vireo_amd import _lib, synth
+    from vireo_amd.counts import DeviceCounts
+    from vireo_amd.engine import DeviceModel
+    N, M, K, dens = synth.CONFIGS["c3"]
+    w = synth.donor_workload(N, M, K, dens, seed=0, skew=synth.C3_SKEW)
+    rows = np.bincount(w["rowidx"], minlength=N)
+    cols = np.diff(w["colptr"])
+    assert rows.max() > 20 * np.median(rows) and cols.max() > 5 * np.median(cols)    # heavy tails
+    counts = DeviceCounts.from_merged(w["shape"], w["colptr"], w["rowidx"], w["ad"], w["dp"])
+    info = DeviceModel(counts, _lib.KIND_VIREO, K).info()
+    print("c3 skew: nnz %d, rows %d..%d (median %d), cells %d..%d (median %d), max count %d; %s"
+          % (w["rowidx"].size, rows.min(), rows.max(), np.median(rows), cols.min(), cols.max(),
+             np.median(cols), w["dp"].max(), info))
+    assert info["lds_variant"] and info["lds_cell"]
+    assert (info["cell_form"], info["var_form"]) == (1, 3)
+    assert info["extra_pieces_variant"] > 0 and info["extra_pieces_cell"] > 0
+
+    def fit():
+        np.random.seed(1)
+        m = va.Vireo(n_var=N, n_cell=M, n_donor=K)
+        m.fit(counts, None, min_iter=5, max_iter=20, delay_fit_theta=3, verbose=False)
+        return m
+
+    m = fit()
+    m2 = fit()
+    assert np.array_equal(m.ELBO_, m2.ELBO_) and np.array_equal(m.ID_prob, m2.ID_prob)
+    assert np.array_equal(m.GT_prob, m2.GT_prob)
+    assert np.all(np.isfinite(m.ELBO_)) and len(m.ELBO_) >= 6
+    np.testing.assert_allclose(m.ID_prob.sum(1), 1.0, rtol=0, atol=1e-12)
+    AD, DP = synth.as_scipy(w)
+    st = O.vireo_new(M, N, K, ID_prob_init=m.ID_prob, GT_prob_init=m.GT_prob,
+                     beta_mu_init=m.beta_mu.copy(), beta_sum_init=m.beta_sum.copy())
+    st.ID_prob, st.GT_prob = m.ID_prob.copy(), m.GT_prob.copy()
+    O.vireo_theta_step(st, AD, DP)
+    O.vireo_gt_step(st, AD, DP)
+    L = O.vireo_id_step(st, AD, DP)
+    elbo_ref = O.vireo_elbo(st, L)
+    m.update_theta_size(counts, None)
+    m.update_GT_prob(counts, None)
+    Lg = m.update_ID_prob(counts, None)
+    elbo_gpu = m.get_ELBO(Lg, counts, None)
+    np.testing.assert_allclose(m.beta_mu, st.beta_mu, rtol=RTOL)
+    np.testing.assert_allclose(m.beta_sum, st.beta_sum, rtol=RTOL)
+    np.testing.assert_allclose(m.GT_prob, st.GT_prob, rtol=RTOL, atol=1e-290)
+    np.testing.assert_allclose(m.ID_prob, st.ID_prob, rtol=RTOL, atol=1e-290)
+    np.testing.assert_allclose(Lg, L, rtol=1e-9)
+    np.testing.assert_allclose(elbo_gpu, elbo_ref, rtol=RTOL)
+    assert np.array_equal(m.ID_prob.argmax(1), st.ID_prob.argmax(1))
+
+
 def test_config5_clone_mode_vs_oracle(va):
     """BinomMixtureVB at N=200 x M=200k, K=8 (BASELINE.json configs[4]): three iterations
     from the same seeded start against the oracle."""
@@ -172,17 +227,36 @@ def test_config3_whole_protocol_trace_vs_oracle(va):
     assert np.array_equal(dev.ID_prob.argmax(1), g["assign"])
     np.testing.assert_allclose(dev.beta_mu, st.beta_mu, rtol=RTOL)
     np.testing.assert_allclose(dev.beta_sum, st.beta_sum, rtol=RTOL)
-    # the protocol stops after 20 iterations, before the remnant of that amplified difference has
-    # died out, so the two states sit ~5e-9 (ELBO) apart: posteriors agree to 1e-5 relative OR
-    # 1e-6 (ID_prob) / 1e-3 (GT_prob: a few genotypes are still moving, observed 1.6e-4)
-    # absolute -- a probability of 1e-200 has no meaningful relative error between them
-    print("GT_prob max abs err %.2e, ID_prob max abs err %.2e"
-          % (np.max(np.abs(dev.GT_prob - st.GT_prob)), np.max(np.abs(dev.ID_prob - st.ID_prob))))
-    np.testing.assert_allclose(dev.GT_prob, st.GT_prob, rtol=RTOL, atol=1e-3)
-    np.testing.assert_allclose(dev.ID_prob, st.ID_prob, rtol=RTOL, atol=1e-6)
+    # END-STATE POSTERIORS (vireo_model.py:198-199, :218-219), pinned by the arbiter as well (round
+    # 4): the protocol stops after 20 iterations, before the remnant of the amplified difference has
+    # died out, so the GPU's and the oracle's final states each sit a little off the exact one.  An
+    # element of the GPU's posteriors must be within 1e-5 relative of the exact value OR within
+    # twice the oracle's own largest absolute deviation from it -- the HIP path may not be further
+    # from the mathematics than the reference's float64 arithmetic is.  No absolute allowance
+    # beyond that, none on the genotype calls.
+    sl = slice(None, None, int(g["GT_stride"]))
+    for name, gpu, cpu, exact_a in (("ID_prob", dev.ID_prob, st.ID_prob, g["ID_prob"]),
+                                    ("GT_prob[::%d]" % int(g["GT_stride"]), dev.GT_prob[sl], st.GT_prob[sl],
+                                     g["GT_prob_sample"])):
+        assert gpu.shape == exact_a.shape
+        d_gpu, d_cpu = np.abs(gpu - exact_a), np.abs(cpu - exact_a)
+        tol = np.maximum(RTOL * np.abs(exact_a), 2.0 * d_cpu.max())
+        print("%s: max |gpu - exact| %.2e, max |oracle - exact| %.2e; worst element at %.2f of its tolerance"
+              % (name, d_gpu.max(), d_cpu.max(), np.max(d_gpu / np.maximum(tol, 1e-300))))
+        assert np.all(d_gpu <= tol), name
     assert np.array_equal(dev.ID_prob.argmax(1), st.ID_prob.argmax(1))
-    assert np.array_equal(dev.GT_prob.argmax(2), st.GT_prob.argmax(2)) or \
-        np.mean(dev.GT_prob.argmax(2) != st.GT_prob.argmax(2)) < 1e-4     # (exact ties: no reads)
+    # genotype calls: identical to the exact ones wherever the exact posterior is not a tie
+    # (variants without reads under a donor keep the uniform prior: argmax of three equal numbers)
+    xg = g["GT_prob_sample"]
+    top2 = np.sort(xg, axis=2)
+    decided = top2[:, :, 2] - top2[:, :, 1] > 4.0 * np.abs(st.GT_prob[sl] - xg).max()
+    assert decided.mean() > 0.9
+    assert np.array_equal(dev.GT_prob[sl].argmax(2)[decided], xg.argmax(2)[decided])
+    # ... and over ALL variants the GPU's calls equal the oracle's wherever the oracle's own
+    # posterior is decided by more than that margin
+    t2 = np.sort(st.GT_prob, axis=2)
+    dec_all = t2[:, :, 2] - t2[:, :, 1] > 4.0 * np.abs(st.GT_prob[sl] - xg).max()
+    assert np.array_equal(dev.GT_prob.argmax(2)[dec_all], st.GT_prob.argmax(2)[dec_all])
 
 
 def test_config4_restart_search_n_init32(va):

@@ -735,6 +735,49 @@ def test_restart_batch_equals_independent_fits(va, monkeypatch, K, R, lds):
             close(bmu, m.beta_mu, rtol=1e-9)
 
 
+@pytest.mark.parametrize("lds", [True, False])
+def test_restart_batch_in_ase_mode(va, monkeypatch, lds):
+    """R restarts in one model with ASE_mode=True (one theta row per variant: psi is
+    [R][3][N][T], the largest per-restart table -- an indexing slip between restarts would show
+    here): every restart equals its independent fit, also the LAST one of the batch."""
+    from vireo_amd import _lib
+    from vireo_amd.counts import DeviceCounts
+    from vireo_amd.engine import DeviceBatch, DeviceModel
+    monkeypatch.setenv("VIREO_LDS", "1" if lds else "0")
+    K, R = 4, 4
+    AD, DP = O.synth_donor(1200, 700, K, 0.05, seed=9)
+    counts = DeviceCounts(AD, DP)
+    N, M = AD.shape
+    np.random.seed(6)
+    singles = []
+    for _ in range(R):
+        m = va.Vireo(n_var=N, n_cell=M, n_donor=K, ASE_mode=True)
+        m.fit(counts, None, min_iter=5, max_iter=25, delay_fit_theta=2, verbose=False)
+        singles.append(m)
+    np.random.seed(6)
+    db = DeviceBatch(counts, _lib.KIND_VIREO, K, R, ase_mode=True)
+    singles[0]._set_device_prior(db)
+    mu = np.ones((N, 3)) * np.linspace(0.01, 0.99, 3)[None, :]
+    sm = np.full((N, 3), 50.0)
+    for r in range(R):
+        db.set_restart(r, np.random.rand(M, K), np.random.rand(N, K, 3), mu, sm, raw=True)
+    traces, its, _ = db.fit(25, 5, 1e-2, 2)
+    one = DeviceModel(counts, _lib.KIND_VIREO, K, ase_mode=True)
+    for r, m in enumerate(singles):
+        elbo = traces[r][:its[r]] + counts.binom_const()
+        db.copy_to(one, r)
+        ID, GT, bmu, bsm = one.get_state()
+        assert bmu.shape == (N, 3) and len(elbo) == len(m.ELBO_)
+        if lds:
+            assert np.array_equal(elbo, m.ELBO_), r
+            assert np.array_equal(ID, m.ID_prob) and np.array_equal(GT, m.GT_prob)
+            assert np.array_equal(bmu, m.beta_mu) and np.array_equal(bsm, m.beta_sum)
+        else:
+            close(elbo, m.ELBO_, rtol=1e-9)
+            close(ID, m.ID_prob, rtol=1e-6, atol=1e-12)
+            close(bmu, m.beta_mu, rtol=1e-9)
+
+
 @pytest.mark.parametrize("batch", [2, 3, 4])
 def test_wrap_with_restart_batches(va, monkeypatch, capsys, batch):
     """vireo_wrap with its restarts fitted `batch` at a time reproduces the reference's run
@@ -849,3 +892,68 @@ def test_bmm_fit_with_batched_initialisations(va, monkeypatch, capsys, data):
     close(packed.ELBO_iters, one.ELBO_iters, rtol=1e-9)
     close(packed.ID_prob, one.ID_prob, rtol=1e-6, atol=1e-12)
     close(packed.beta_mu, one.beta_mu, rtol=1e-8)
+
+
+def test_staged_upload_and_pipelined_polls(va, monkeypatch):
+    """Round 4 (vireo_wrap turnaround): (1) raw draws uploaded into a staging buffer -- from a
+    second thread, while the model is fitting -- and normalised from there give the bits of
+    vrx_model_set_state_raw; (2) vrx_model_fit with its polls pipelined (the next batch of
+    iterations is enqueued before the control words of the last one are read) returns what the
+    wait-then-enqueue loop returns: trace, iteration count, flags, state -- also when the stop rule
+    fires in the middle of a batch."""
+    import threading
+    from vireo_amd import _lib
+    from vireo_amd.counts import DeviceCounts
+    from vireo_amd.engine import DeviceModel
+    AD, DP = O.synth_donor(1800, 1100, 5, 0.04, seed=31)
+    counts = DeviceCounts(AD, DP)
+    N, M = AD.shape
+    K = 5
+    rng = np.random.default_rng(3)
+    draws = [(rng.random((M, K)), rng.random((N, K, 3))) for _ in range(3)]
+    mu, sm = np.linspace(0.01, 0.99, 3)[None, :], np.full((1, 3), 50.0)
+    tmpl = va.Vireo(n_var=N, n_cell=M, n_donor=K, ID_prob_init=np.ones((M, K)), GT_prob_init=np.ones((N, K, 3)))
+
+    def fitted(dm, pipeline):
+        monkeypatch.setenv("VIREO_FIT_PIPELINE", pipeline)
+        tr, it, fl = dm.fit(60, 5, 1e-2, 2)
+        return tr, it, fl, dm.get_state()
+
+    ref = DeviceModel(counts, _lib.KIND_VIREO, K)
+    tmpl._set_device_prior(ref)
+    want = []
+    for ID_raw, GT_raw in draws:
+        ref.set_state_raw(ID_raw, GT_raw, mu, sm)
+        want.append(fitted(ref, "0"))
+    assert len({w[1] for w in want}) > 1 and all(w[1] < 59 for w in want)   # stops at different iterations
+
+    dm = DeviceModel(counts, _lib.KIND_VIREO, K)
+    tmpl._set_device_prior(dm)
+    dm.stage_reserve()
+    dm.stage_raw(0, *draws[0])
+    for i in range(3):
+        dm.set_state_staged(i & 1, mu, sm)
+        th = None
+        if i + 1 < 3:       # the next restart's draws go up while this one fits
+            th = threading.Thread(target=dm.stage_raw, args=((i + 1) & 1,) + draws[i + 1])
+            th.start()
+        got = fitted(dm, "1")
+        if th is not None:
+            th.join()
+        assert got[1] == want[i][1] and got[2] == want[i][2]
+        assert np.array_equal(got[0], want[i][0])
+        for a, b in zip(got[3], want[i][3]):
+            assert np.array_equal(a, b)
+
+
+def test_max_iter_beyond_the_initial_trace_capacity(va):
+    """the reference takes any max_iter (its trace is np.zeros(max_iter), vireo_model.py:251); the
+    device-side trace grows on demand (it was capped at 65 536)"""
+    AD, DP = gold.c1()
+    np.random.seed(2)
+    a = va.Vireo(n_var=AD.shape[0], n_cell=AD.shape[1], n_donor=4)
+    np.random.seed(2)
+    b = va.Vireo(n_var=AD.shape[0], n_cell=AD.shape[1], n_donor=4)
+    a.fit(AD, DP, min_iter=5, max_iter=200, verbose=False)
+    b.fit(AD, DP, min_iter=5, max_iter=70000, verbose=False)
+    assert np.array_equal(a.ELBO_, b.ELBO_) and np.array_equal(a.ID_prob, b.ID_prob)

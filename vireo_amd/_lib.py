@@ -50,6 +50,9 @@ SIGNATURES = {
     "vrx_model_set_state": (C.c_int, [_P, _D, _D, _D, _D]),
     "vrx_model_get_state": (C.c_int, [_P, _D, _D, _D, _D]),
     "vrx_model_set_state_raw": (C.c_int, [_P, _D, _D, _D, _D]),
+    "vrx_model_stage_reserve": (C.c_int, [_P]),
+    "vrx_model_stage_raw": (C.c_int, [_P, C.c_int32, _D, _D]),
+    "vrx_model_set_state_staged": (C.c_int, [_P, C.c_int32, _D, _D]),
     "vrx_model_snapshot": (C.c_int, [_P, C.c_int32]),
     "vrx_model_set_restart": (C.c_int, [_P, C.c_int32, _D, _D, _D, _D, C.c_int32]),
     "vrx_model_copy_restart": (C.c_int, [_P, _P, C.c_int32]),

@@ -15,21 +15,8 @@
 #include "vrx_kernels.h"
 #include "vrx_build.h"
 
-// ------------------------------------------------------------------------------------
-// errors
-// ------------------------------------------------------------------------------------
-static thread_local std::string g_last_error;
-
-void vrx_set_error(const char* fmt, ...) {
-    char buf[1024];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    g_last_error = buf;
-}
-
-extern "C" const char* vrx_last_error(void) { return g_last_error.c_str(); }
+// (vrx_set_error / vrx_last_error: vrx_host.cpp, so that the host-only translation unit links on
+//  its own for the sanitizer build of tests/test_host_sanitizers_cpu.py)
 
 extern "C" int vrx_device_count(int* n) {
     VRX_REQUIRE(n, "vrx_device_count: null output");
@@ -1312,7 +1299,7 @@ extern "C" int vrx_problem_n_vars(vrx_problem* p, int32_t* out) {
 // ------------------------------------------------------------------------------------
 // model
 // ------------------------------------------------------------------------------------
-static constexpr int kMaxTrace = 1 << 16;
+static constexpr int kTraceInit = 1 << 12;  // ELBO slots per restart a model starts with (ensure_trace grows them)
 static constexpr int kEventPairs = 1 << 13;
 
 struct vrx_model {
@@ -1343,6 +1330,7 @@ struct vrx_model {
     bool theta_pending = false;  // stage-1 partials wait for the finalisation inside vrx_gt_update
     DevBuf<double> part_theta, part_gt, part_cell, part_th;
     DevBuf<double> d_elbo, d_parts;
+    int64_t trace_cap = 0;  // ELBO slots per restart in d_elbo
     DevBuf<int32_t> ctl;  // device-side loop control (VRX_CTL_*)
     DevBuf<double> snapID, snapGT, snapTh;  // vrx_model_snapshot
     bool snap_valid = false;
@@ -1379,6 +1367,19 @@ struct vrx_model {
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
     }
 };
+
+// the device-side ELBO trace holds n entries per restart (grown between fits: its content is
+// read back before a fit returns and never carried over)
+static int ensure_trace(vrx_model* m, int64_t n) {
+    if (n <= m->trace_cap) return VRX_OK;
+    VRX_REQUIRE(n < ((int64_t)1 << 31), "max_iter too large");
+    VRX_HIP(hipStreamSynchronize(m->p->stream));
+    int64_t cap = m->trace_cap;
+    while (cap < n) cap *= 2;
+    VRX_HIP(m->d_elbo.alloc((size_t)m->R * (size_t)cap));
+    m->trace_cap = cap;
+    return VRX_OK;
+}
 
 static int pick_kp(int K, int cap = 64) {
     int kp = 1;
@@ -1488,7 +1489,7 @@ extern "C" int vrx_model_create(vrx_problem* p, const vrx_model_cfg* cfg, vrx_mo
     VRX_HIP(hipMemsetAsync(m->part_gt.p, 0, (size_t)m->R * m->nb_nk * sizeof(double), s));
     if (cfg->kind == VRX_KIND_VIREO) {
         VRX_HIP(m->GT.alloc((size_t)m->NKt * m->T));
-        VRX_HIP(m->psi.alloc(3 * th * m->R));
+        VRX_HIP(m->psi.alloc(3 * th));  // [R][3][rows][T]; th counts the R restarts
         VRX_HIP(m->part_theta.alloc((size_t)m->R * m->nb_theta * 2 * VRX_MAXT));
         m->n_th_part = cfg->ase_mode ? m->nb_throws : 1;
     } else {
@@ -1498,7 +1499,8 @@ extern "C" int vrx_model_create(vrx_problem* p, const vrx_model_cfg* cfg, vrx_mo
     const size_t th_cap = (size_t)m->R * (cfg->kind == VRX_KIND_VIREO ? m->n_th_part : (m->NK * 16 + VRX_BLOCK - 1) / VRX_BLOCK + 1);
     VRX_HIP(m->part_th.alloc(th_cap));
     VRX_HIP(hipMemsetAsync(m->part_th.p, 0, th_cap * sizeof(double), s));
-    VRX_HIP(m->d_elbo.alloc((size_t)m->R * kMaxTrace));
+    m->trace_cap = kTraceInit;
+    VRX_HIP(m->d_elbo.alloc((size_t)m->R * m->trace_cap));
     VRX_HIP(m->ctl.alloc((size_t)m->R * VRX_CTL_WORDS));
     VRX_HIP(hipMemsetAsync(m->ctl.p, 0, (size_t)m->R * VRX_CTL_WORDS * sizeof(int32_t), s));
     VRX_HIP(m->d_parts.alloc((size_t)m->R * 4));
@@ -2248,7 +2250,7 @@ static VrxElboIn elbo_inputs(vrx_model* m) {
     e.n_th_part = m->n_th_part;
     e.elbo = m->d_elbo.p;
     e.parts = m->d_parts.p;
-    e.trace_stride = kMaxTrace;
+    e.trace_stride = m->trace_cap;
     return e;
 }
 
@@ -2347,9 +2349,12 @@ extern "C" int vrx_model_fit(vrx_model* m, int32_t max_iter, int32_t min_iter, d
                              int32_t delay_fit_theta, double* elbo_trace, int32_t* it_out,
                              int32_t* warn_flags) {
     VRX_REQUIRE(m && elbo_trace && it_out, "vrx_model_fit: null argument");
-    VRX_REQUIRE(max_iter >= 1 && max_iter <= kMaxTrace, "vrx_model_fit: max_iter must be in 1..%d",
-                kMaxTrace);
+    VRX_REQUIRE(max_iter >= 1, "vrx_model_fit: max_iter must be >= 1");
     VRX_HIP(hipSetDevice(m->p->device));
+    {   // (the reference takes any max_iter, vireo_model.py:251: its trace is np.zeros(max_iter))
+        int rc0 = ensure_trace(m, max_iter);
+        if (rc0) return rc0;
+    }
     hipStream_t s = m->p->stream;
     int rc;
     if ((rc = reset_ctl(m))) return rc;
@@ -2362,7 +2367,7 @@ extern "C" int vrx_model_fit(vrx_model* m, int32_t max_iter, int32_t min_iter, d
     // Polls are PIPELINED: batch b + 1 is enqueued before the host waits for the control words
     // batch b left, so the device never idles between batches (a 20-iteration restart used to
     // pay five drained queues).  VIREO_FIT_PIPELINE=0: wait before enqueuing, as before.
-    static const int pipeline = env_int("VIREO_FIT_PIPELINE", 1);
+    const int pipeline = env_int("VIREO_FIT_PIPELINE", 1);  // (read per call: the tests switch it)
     const int R = m->R;  // elbo_trace [R][max_iter], it_out [R], warn_flags [R]
     // two pinned read-back buffers of R * VRX_CTL_WORDS <= 64 words inside h_pin (64 doubles)
     int32_t* hbuf[2] = {reinterpret_cast<int32_t*>(m->h_pin), reinterpret_cast<int32_t*>(m->h_pin) + 64};
@@ -2415,7 +2420,7 @@ extern "C" int vrx_model_fit(vrx_model* m, int32_t max_iter, int32_t min_iter, d
         it = c[VRX_CTL_STOP] ? c[VRX_CTL_IT] : max_iter - 1;
         it_out[r] = it;
         if (warn_flags) warn_flags[r] = c[VRX_CTL_WARN];
-        VRX_HIP(hipMemcpyAsync(elbo_trace + (size_t)r * max_iter, m->d_elbo.p + (size_t)r * kMaxTrace,
+        VRX_HIP(hipMemcpyAsync(elbo_trace + (size_t)r * max_iter, m->d_elbo.p + (size_t)r * m->trace_cap,
                                (size_t)(it + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
     }
     VRX_HIP(hipStreamSynchronize(s));
@@ -2427,8 +2432,12 @@ extern "C" int vrx_model_fit(vrx_model* m, int32_t max_iter, int32_t min_iter, d
 
 extern "C" int vrx_model_run_iters(vrx_model* m, int32_t n_iter, int32_t theta_from_iter,
                                    double* elbo_trace, double* ms_out) {
-    VRX_REQUIRE(m && n_iter >= 1 && n_iter <= kMaxTrace, "vrx_model_run_iters: bad argument");
+    VRX_REQUIRE(m && n_iter >= 1, "vrx_model_run_iters: bad argument");
     VRX_HIP(hipSetDevice(m->p->device));
+    {
+        int rc0 = ensure_trace(m, n_iter);
+        if (rc0) return rc0;
+    }
     hipStream_t s = m->p->stream;
     int rc;
     if ((rc = reset_ctl(m))) return rc;
@@ -2446,7 +2455,7 @@ extern "C" int vrx_model_run_iters(vrx_model* m, int32_t n_iter, int32_t theta_f
     if (ms_out) *ms_out = ms;
     if (elbo_trace)  // [R][n_iter]
         for (int r = 0; r < m->R; ++r)
-            VRX_HIP(hipMemcpy(elbo_trace + (size_t)r * n_iter, m->d_elbo.p + (size_t)r * kMaxTrace,
+            VRX_HIP(hipMemcpy(elbo_trace + (size_t)r * n_iter, m->d_elbo.p + (size_t)r * m->trace_cap,
                               (size_t)n_iter * sizeof(double), hipMemcpyDeviceToHost));
     return prof_drain(m);
 }
@@ -2489,7 +2498,7 @@ extern "C" int vrx_model_step(vrx_model* m, int32_t which, double* elbo_out) {
             if ((rc = softmax_step(m, 0))) return rc;
             if ((rc = elbo_step(m, no_rule(0)))) return rc;
             for (int r = 0; r < m->R; ++r)  // elbo_out [R]
-                VRX_HIP(hipMemcpyAsync(m->h_pin + r, m->d_elbo.p + (size_t)r * kMaxTrace, sizeof(double),
+                VRX_HIP(hipMemcpyAsync(m->h_pin + r, m->d_elbo.p + (size_t)r * m->trace_cap, sizeof(double),
                                        hipMemcpyDeviceToHost, s));
             VRX_HIP(hipStreamSynchronize(s));
             for (int r = 0; r < m->R; ++r) elbo_out[r] = m->h_pin[r];
@@ -2537,7 +2546,10 @@ extern "C" int vrx_model_info(vrx_model* m, int32_t* info) {
     info[12] = c.tiled.ready ? c.tiled.form : 0;
     info[13] = v.tiled.ready ? (v.tiled.virt ? 3 : v.tiled.form) : 0;  // 3: AD/BD virtual rows
     info[14] = m->R;
-    info[15] = 0;
+    // longest wave stream / mean wave stream of each pass, x 1000: variant in the low, cell in the high half
+    const int32_t iv = v.tiled.ready ? (int32_t)std::min(65535.0, v.tiled.imbalance * 1000.0 + 0.5) : 0;
+    const int32_t ic = c.tiled.ready ? (int32_t)std::min(32767.0, c.tiled.imbalance * 1000.0 + 0.5) : 0;
+    info[15] = iv | (ic << 16);
     return VRX_OK;
 }
 

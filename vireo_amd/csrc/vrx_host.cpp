@@ -13,17 +13,33 @@
 //   MT19937 (Matsumoto & Nishimura 1998) with the genrand_res53 conversion
 //   (a >> 5, b >> 6) -> (a * 2^26 + b) / 2^53.
 #include <algorithm>
+#include <cstdarg>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "../../include/vireo_hip.h"
 
-void vrx_set_error(const char* fmt, ...);
+// ------------------------------------------------------------------------------------
+// errors: a thread-local message behind every non-zero status (include/vireo_hip.h)
+// ------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+void vrx_set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+extern "C" const char* vrx_last_error(void) { return g_last_error.c_str(); }
 
 namespace {
 constexpr int MT_N = 624, MT_M = 397;
@@ -519,9 +535,18 @@ inline const char* parse_i64(const char* p, const char* e, int64_t& out, bool& o
         ok = false;
         return p;
     }
-    int64_t v = 0;
-    while (p < e && *p >= '0' && *p <= '9') v = v * 10 + (*p++ - '0');
-    out = neg ? -v : v;
+    // (more digits than an int64 holds: not a count / an index of this format -- reject instead
+    //  of overflowing; found by the UBSan run, tests/test_host_sanitizers_cpu.py)
+    uint64_t v = 0;
+    while (p < e && *p >= '0' && *p <= '9') {
+        const uint64_t d = (uint64_t)(*p++ - '0');
+        if (v > ((uint64_t)INT64_MAX - d) / 10) {
+            ok = false;
+            return p;
+        }
+        v = v * 10 + d;
+    }
+    out = neg ? -(int64_t)v : (int64_t)v;
     return p;
 }
 }  // namespace
@@ -644,8 +669,10 @@ extern "C" int vrx_mtx_read(const char* path, int64_t nnz, int32_t* row, int32_t
                             buf[len] = 0;
                             char* stop = nullptr;
                             const double d = strtod(buf, &stop);
-                            v = (int64_t)d;
-                            ok = stop != buf && (double)v == d;
+                            // (range first: converting a double outside int64 is undefined)
+                            ok = stop != buf && d >= -2147483648.0 && d <= 2147483647.0;
+                            v = ok ? (int64_t)d : 0;
+                            ok = ok && (double)v == d;
                         }
                         if (!ok || r < 1 || r > h.rows || c < 1 || c > h.cols || v < INT32_MIN ||
                             v > INT32_MAX) {

@@ -80,6 +80,21 @@ class DeviceModel:
         _lib.check(_lib.lib().vrx_model_set_state_raw(self._h, dptr(ID_raw), dptr(GT_raw),
                                                       dptr(beta_mu), dptr(beta_sum)))
 
+    # staged uploads: the next restart's raw draws go up while this one fits
+    def stage_reserve(self):
+        _lib.check(_lib.lib().vrx_model_stage_reserve(self._h))
+
+    def stage_raw(self, buf, ID_raw, GT_raw):
+        """staging buffer ``buf`` (0 | 1) <- raw draws; thread-safe against a running ``fit``"""
+        ID_raw = self._check(ID_raw, (self.M, self.K), "ID_raw")
+        GT_raw = self._check(GT_raw, (self.N, self.K, self.T), "GT_raw")
+        _lib.check(_lib.lib().vrx_model_stage_raw(self._h, int(buf), dptr(ID_raw), dptr(GT_raw)))
+
+    def set_state_staged(self, buf, beta_mu=None, beta_sum=None):
+        beta_mu = self._check(beta_mu, self.theta_shape, "beta_mu")
+        beta_sum = self._check(beta_sum, self.theta_shape, "beta_sum")
+        _lib.check(_lib.lib().vrx_model_set_state_staged(self._h, int(buf), dptr(beta_mu), dptr(beta_sum)))
+
     def snapshot(self):
         """keep the current state in a device-side slot"""
         _lib.check(_lib.lib().vrx_model_snapshot(self._h, 0))
@@ -157,7 +172,9 @@ class DeviceModel:
                     ranges_variant=int(a[6]), ranges_cell=int(a[7]),
                     pad_variant=a[8] / 1000.0, pad_cell=a[9] / 1000.0,
                     extra_pieces_variant=int(a[10]), extra_pieces_cell=int(a[11]),
-                    cell_form=int(a[12]), var_form=int(a[13]), n_batch=int(a[14]))
+                    cell_form=int(a[12]), var_form=int(a[13]), n_batch=int(a[14]),
+                    imbalance_variant=(int(a[15]) & 0xffff) / 1000.0,
+                    imbalance_cell=(int(a[15]) >> 16) / 1000.0)
 
     # ---- timing -----------------------------------------------------------------------
     def profile(self, enable=True):
@@ -194,6 +211,7 @@ class DeviceBatch(DeviceModel):
         raise TypeError("not available on a restart batch; use set_restart / copy_to")
 
     set_state = set_state_raw = get_state = snapshot = restore = _single_only
+    stage_reserve = stage_raw = set_state_staged = _single_only
     get_loglik = set_loglik = _single_only
 
     def set_restart(self, r, ID=None, GT=None, beta_mu=None, beta_sum=None, raw=False):

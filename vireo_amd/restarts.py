@@ -12,6 +12,7 @@ double), uploads the raw draws, normalises them on the device in NumPy's summati
 runs all its restarts through ONE device model whose best state so far stays in HBM.
 """
 import ctypes as C
+import threading
 import time
 
 import numpy as np
@@ -97,6 +98,13 @@ def restart_batch(n_donor, n_owned, nnz, wide=True):
     return min(R for R, c in costs.items() if c <= 1.05 * best)
 
 
+class Staged:
+    """raw draws of one restart, already uploaded to staging buffer ``buf`` of the runner's model"""
+
+    def __init__(self, buf):
+        self.buf = buf
+
+
 class DeviceRestarts:
     """This rank's restarts on the device; the best fitted state is snapshotted device-side.
     ``template`` is a host ``Vireo`` carrying shapes, flags and priors (its own ID_prob /
@@ -125,6 +133,17 @@ class DeviceRestarts:
             self.db = DeviceBatch(counts, _lib.KIND_VIREO, template.n_donor, self.batch, **shape)
             template._set_device_prior(self.db)
         self.pending, self.done = [], {}
+        # one restart per model: the raw draws of the next restart are uploaded (``stage``, called
+        # from the thread that draws them) while the current one fits.  VIREO_STAGE_UPLOADS=0: off
+        self.can_stage = (self.batch == 1 and template.n_donor <= 128 and template.n_GT <= 128
+                          and os.environ.get("VIREO_STAGE_UPLOADS", "1") != "0")
+        if self.can_stage:
+            self.dm.stage_reserve()
+        self._n_staged = 0
+        # a staging buffer is free again once ``run`` has taken its content into the model's
+        # state: the producer thread waits for that (two buffers = two slots)
+        self._slots = threading.Semaphore(2)
+        self._cancel = threading.Event()
         self.const = counts.binom_const()
         self.best = None            # (elbo, restart index, trace)
         self.iterations = 0
@@ -184,15 +203,33 @@ class DeviceRestarts:
         done, self.done = self.done, {}
         return done
 
+    def stage(self, ID_raw, GT_raw):
+        """Upload one restart's raw draws into the next staging buffer -> a token for ``run``.
+        Called from the thread that produces the draws, possibly while ``run`` fits the restart
+        before; at most two staged restarts may be outstanding (the producer runs one ahead)."""
+        while not self._slots.acquire(timeout=0.05):
+            if self._cancel.is_set():
+                raise _lib.VrxError("restart search cancelled while staging an upload")
+        buf = self._n_staged & 1
+        self._n_staged += 1
+        with _phase("stage"):
+            self.dm.stage_raw(buf, ID_raw, GT_raw)
+        return Staged(buf)
+
     def run(self, im, ID_raw, GT_raw, ID_fixed, GT_fixed, max_iter, delay_fit_theta):
         """Fit restart ``im`` from raw draws (normalised on the device) or, where the caller
-        supplied initial values, from those (already normalised on the host).  Returns
-        ``ELBO_[-1]`` as ``Vireo.fit`` would leave it."""
+        supplied initial values, from those (already normalised on the host).  ``ID_raw`` may be a
+        ``Staged`` token (the draws are already on the device).  Returns ``ELBO_[-1]`` as
+        ``Vireo.fit`` would leave it."""
         mu, sm = self._theta0()
         with _phase("upload+normalise"):
-            if ID_fixed is not None or GT_fixed is not None:
-                self.dm.set_state(ID_fixed, GT_fixed, None, None)
-            self.dm.set_state_raw(ID_raw, GT_raw, mu, sm)
+            if isinstance(ID_raw, Staged):
+                self.dm.set_state_staged(ID_raw.buf, mu, sm)
+                self._slots.release()
+            else:
+                if ID_fixed is not None or GT_fixed is not None:
+                    self.dm.set_state(ID_fixed, GT_fixed, None, None)
+                self.dm.set_state_raw(ID_raw, GT_raw, mu, sm)
         with _phase("fit"):
             trace, it, _ = self.dm.fit(max_iter, 5, 1e-2, delay_fit_theta)
         self.iterations += it + 1
@@ -219,7 +256,12 @@ class DeviceRestarts:
             t._pull(self.dm, want_GT=True)
         return t
 
+    def cancel(self):
+        """wake a producer thread that waits for a staging buffer (the search is being abandoned)"""
+        self._cancel.set()
+
     def close(self):
+        self._cancel.set()
         self.dm.close()
         if self.db is not None:
             self.db.close()

@@ -26,6 +26,14 @@ CONFIGS = {
 }
 
 
+# Heavy-tailed companion of c3: the same shape, donors and target density,
+# but per-variant coverage and per-cell depth drawn with log-normal weights (sigma 1.0 / 0.7) --
+# what a real cellSNP matrix looks like (vireoSNP/utils/io_utils.py:42-59 loads those): row
+# lengths from a handful to tens of thousands, counts in the hundreds where popular variants
+# meet deep cells.  ``donor_workload(*CONFIGS["c3"], seed=0, skew=C3_SKEW)``.
+C3_SKEW = (1.0, 0.7)
+
+
 def _skewed_draw(rng, n, size, sigma):
     """indices in [0, n) with log-normal(sigma) weights: heavy-tailed coverage / depth"""
     w = rng.lognormal(0.0, sigma, n)

@@ -61,12 +61,19 @@ def _template(counts, n_donor, learn_GT, GT_prior, kwargs, **state):
     n_var, n_cell = counts.shape
     n_GT = kwargs.get("n_GT", 3)
     rows = n_var if kwargs.get("ASE_mode", False) else 1
-    init = dict(ID_prob_init=np.ones((n_cell, n_donor)),
-                GT_prob_init=np.ones((n_var, n_donor, n_GT)) if GT_prior is None else GT_prior)
+    # placeholders: ONE row each through the constructor (it normalises what it is given: 45 MB
+    # of ones at c3, 27 ms per vireo_wrap), then untouched arrays of the full shape -- a fitted
+    # device state or a broadcast replaces them before anything reads them
+    init = dict(ID_prob_init=np.ones((1, n_donor)),
+                GT_prob_init=np.ones((1, n_donor, n_GT)) if GT_prior is None else GT_prior)
     init.update({k: v for k, v in kwargs.items() if k in _INIT_KEYS and v is not None})
     init.update(state)
     flags = {k: v for k, v in kwargs.items() if k not in _INIT_KEYS}
     m = Vireo(n_var=n_var, n_cell=n_cell, n_donor=n_donor, learn_GT=learn_GT, **init, **flags)
+    if m.ID_prob.shape[0] != n_cell:
+        m.ID_prob = np.empty((n_cell, n_donor))
+    if m.GT_prob.shape[0] != n_var:
+        m.GT_prob = np.empty((n_var, n_donor, n_GT))
     m.set_prior(GT_prior=GT_prior)
     assert m.beta_mu.shape[0] in (1, rows)
     return m
@@ -151,6 +158,8 @@ def _search(counts, plan, comm, max_iter_init, delay_fit_theta, kwargs, restarts
         else:
             runner, batch = restarts_cls(counts, tmpl), 1
 
+    stage = runner.stage if batch == 1 and getattr(runner, "can_stage", False) else None
+
     def draws():
         """this rank's restarts in order, each with what its constructor draws; the draws of
         the other ranks' restarts are consumed without being formed -- runs of them in ONE skip
@@ -163,8 +172,13 @@ def _search(counts, plan, comm, max_iter_init, delay_fit_theta, kwargs, restarts
                     if im > consumed:
                         stream.skip((im - consumed) * per_restart)
                     consumed = im + 1
-                    yield (im, stream.rand(n_cell, K) if ID0 is None else None,
-                           stream.rand(n_var, K, T) if GT0 is None else None)
+                    ID_raw = stream.rand(n_cell, K) if ID0 is None else None
+                    GT_raw = stream.rand(n_var, K, T) if GT0 is None else None
+                    if stage is not None and ID_raw is not None and GT_raw is not None:
+                        # (this generator runs on the helper thread: the upload overlaps the fit
+                        #  of the restart before, restarts.DeviceRestarts.stage)
+                        ID_raw, GT_raw = stage(ID_raw, GT_raw), None
+                    yield (im, ID_raw, GT_raw)
         finally:
             # the global stream ends where the reference's would (all n_init constructors run
             # before the first fit, vireo_wrap.py:66-71) -- also when the consumer stops early
@@ -175,13 +189,18 @@ def _search(counts, plan, comm, max_iter_init, delay_fit_theta, kwargs, restarts
     t_search = time.perf_counter()
     # the generator runs one restart ahead on a helper thread: the Mersenne Twister (host, serial)
     # and the fit (device) overlap; the helper is the only user of the stream meanwhile
-    for im, ID_raw, GT_raw in _one_ahead(draws(), depth=batch):
-        args = (im, ID_raw, GT_raw, ID0, GT0_first if im == 0 else GT0, max_iter_init,
-                delay_fit_theta)
-        if batch > 1:
-            runner.submit(*args)         # fitted `batch` at a time
-        else:
-            local[im] = runner.run(*args)
+    try:
+        for im, ID_raw, GT_raw in _one_ahead(draws(), depth=batch):
+            args = (im, ID_raw, GT_raw, ID0, GT0_first if im == 0 else GT0, max_iter_init,
+                    delay_fit_theta)
+            if batch > 1:
+                runner.submit(*args)         # fitted `batch` at a time
+            else:
+                local[im] = runner.run(*args)
+    except BaseException:
+        if hasattr(runner, "cancel"):        # (the helper thread may be waiting for a staging buffer)
+            runner.cancel()
+        raise
     if batch > 1:
         local.update(runner.flush())
     if restarts_mod.PHASES is not None:
