@@ -354,33 +354,39 @@ def main():
         c4 = c4_leg(counts, K, comm)
         preceded_by.append("c4 leg (vireo_wrap n_init=32 on the same data: ~0.6 s of fits)")
 
-    if solo and not args.no_cpu:     # (N = 1 only: the other ranks would wait)
-        # Whole-protocol parity, GPU half: the same fit the CPU oracle runs after the timed region,
-        # and the same fit from an initial ID_prob perturbed by 1e-13 relative (the size of the
-        # GPU/CPU difference over the first iterations): the first iterations leave a symmetric,
-        # unstable state (posteriors uniform to ~3e-7) and rounding-order differences are
-        # amplified while the clusters form; no two implementations can agree better mid-trace
-        # than this self-sensitivity.
-        # The two fits are Vireo._fit_VB taken apart -- device model + upload first, the fit
-        # itself here, the download after the timed region -- so that the LAST thing the chip does
-        # before the warm-up is 2 x 20 iterations of this very workload with no host work in
-        # between: on this part a 5-ms pause (one 45-MB upload) is enough for the clocks to drop,
-        # and the next ~15 ms then run ~10 % slow (scratch/gap_probe.py).
-        np.random.seed(1)
-        dev = Vireo(n_var=N, n_cell=M, n_donor=K)
+    # The whole timing protocol _fit_VB(min_iter=5, max_iter=20, delay_fit_theta=3) of this rank's
+    # restart, on a second device model from the same constructor draws: what vireo_wrap runs per
+    # restart (vireo_wrap.py:84-87) and, on rank 0 at N = 1, the GPU half of the parity check (the
+    # CPU oracle runs the same fit after the timed region).  It is Vireo._fit_VB taken apart --
+    # device model + upload first, the fit here, the download after the timed region -- so that the
+    # LAST thing the chip does before the warm-up is 20 (rank 0, N = 1: 2 x 20) iterations of
+    # this very workload with no host work in between: on this part a 5-ms pause (one 45-MB
+    # upload) is enough for the clocks to drop, and the next ~15 ms then run ~10 % slow
+    # (scratch/gap_probe.py).
+    fit_args = (PROTOCOL["max_iter"], PROTOCOL["min_iter"], 1e-2, PROTOCOL["delay_fit_theta"])
+    proto_dm, _ = host._device_model(counts, None)
+    pert_dm = None
+    if solo and not args.no_cpu:     # (N = 1 only: the other ranks would wait for the oracle)
+        # the same fit from an initial ID_prob perturbed by 1e-13 relative (the size of the GPU/CPU
+        # difference over the first iterations): the first iterations leave a symmetric, unstable
+        # state (posteriors uniform to ~3e-7) and rounding-order differences are amplified while
+        # the clusters form; no two implementations can agree better mid-trace than this
         np.random.seed(1)
         pert = Vireo(n_var=N, n_cell=M, n_donor=K)
         pert.ID_prob = pert.ID_prob * (1.0 + 1e-13 * np.random.default_rng(7).standard_normal(pert.ID_prob.shape))
-        dev_dm, _ = dev._device_model(counts, None)
         pert_dm, _ = pert._device_model(counts, None)
-        fit_args = (PROTOCOL["max_iter"], PROTOCOL["min_iter"], 1e-2, PROTOCOL["delay_fit_theta"])
-        tg = time.perf_counter()
-        gfull, git, _ = dev_dm.fit(*fit_args)
-        tg = time.perf_counter() - tg
+        del pert
+    tg = time.perf_counter()
+    gfull, git, _ = proto_dm.fit(*fit_args)
+    tg = time.perf_counter() - tg
+    n_pre = 1
+    if pert_dm is not None:
         pfull, pit, _ = pert_dm.fit(*fit_args)
-        parity_gpu = (dev, dev_dm, gfull[:git], pert_dm, pfull[:pit], tg)
-        preceded_by.append("whole-protocol parity fits on the GPU (2 x %d iterations; their "
-                           "results are downloaded after the timed region)" % (git + 1))
+        parity_gpu = (host, proto_dm, gfull[:git], pert_dm, pfull[:pit], tg)
+        n_pre = 2
+    preceded_by.append("whole-protocol fit of this rank's restart on the GPU (%d x %d iterations%s)"
+                       % (n_pre, git + 1, "; the parity check downloads their results after the timed region"
+                          if pert_dm is not None else ""))
 
     if args.warmup > 0:
         dm.run_iters(args.warmup, theta_from_iter=PROTOCOL["delay_fit_theta"])
@@ -393,6 +399,7 @@ def main():
     walls = comm.allgather(np.array([wall]))
     wall_max = float(np.max(walls))
     last_elbos = comm.allgather(np.array([trace[-1]]))            # the restart-shard exchange
+    proto_elbos = comm.allgather(np.array([gfull[git - 1]]))      # ELBO[:it][-1] of every rank's protocol fit
     # spread of the number above: the same K iterations four more times (not part of `value`)
     repeats = [wall / args.steps * 1e3]
     for _ in range(4):
@@ -408,6 +415,8 @@ def main():
     dm.profile(False)
     kinfo = dm.info()
     dm.close()
+    if parity_gpu is None:
+        proto_dm.close()
 
     c3_skew = None
     if solo and not args.no_c4 and args.config == "c3":
@@ -519,6 +528,7 @@ def main():
                        "N": N, "M": M, "K": K, "nnz": nnz, "device": info["name"],
                        "restart_elbos": [float(x) for x in np.ravel(last_elbos)],
                        "best_restart": int(np.argmax(last_elbos)),
+                       "restart_protocol_elbos": [float(x) for x in np.ravel(proto_elbos)],
                        "host_setup_s": {"generate": round(t_gen, 1), "upload+transpose": round(t_up, 1)}},
             "roofline": {"bound": "hbm",
                          "kernel": "%s (%s pass)" % (

@@ -250,7 +250,10 @@ def test_config3_whole_protocol_trace_vs_oracle(va):
     xg = g["GT_prob_sample"]
     top2 = np.sort(xg, axis=2)
     decided = top2[:, :, 2] - top2[:, :, 1] > 4.0 * np.abs(st.GT_prob[sl] - xg).max()
-    assert decided.mean() > 0.9
+    # (a donor column without cells keeps the uniform genotype prior -- an exact tie; when the
+    #  protocol stops after 20 iterations, 6 of the 16 columns are still empty)
+    used = np.bincount(g["assign"], minlength=K) > 0
+    assert used.sum() >= 2 and decided[:, used].mean() > 0.9 and not decided[:, ~used].any()
     assert np.array_equal(dev.GT_prob[sl].argmax(2)[decided], xg.argmax(2)[decided])
     # ... and over ALL variants the GPU's calls equal the oracle's wherever the oracle's own
     # posterior is decided by more than that margin
@@ -264,7 +267,8 @@ def test_config4_restart_search_n_init32(va):
     check_doublet=False) on the c3 data (vireo_wrap.py:64-94).  Every restart must be the fit the
     reference would run from the i-th constructor's draws: checked against independent
     ``Vireo.fit`` calls from those draws (bitwise: same kernels, same order), for restart 0 (the
-    single-restart timing protocol), three others and the winner; the winner is the FIRST
+    single-restart timing protocol), three others and the winner -- and those three others meet
+    the oracle for one iteration from their fitted state; the winner is the FIRST
     maximum of LB_list, and the returned state is that restart refined by
     ``fit(min_iter=5)`` (vireo_wrap.py:93)."""
     import contextlib
@@ -293,6 +297,33 @@ def test_config4_restart_search_n_init32(va):
             del m
     for i in check:
         assert fitted[i].ELBO_[-1] == LB[i], (i, fitted[i].ELBO_[-1], LB[i])
+    # restarts 7 / 19 / 31 meet the ORACLE too: one oracle iteration from the state the
+    # restart's 20-iteration fit left against one GPU iteration from the same state
+    AD, DP = synth.as_scipy(w)
+    for i in (7, 19, 31):
+        m = fitted[i]
+        st = O.vireo_new(M, N, K, ID_prob_init=m.ID_prob, GT_prob_init=m.GT_prob,
+                         beta_mu_init=m.beta_mu.copy(), beta_sum_init=m.beta_sum.copy())
+        st.ID_prob, st.GT_prob = m.ID_prob.copy(), m.GT_prob.copy()
+        O.vireo_theta_step(st, AD, DP)
+        O.vireo_gt_step(st, AD, DP)
+        L = O.vireo_id_step(st, AD, DP)
+        elbo_ref = O.vireo_elbo(st, L)
+        g = va.Vireo(n_var=N, n_cell=M, n_donor=K, ID_prob_init=m.ID_prob.copy(), GT_prob_init=m.GT_prob.copy(),
+                     beta_mu_init=m.beta_mu.copy(), beta_sum_init=m.beta_sum.copy())
+        g.ID_prob, g.GT_prob = m.ID_prob.copy(), m.GT_prob.copy()      # (exactly the fitted state)
+        g.update_theta_size(counts, None)
+        g.update_GT_prob(counts, None)
+        Lg = g.update_ID_prob(counts, None)
+        elbo_gpu = g.get_ELBO(Lg, counts, None)
+        np.testing.assert_allclose(g.beta_mu, st.beta_mu, rtol=RTOL)
+        np.testing.assert_allclose(g.beta_sum, st.beta_sum, rtol=RTOL)
+        np.testing.assert_allclose(g.GT_prob, st.GT_prob, rtol=RTOL, atol=1e-290)
+        np.testing.assert_allclose(g.ID_prob, st.ID_prob, rtol=RTOL, atol=1e-290)
+        np.testing.assert_allclose(Lg, L, rtol=1e-9)
+        np.testing.assert_allclose(elbo_gpu, elbo_ref, rtol=RTOL)
+        assert np.array_equal(g.ID_prob.argmax(1), st.ID_prob.argmax(1))
+        del st, g
     # restart 0 is the timing protocol of bench.py (the same seed, the first constructor)
     np.random.seed(1)
     m0 = va.Vireo(n_var=N, n_cell=M, n_donor=K)

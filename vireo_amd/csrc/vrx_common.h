@@ -96,6 +96,8 @@ struct TiledStream {
     DevBuf<int32_t> bnd;
     DevBuf<int32_t> rowmap;   // tile position -> piece (-1 = padding), pieces sorted by length
     DevBuf<int32_t> vptr;     // row -> its pieces [vptr[r], vptr[r+1]) (only when split)
+    DevBuf<int32_t> split_rows;  // the rows with more than one piece (vrx_fold_split)
+    int64_t n_split = 0;
     int64_t n_vrows = 0;      // pieces (== rows unless split)
     bool split = false;       // some row is cut into several pieces
     double pad_ratio = 0.0;   // stream words per entry

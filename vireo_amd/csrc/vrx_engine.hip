@@ -437,6 +437,10 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
     const int64_t n_vrows = vptr[(size_t)o_n_rows];
     t.n_vrows = n_vrows;
     t.split = n_vrows != o_n_rows;
+    std::vector<int32_t> split_rows;  // rows cut into several pieces: folded by vrx_fold_split
+    for (int64_t r = 0; r < o_n_rows; ++r)
+        if (vptr[(size_t)r + 1] - vptr[(size_t)r] > 1) split_rows.push_back((int32_t)r);
+    t.n_split = (int64_t)split_rows.size();
     std::vector<int32_t> vrow_row((size_t)n_vrows);
     for (int64_t r = 0; r < o_n_rows; ++r)
         for (int32_t v = vptr[(size_t)r]; v < vptr[(size_t)r + 1]; ++v) vrow_row[(size_t)v] = (int32_t)r;
@@ -587,7 +591,10 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
             A, seg_lo.p, seg_hi.p, rlen.p, t.bnd.p, t.wave_start.p, t.ent.p);
         VRX_HIP(hipGetLastError());
         VRX_HIP(t.rowmap.upload(rowmap.data(), rowmap.size(), s));
-        if (t.split) VRX_HIP(t.vptr.upload(vptr.data(), vptr.size(), s));
+        if (t.split) {
+            VRX_HIP(t.vptr.upload(vptr.data(), vptr.size(), s));
+            VRX_HIP(t.split_rows.upload(split_rows.data(), split_rows.size(), s));
+        }
         VRX_HIP(hipMemcpyAsync(bnd.data(), t.bnd.p, bnd.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         VRX_HIP(hipStreamSynchronize(s));
         const int rc = plan_items(t, bnd.data(), n_wave, NR * PH, n_cu, rowmap.data(), mode, s);
@@ -749,7 +756,10 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
     VRX_HIP(t.wave_start.upload(wave_start.data(), wave_start.size(), s));
     VRX_HIP(t.bnd.upload(bnd.data(), bnd.size(), s));
     VRX_HIP(t.rowmap.upload(rowmap.data(), rowmap.size(), s));
-    if (t.split) VRX_HIP(t.vptr.upload(vptr.data(), vptr.size(), s));
+    if (t.split) {
+        VRX_HIP(t.vptr.upload(vptr.data(), vptr.size(), s));
+        VRX_HIP(t.split_rows.upload(split_rows.data(), split_rows.size(), s));
+    }
     VRX_HIP(hipStreamSynchronize(s));
     const int rc = plan_items(t, bnd.data(), n_wave, NR * PH, n_cu, rowmap.data(), mode, s);
     if (rc) return rc;
@@ -982,6 +992,7 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
             o->tiled.bnd.release();
             o->tiled.rowmap.release();
             o->tiled.vptr.release();
+            o->tiled.split_rows.release();
             o->tiled.items.release();
             o->tiled.wg_first.release();
             o->tiled.npiece.release();
@@ -2013,7 +2024,8 @@ static int launch_spmm_lds(vrx_model* m, const Orient& o, const double* X, int K
     int rc;
     rc = launch_lds_one<VRX_LDS_LPE, MODE>(o, s, X, K, dst, m->ctl.p, m->R);  // K < 16 leaves lanes idle
     if (rc) return rc;
-    if (t.split) {  // rows cut into pieces: sum pieces and ranges in one fixed order
+    if (t.split && !(MODE == 1 && defer_sum)) {  // rows cut into pieces: sum pieces and ranges in one fixed order
+        // (the cell pass's consumer, vrx_cell_softmax, sums the pieces itself when asked to: defer_sum)
         const int64_t n = o.n_rows * K * NV;
         if ((int64_t)t.n_range * t.n_vrows >= 64 * o.n_rows)  // >= 64 terms per row on average
             vrx_sum_pieces_wave<<<(unsigned)((n * 64 + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
@@ -2085,7 +2097,7 @@ static int variant_pass(vrx_model* m, bool defer_sum = false) {
 static int cell_pass(vrx_model* m, bool defer_sum = false) {
     ProfScope ps(m, VRX_KERN_CELL_PASS);
     if (lds_eligible<1>(m->p->by_cell, m->Kt)) {
-        m->l_pending = defer_sum && m->p->by_cell.tiled.n_range > 1 && !m->p->by_cell.tiled.split;
+        m->l_pending = defer_sum && (m->p->by_cell.tiled.n_range > 1 || m->p->by_cell.tiled.split);
         return launch_spmm_lds<1>(m, m->p->by_cell, m->W.p, m->Kt, m->LID.p, m->RC.p, defer_sum);
     }
     return launch_spmm<1>(m, m->p->by_cell, m->W.p, m->Kt, m->LID.p, m->PC.p);
@@ -2116,6 +2128,17 @@ static int cell_pass_softmax(vrx_model* m) {
     return launch_spmm<1>(m, o, m->W.p, m->Kt, m->LID.p, m->PC.p, &F);
 }
 
+// the rows a tiled stream cut into pieces: sum of all their terms -> slot 0 of the first piece
+// (vrx_fold_split), for the consumers that sum the partial arrays themselves
+static int fold_split(vrx_model* m, const TiledStream& t, double* partial) {
+    if (t.n_split == 0) return VRX_OK;
+    const int64_t lanes = t.n_split * m->Kt * 8;  // eight lanes per (split row, column)
+    vrx_fold_split<<<(unsigned)((lanes + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, m->p->stream>>>(
+        t.n_split, t.split_rows.p, m->Kt, t.n_vrows, t.vptr.p, t.npiece.p, partial, m->ctl.p, m->R);
+    VRX_HIP(hipGetLastError());
+    return VRX_OK;
+}
+
 // a consumer that cannot fuse the range sum forms S / logLik_ID explicitly
 static int resolve_S(vrx_model* m) {
     if (!m->s_pending) return VRX_OK;
@@ -2140,6 +2163,11 @@ static int resolve_S(vrx_model* m) {
 static int resolve_LID(vrx_model* m) {
     if (!m->l_pending) return VRX_OK;
     const int64_t n = m->M * m->Kt;
+    const TiledStream& tc = m->p->by_cell.tiled;
+    if (tc.split)
+        vrx_sum_pieces<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, m->p->stream>>>(
+            m->M, m->Kt, tc.n_range, tc.n_vrows, tc.vptr.p, tc.npiece.p, m->RC.p, m->LID.p, m->ctl.p, m->R);
+    else
     vrx_sum_ranges<<<(unsigned)((n + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, m->p->stream>>>(
         n, m->Kt, m->p->by_cell.tiled.npiece.p, m->RC.p, m->LID.p, m->ctl.p, m->R);
     VRX_HIP(hipGetLastError());
@@ -2179,8 +2207,8 @@ static int theta_step(vrx_model* m, int update, bool defer_final = false) {
     } else {
         if (update) {
             const TiledStream& tv = m->p->by_var.tiled;
-            if (m->s_pending && tv.virt && tv.split) {  // (pieces of long rows: the general sum first)
-                int rc = resolve_S(m);
+            if (m->s_pending && tv.virt && tv.split) {  // rows cut into pieces: their terms first
+                int rc = fold_split(m, tv, m->RV.p);
                 if (rc) return rc;
             }
             const uint16_t* np = m->s_pending ? tv.npiece.p : nullptr;
@@ -2188,6 +2216,7 @@ static int theta_step(vrx_model* m, int update, bool defer_final = false) {
             kern<<<dim3(m->nb_theta, m->R), VRX_BLOCK, 0, s>>>(
                 m->NK, m->T, reinterpret_cast<double2*>(m->S.p), np,
                 reinterpret_cast<const double2*>(m->RV.p), m->s_pending && tv.virt ? tv.n_vrows : 0,
+                m->s_pending && tv.virt && tv.split ? tv.vptr.p : nullptr,
                 m->GT.p, m->part_theta.p, m->batch(), m->ctl.p);
             VRX_HIP(hipGetLastError());
             m->s_pending = false;
@@ -2266,13 +2295,20 @@ static int softmax_step(vrx_model* m, int update) {
     ProfScope ps(m, VRX_KERN_DENSE);
     hipStream_t s = m->p->stream;
     const double lu = -std::log((double)m->K);
-    const uint16_t* nr = m->l_pending ? m->p->by_cell.tiled.npiece.p : nullptr;  // fused sum of the partials
+    const TiledStream& tcs = m->p->by_cell.tiled;
+    if (m->l_pending && tcs.split) {  // rows cut into pieces: their terms first
+        int rc = fold_split(m, tcs, m->RC.p);
+        if (rc) return rc;
+    }
+    const uint16_t* nr = m->l_pending ? tcs.npiece.p : nullptr;  // fused sum of the partials
+    const int32_t* vp = m->l_pending && tcs.split ? tcs.vptr.p : nullptr;  // ... of the pieces of long rows too
+    const int64_t nvr = m->l_pending ? tcs.n_vrows : m->M;
     m->l_pending = false;
     m->n_cell_part = m->nb_cell;
 #define VRX_SM_CASE(KPV)                                                                        \
     case KPV:                                                                                   \
         vrx_cell_softmax<KPV><<<dim3(m->nb_cell, m->R), VRX_BLOCK, 0, s>>>(                     \
-            m->M, m->K, update, m->LID.p, nr, m->RC.p, m->logq_id.p, m->id_mode, lu, m->ID.p,   \
+            m->M, m->K, update, m->LID.p, nr, m->RC.p, vp, nvr, m->logq_id.p, m->id_mode, lu, m->ID.p, \
             m->part_cell.p, m->batch(), m->ctl.p);                                              \
         break;
     switch (m->KP) {

@@ -1105,6 +1105,47 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_pieces_wave(
     if (lane == 0) out[i] = s;
 }
 
+// Rows that were cut into pieces (heavy-tailed data: ~10 % of the rows at c3 size), ahead of a
+// consumer that sums the partial arrays itself (vrx_theta_partial, vrx_cell_softmax): EIGHT lanes
+// per (split row, column) add the row's terms -- lane l the terms l, l + 8, ... in (slot, piece)
+// order, then three butterfly steps -- and leave the sum in slot 0 of the row's first piece, where
+// the consumer reads ONE value for the row.  A typical split row has 2-3 pieces x <= 3 slots
+// (one load per lane), the longest ~100 terms.  (Measured at c3 size, dense kernels per iteration:
+// the consumers' own per-thread loop over the terms 0.20 ms; one wavefront per element 0.27 ms --
+// 400 k waves of a few dependent loads each; this form: see DESIGN.md 4.2.)
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_fold_split(
+    int64_t n_split, const int32_t* __restrict__ split_rows, int width, int64_t n_vrows,
+    const int32_t* __restrict__ vptr, const uint16_t* __restrict__ npiece, double* partial,
+    const int32_t* __restrict__ ctl, int n_batch) {
+    if (vrx_all_stopped(ctl, n_batch)) return;
+    const int64_t i = ((int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x) >> 3;
+    const int sub = threadIdx.x & 7;
+    const bool live = i < n_split * width;  // (idle groups stay: the group sum below wants whole waves)
+    const int64_t j = live ? i / width : 0;
+    const int c = (int)(i - j * width);
+    const int64_t row = live ? split_rows[j] : 0;
+    const int v0 = live ? vptr[row] : 0, np = live ? vptr[row + 1] - v0 : 0;
+    int most = 0;
+    for (int q = sub; q < np; q += 8) most = max(most, (int)npiece[v0 + q]);
+    most = max(most, __shfl_xor(most, 1, 64));
+    most = max(most, __shfl_xor(most, 2, 64));
+    most = max(most, __shfl_xor(most, 4, 64));
+    const int nt = most * np;
+    double s = 0.0;
+    for (int t0 = sub; t0 < nt; t0 += 32) {  // four loads in flight per lane
+        double x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + 8 * u, r = t / max(np, 1), v = v0 + (t - r * np);
+            x[u] = t < nt && r < npiece[v] ? partial[((int64_t)r * n_vrows + v) * width + c] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += x[u];
+    }
+    s = vrx_group_sum<8>(s);
+    if (live && sub == 0) partial[(int64_t)v0 * width + c] = s;
+}
+
 // partial[slot][row][width] summed in slot order over the npiece[row] partial arrays that hold a
 // term of the row (the pieces its tile was cut into, TiledStream::items)
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_ranges(int64_t n, int width,
@@ -1320,8 +1361,9 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_final(int n_part, int T, 
 template <int TT>  // genotype classes: 3 exactly (no per-class branches), or VRX_MAXT = any T
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_partial(
     int64_t NK, int T, double2* S, const uint16_t* __restrict__ npiece,
-    const double2* __restrict__ ranges, int64_t n_virtual, const double* __restrict__ GT,
-    double* __restrict__ part, VrxBatch B, const int32_t* __restrict__ ctl) {
+    const double2* __restrict__ ranges, int64_t n_virtual, const int32_t* __restrict__ vptr,
+    const double* __restrict__ GT, double* __restrict__ part, VrxBatch B,
+    const int32_t* __restrict__ ctl) {
     const int rb = blockIdx.y;
     const int Tn = TT == VRX_MAXT ? T : TT;
     const int stop = ctl[rb * VRX_CTL_WORDS + VRX_CTL_STOP];
@@ -1364,17 +1406,28 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_partial(
             double sk[2];
 #pragma unroll
             for (int kind = 0; kind < 2; ++kind) {
-                const int64_t v = 2 * n + kind;
-                const int nr = npiece[v];
-                const double* src = P + v * B.Kt + col;
+                // vptr != null: long rows are cut into pieces (heavy-tailed data); virtual row
+                // 2n + kind is the pieces [vptr[.], vptr[. + 1]), whose terms vrx_fold_split has
+                // summed beforehand (one wave per row and column: a long row has ~100 terms)
+                const int64_t vr = 2 * n + kind;
+                const int64_t v = vptr ? vptr[vr] : vr;
+                const int np = vptr ? vptr[vr + 1] - (int)v : 1;
                 double t = 0.0;
-                for (int r0 = 0; r0 < nr; r0 += 8) {
-                    double x[8];
+                if (np == 1) {
+                    const int nr = npiece[v];
+                    const double* src = P + v * B.Kt + col;
+                    for (int r0 = 0; r0 < nr; r0 += 8) {
+                        double x[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) x[u] = r0 + u < nr ? src[(int64_t)(r0 + u) * n_virtual * B.Kt] : 0.0;
+                        for (int u = 0; u < 8; ++u) x[u] = r0 + u < nr ? src[(int64_t)(r0 + u) * n_virtual * B.Kt] : 0.0;
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (r0 + u < nr) t += x[u];
+                        for (int u = 0; u < 8; ++u)
+                            if (r0 + u < nr) t += x[u];
+                    }
+                } else if (np > 1) {
+                    // (a row cut into pieces: vrx_fold_split has left its whole sum in slot 0 of
+                    //  its first piece)
+                    t = P[v * B.Kt + col];
                 }
                 sk[kind] = t;
             }
@@ -1896,7 +1949,7 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_elbo_final(VrxElboIn e, VrxStop
 template <int KP>
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_cell_softmax(
     int64_t M, int K, int update, double* LID, const uint16_t* __restrict__ npiece,
-    const double* __restrict__ ranges,
+    const double* __restrict__ ranges, const int32_t* __restrict__ vptr, int64_t n_vrows,
     const double* __restrict__ logq, int id_mode, double logq_uni, double* __restrict__ ID,
     double* __restrict__ part, VrxBatch B, const int32_t* __restrict__ ctl) {
     const int rb = blockIdx.y;
@@ -1911,14 +1964,20 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_cell_softmax(
     const bool pre = live && npiece == nullptr && kl < K;
     const double L_pre = pre ? Lr[kl] : 0.0;
     if (stop) return;
-    const int n_range = live && npiece ? npiece[cell] : 0;
-    if (n_range > 0)
+    // npiece != null: logLik_ID still sits in the pass's partial arrays [slot][piece][Kt] (n_vrows
+    // pieces; vptr == null: piece = cell).  A cell that was cut into several pieces (heavy-tailed
+    // data) has been summed by vrx_fold_split.
+    const int64_t pv0 = live && npiece ? (vptr ? vptr[cell] : cell) : 0;
+    const int np = live && npiece ? (vptr ? vptr[cell + 1] - (int)pv0 : 1) : 0;
+    const int64_t col0 = (int64_t)rb * K;
+    if (np == 1) {
+        const int n_range = npiece[pv0];
         for (int k = kl; k < K; k += KP) {
             // the loads of 8 ranges are issued together (one memory round trip instead of 8);
             // the additions keep the range order
             double t = 0.0;
-            const double* src = ranges + row0 + k;
-            const int64_t stride = M * B.Kt;
+            const double* src = ranges + pv0 * B.Kt + col0 + k;
+            const int64_t stride = n_vrows * B.Kt;
             for (int r0 = 0; r0 < n_range; r0 += 8) {
                 double v[8];
 #pragma unroll
@@ -1929,6 +1988,10 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_cell_softmax(
             }
             Lr[k] = t;
         }
+    } else if (np > 1) {
+        // (a cell cut into pieces: vrx_fold_split has left its whole sum in slot 0 of its first piece)
+        for (int k = kl; k < K; k += KP) Lr[k] = ranges[pv0 * B.Kt + col0 + k];
+    }
     const double* qr = id_mode == 2 ? logq + (live ? cell : 0) * (int64_t)K : logq;
     double mx = -__builtin_inf();
     if (live)
