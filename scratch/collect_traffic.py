@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 config = sys.argv[1] if len(sys.argv) > 1 else "c3"
-prefix = sys.argv[2] if len(sys.argv) > 2 else "profiles/r03"
+prefix = sys.argv[2] if len(sys.argv) > 2 else "profiles/r04"
 cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu", "--no-c4", "--steps", "3", "--warmup", "1",
        "--config", config]
 if config == "c5":      # BinomMixtureVB clone mode (BASELINE.json configs[4]): its own driver
