@@ -879,6 +879,47 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
 #pragma unroll
                         for (int u = 0; u < NE; ++u) w[u] = qq[u];
                     }
+                    if constexpr (NQ == 1) {
+                        // EXPERIMENT BUILDS ONLY (-DVRX_LDS_LPE_DEF=8: rounds of 8 rows, 8 lanes and 2
+                        // columns each): one 16-B slice per word and lane
+                        vrx_d2 y[NE];
+                        if (NE == 4) asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[NE - 1]));
+                        if (NE == 3) asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[NE - 1]));
+                        if (NE == 2) asm volatile("" : "+v"(w[0]), "+v"(w[NE - 1]));
+                        uint32_t b0, b1;
+#define VRX_R1(X0, W, A) "v_and_or_b32 " A ", " W ", %[msk], %[q0]\n\tds_read_b128 " X0 ", " A "\n\t"
+                        if constexpr (NE == 4)
+                            asm volatile(VRX_R1("%[x0]", "%[w0]", "%[a0]") VRX_R1("%[x1]", "%[w1]", "%[a1]")
+                                         VRX_R1("%[x2]", "%[w2]", "%[a0]") VRX_R1("%[x3]", "%[w3]", "%[a1]")
+                                         : [x0] "=&v"(y[0]), [x1] "=&v"(y[1]), [x2] "=&v"(y[2]), [x3] "=&v"(y[NE - 1]),
+                                           [a0] "=&v"(b0), [a1] "=&v"(b1)
+                                         : [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[NE - 1]),
+                                           [msk] "s"(0x3ff80u), [q0] "v"(qoff[0])
+                                         : "memory");
+                        else {
+#pragma unroll
+                            for (int u = 0; u < NE; ++u)
+                                asm volatile(VRX_R1("%[x0]", "%[w0]", "%[a0]")
+                                             : [x0] "=&v"(y[u]), [a0] "=&v"(b0)
+                                             : [w0] "v"(w[u]), [msk] "s"(0x3ff80u), [q0] "v"(qoff[0])
+                                             : "memory");
+                        }
+#undef VRX_R1
+                        if (NE == 4) {
+                            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(y[0]), "+v"(y[1]));
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < NE; ++u) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y[u]));
+                        }
+#pragma unroll
+                        for (int u = 0; u < NE; ++u) {
+                            if (NE == 4 && u == 2)
+                                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y[2]), "+v"(y[NE - 1]), "+v"(ac[0][0]), "+v"(ac[0][1]));
+                            const double v = __builtin_bit_cast(double, vrx_u2{0u, w[u] & 0xfffc0000u});
+                            ac[0][0] = fma(v, y[u][0], ac[0][0]);
+                            ac[0][1] = fma(v, y[u][1], ac[0][1]);
+                        }
+                    } else {
                     vrx_d2 x[NE][2];
                     // (all words have landed before the first slice is requested: the compiler's
                     //  own waits do not count the reads issued from inline assembly)
@@ -956,6 +997,7 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
                             ac[q][1] = fma(v, x[u][q][1], ac[q][1]);
                         }
                     }
+                    }  // NQ == 2
                 };
                 for (int at = base; at < full_end; at += U * G) trip(at, std::integral_constant<int, 4>());
                 if (tail == 1) trip(full_end, std::integral_constant<int, 1>());
