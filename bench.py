@@ -9,11 +9,14 @@ and state already resident in HBM.  Default workload = BASELINE.json configs[2]
 (N=100k variants x M=50k cells, K=16, ~2 % nnz), the configuration the metric is quoted on.
 The W warm-up iterations are the protocol's start (delay_fit_theta=3: the first three without the
 theta update, so every kernel of the timed iterations has been launched once), the K timed ones
-all run with it.  The GPU legs this run executes anyway (c2, c5's GPU half, the two
-whole-protocol parity fits, the c4 restart search) come BEFORE the timed region and are listed in
-`preceded_by`: the chip used to idle through ~20 s of host-side input generation right before a
-16-ms timed window (driver flags --steps 20 --warmup 5), which then ran 10-15 % slower than its
-own repeats; the CPU-oracle legs run after it.  `ms_per_step_repeats` shows the spread.
+all run with it.  The GPU legs this run executes anyway (c2, c5's GPU half, the c4 restart
+search, and last -- directly before the warm-up, nothing but Python call overhead in between --
+every rank's own whole-protocol fit of its restart, at N = 1 also the perturbed copy of the
+parity check) come BEFORE the timed region and are listed in `preceded_by`: the chip used to
+idle through ~20 s of host-side input generation right before a 16-ms timed window (driver flags
+--steps 20 --warmup 5), which then ran 10-15 % slower than its own repeats (a 5-ms pause is
+enough: scratch/gap_probe.py); the CPU-oracle legs and the heavy-tailed c3_skew leg run after it.
+`ms_per_step_repeats` shows the spread.
 N > 1 (launched by torch.distributed.run, one rank per GPU): every
 rank holds the problem and iterates its own restart (vireo_wrap's restart shard, weak
 scaling); the per-restart ELBOs are all-gathered over RCCL.  Rank 0 prints ONE JSON line.
@@ -281,7 +284,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="c3")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity leg")
-    ap.add_argument("--no-c4", action="store_true", help="skip the n_init=32 restart-shard leg")
+    ap.add_argument("--no-c4", action="store_true",
+                    help="skip the n_init=32 restart-shard leg (and with it the c2 / c5 / c3_skew legs)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE JSON line: libraries that print on the C stdout (librccl's
