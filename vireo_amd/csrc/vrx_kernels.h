@@ -1226,12 +1226,25 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_s_from_virtual(
     for (int kind = 0; kind < 2; ++kind) {
         const int64_t row = 2 * n + kind;
         const int64_t v0 = vptr ? vptr[row] : row, v1 = vptr ? vptr[row + 1] : row + 1;
-        int most = 0;
-        for (int64_t v = v0; v < v1; ++v) most = max(most, (int)npiece[v]);
         double t = 0.0;
-        for (int r = 0; r < most; ++r)
-            for (int64_t v = v0; v < v1; ++v)
-                if (r < npiece[v]) t += partial[((int64_t)r * n_vrows + v) * Kt + c];
+        if (v1 - v0 == 1) {  // one piece (every row of uniform data): its slots, 8 loads in flight
+            const int nr = npiece[v0];
+            const double* src = partial + v0 * Kt + c;
+            for (int r0 = 0; r0 < nr; r0 += 8) {
+                double x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = r0 + u < nr ? src[(int64_t)(r0 + u) * n_vrows * Kt] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (r0 + u < nr) t += x[u];
+            }
+        } else {
+            int most = 0;
+            for (int64_t v = v0; v < v1; ++v) most = max(most, (int)npiece[v]);
+            for (int r = 0; r < most; ++r)
+                for (int64_t v = v0; v < v1; ++v)
+                    if (r < npiece[v]) t += partial[((int64_t)r * n_vrows + v) * Kt + c];
+        }
         sk[kind] = t;
     }
     S[i] = make_double2(sk[0], sk[0] + sk[1]);
