@@ -105,7 +105,7 @@ def c4_leg(counts, K, comm, n_init=32):
     phases, restarts.PHASES = restarts.PHASES, None
     stats = dict(W.LAST_SEARCH)
     # per-rank numbers -> rank-major arrays on every rank
-    keys = ["search_wall", "draw", "skip", "upload+normalise", "fit", "snapshot", "gather",
+    keys = ["search_wall", "draw", "skip", "stage", "upload+normalise", "fit", "snapshot", "gather",
             "final_fit", "download", "broadcast", "template", "device_models"]
     mine = np.array([wall, stats["restart_iterations"], stats["final_iterations"]] +
                     [phases.get(k, 0.0) for k in keys])
@@ -114,8 +114,8 @@ def c4_leg(counts, K, comm, n_init=32):
     restart_its = int(allr[:, 1].sum())
     final_its = int(allr[:, 2].sum())
     # the restart-shard phase ends when the slowest rank has fitted its share (wall clock of
-    # the restart loop: the random draws run one restart ahead on a helper thread, so the
-    # draw / skip and the upload / fit phases below overlap)
+    # the restart loop: the random draws and their staged upload ("stage") run one restart ahead
+    # on a helper thread, so the draw / skip / stage and the fit phases below overlap)
     shard = allr[:, 3]
     return dict(
         workload="c4: vireo_wrap(n_init=%d, max_iter_init=20, random_seed=1, no doublets) on the "
