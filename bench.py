@@ -126,7 +126,34 @@ def c4_leg(counts, K, comm, n_init=32):
         whole_job_iterations_per_s=(restart_its + final_its) / wall_max,
         restart_shard_phase_s=float(shard.max()),
         phases_s_max_over_ranks={k: float(allr[:, 3 + i].max()) for i, k in enumerate(keys)},
-        LB_list_head=[float(x) for x in rv["LB_list"][:4]], best_restart=stats["best"])
+        LB_list_head=[float(x) for x in rv["LB_list"][:4]], best_restart=stats["best"]), rv
+
+
+def doublet_leg(counts, K, rv, repeats=3):
+    """The DEFAULT post-step of vireo_wrap (check_doublet=True, vireo_wrap.py:151-156 ->
+    vireo_doublet.py:11-82) on the winner the c4 leg returned: K + K(K-1)/2 columns through the
+    cell pass in sweeps of 16, the pair genotype table (653 MB in the reference at c3) formed
+    inside the W kernel, then the reference's side effects (ID_prob <- singlet block,
+    update_GT_prob).  Seconds per call, host transfers of GT_prob (38 MB up) and the two result
+    tables (54 MB down) included -- what a `vireo_wrap` caller pays on top of the c4 job."""
+    from vireo_amd.vireo_doublet import predict_doublet
+    from vireo_amd.vireo_model import Vireo
+    N, M = counts.shape
+    m = Vireo(n_var=N, n_cell=M, n_donor=K, ID_prob_init=rv["ID_prob"], GT_prob_init=rv["GT_prob"],
+              beta_mu_init=rv["theta_mean"], beta_sum_init=rv["theta_sum"])
+    secs = []
+    for _ in range(repeats):
+        m.ID_prob, m.GT_prob = rv["ID_prob"], rv["GT_prob"]      # (the step overwrites both)
+        t0 = time.perf_counter()
+        dbl, sing, llr = predict_doublet(m, counts, None)
+        secs.append(time.perf_counter() - t0)
+    cols = K + K * (K - 1) // 2
+    return dict(workload="predict_doublet(update_GT=True, update_ID=True) on the c4 winner: %d cells x "
+                         "%d columns (%d donors + %d pairs), 6 genotype classes per pair" % (M, cols, K, cols - K),
+                doublet_s=min(secs), doublet_s_runs=[round(x, 4) for x in secs], columns=cols,
+                cell_pass_sweeps=-(-cols // 16),
+                cells_called_doublet=int(np.sum(dbl.sum(1) >= 0.9)),
+                max_doublet_logLikRatio=float(np.max(llr)))
 
 
 def c2_leg(device, steps=200):
@@ -217,13 +244,12 @@ def c5_gpu_leg(device, steps=50):
     Iterations/s with inputs and state resident and the HBM roofline on SURVEY.md 8(d)'s 0.89 GB
     per iteration.  (The GPU half; `c5_cpu_leg` checks its first iterations against the oracle
     after the timed region of the headline.)"""
-    from oracle import vireo_oracle as O          # (the generator only; the checker runs in c5_cpu_leg)
-    from vireo_amd import _lib
+    from vireo_amd import _lib, synth
     from vireo_amd.bmm_model import BinomMixtureVB
     from vireo_amd.counts import DeviceCounts
     from vireo_amd.engine import DeviceModel
     N, M, K = 200, 200000, 8
-    AD, DP = O.synth_clone(N, M, K, seed=0)
+    AD, DP = synth.clone_workload(N, M, K, seed=0)
     counts = DeviceCounts(AD, DP, device=device)
     nnz = int(counts.nnz)
     np.random.seed(1)
@@ -284,39 +310,53 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="c3")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity leg")
-    ap.add_argument("--no-c4", action="store_true",
-                    help="skip the n_init=32 restart-shard leg (and with it the c2 / c5 / c3_skew legs)")
+    ap.add_argument("--no-c4", action="store_true", help="skip the n_init=32 restart-shard leg")
+    ap.add_argument("--no-side-legs", action="store_true",
+                    help="skip the c2 / c5 / c3_skew / doublet legs (N = 1 only anyway)")
+    ap.add_argument("--only-headline", action="store_true",
+                    help="= --no-cpu --no-c4 --no-side-legs (A/B runs, profiler runs)")
     args = ap.parse_args()
+    if args.only_headline:
+        args.no_cpu = args.no_c4 = args.no_side_legs = True
+
+    import __graft_entry__ as entry
+    from vireo_amd import launch
+    # `python bench.py --gpus N` with no launcher around it: this process becomes the launcher --
+    # one copy of this command per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set the way
+    # torch.distributed.run sets them (vireo_amd/launch.py; the reference takes its parallelism
+    # as an argument too: nproc, vireo_wrap.py:74-91).  Rank 0's JSON line is this process's
+    # stdout; the exit code is non-zero if any rank fails.
+    if args.gpus > 1 and not launch.launched_externally():
+        entry.build()                       # once, not N times at once
+        launch.relaunch_self(args.gpus)
 
     # stdout carries exactly ONE JSON line: libraries that print on the C stdout (librccl's
     # version banner sits in the stdio buffer until exit) get stderr instead
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from vireo_amd import dist as vdist
+    rank, world, local = vdist.env_rank_world()
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with "
-                         "python -m torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
-    import __graft_entry__ as entry
     entry.build()
     from vireo_amd import _lib
     from vireo_amd.counts import DeviceCounts
     from vireo_amd.engine import DeviceModel
     from vireo_amd.vireo_model import Vireo
-    from vireo_amd import synth, dist as vdist
+    from vireo_amd import synth
     _lib.require_gpu()
 
-    comm = vdist.LocalComm()
-    # One process per GPU (torch.distributed.run only LAUNCHES the ranks and sets RANK /
-    # WORLD_SIZE / MASTER_*); the ranks talk over RCCL through libvireo_hip.so, and the RCCL
-    # unique id travels over a plain socket -- torch is never imported here: its bundled HIP
-    # runtime and librccl would collide with the library's.  VIREO_BENCH_FORCE_RCCL=1 takes
-    # this path at world 1 too, so a 1-GPU box can exercise it.
-    if world > 1 or os.environ.get("VIREO_BENCH_FORCE_RCCL") == "1":
-        comm = vdist.RcclComm(rank, world, local, vdist.socket_exchange(rank, world))
+    # One process per GPU (a launcher -- torch.distributed.run or vireo_amd/launch.py -- only
+    # STARTS the ranks and sets RANK / WORLD_SIZE / MASTER_*); the ranks talk over RCCL through
+    # libvireo_hip.so, and the RCCL unique id travels over a plain socket -- torch is never
+    # imported here: its bundled HIP runtime and librccl would collide with the library's.
+    # VIREO_FORCE_RCCL=1 (or the older VIREO_BENCH_FORCE_RCCL=1) takes this path at world 1 too,
+    # so a 1-GPU box can exercise it; VIREO_COMM=tcp replaces RCCL by host sockets for ranks that
+    # share one device (RCCL refuses that): `VIREO_COMM=tcp VIREO_DEVICE=0 python bench.py --gpus 8`.
+    comm = vdist.make_comm(rank, world, local,
+                           force_rccl=os.environ.get("VIREO_BENCH_FORCE_RCCL") == "1")
 
     N, M, K, dens = synth.CONFIGS[args.config]
     T = 3
@@ -339,7 +379,7 @@ def main():
     c5_data = None
     parity_gpu = None
     solo = rank == 0 and world == 1
-    if solo and not args.no_c4 and args.config == "c3":
+    if solo and not args.no_side_legs and args.config == "c3":
         c2 = c2_leg(local)
         preceded_by.append("c2 leg (3 x 210 iterations of the N=10k x M=5k problem)")
         c5, c5_data = c5_gpu_leg(local)
@@ -355,8 +395,13 @@ def main():
     # (the timed model is resident before the c4 leg: at N > 1, where no parity fits follow, only
     #  the tail of that leg -- the winner's download / broadcast -- separates its fits from the warm-up)
     if not args.no_c4 and args.config == "c3":
-        c4 = c4_leg(counts, K, comm)
+        c4, c4_rv = c4_leg(counts, K, comm)
         preceded_by.append("c4 leg (vireo_wrap n_init=32 on the same data: ~0.6 s of fits)")
+        if solo and not args.no_side_legs:
+            c4["doublet"] = doublet_leg(counts, K, c4_rv)
+            c4["doublet_s"] = c4["doublet"]["doublet_s"]
+            preceded_by.append("doublet step on the c4 winner (3 x predict_doublet, 136 columns)")
+        del c4_rv
 
     # The whole timing protocol _fit_VB(min_iter=5, max_iter=20, delay_fit_theta=3) of this rank's
     # restart, on a second device model from the same constructor draws: what vireo_wrap runs per
@@ -423,7 +468,7 @@ def main():
         proto_dm.close()
 
     c3_skew = None
-    if solo and not args.no_c4 and args.config == "c3":
+    if solo and not args.no_side_legs and args.config == "c3":
         c3_skew = c3_skew_leg(local, K, (float(np.median(repeats)), nnz))
 
     # ---- CPU legs (rank 0): the oracle beside the GPU results formed above --------------------
@@ -566,7 +611,7 @@ def main():
         if cpu:
             out["speedup_vs_cpu_1core"] = out["value"] / cpu["value"]
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if isinstance(comm, vdist.RcclComm):
+    if not isinstance(comm, vdist.LocalComm):
         comm.barrier()
         comm.close()
 

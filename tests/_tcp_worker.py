@@ -7,6 +7,8 @@ ranks on one device; the shard only needs an all-gather of n_init doubles and a 
 case "c1": the demo data (tests/golden/c1_data.npz), n_donor=4, random_seed=2
 case "c2": the SURVEY.md 8(d) generator at N=10k x M=5k, K=4 (BASELINE.json configs[1]),
            random_seed=5, no doublets
+case "bmm": BinomMixtureVB(n_donor=3).fit(min_iter=30, n_init=<n_init>, random_seed=1, comm=comm)
+           on the mitoDNA demo data (tests/golden/mito_data.npz; bmm_model.py:204-263)
 """
 import contextlib
 import io
@@ -25,6 +27,19 @@ def main(rank, world, port, out_path, case, n_init):
     from tests.tcp_comm import TcpComm
     W = sys.modules["vireo_amd.vireo_wrap"]
     comm = TcpComm(rank, world, port)
+    if case == "bmm":
+        from tests import gold
+        AD, DP = gold.mito()
+        b = vireo_amd.BinomMixtureVB(n_var=AD.shape[0], n_cell=AD.shape[1], n_donor=3)
+        b.fit(AD, DP, min_iter=30, n_init=n_init, random_seed=1, verbose=False, comm=comm)
+        rv = dict(ID_prob=b.ID_prob, beta_mu=b.beta_mu, beta_sum=b.beta_sum, ELBO_iters=b.ELBO_iters,
+                  ELBO_inits=b.ELBO_inits,
+                  rng_after=(np.random.get_state()[1][:8].copy(), int(np.random.get_state()[2])))
+        with open(out_path, "wb") as f:
+            pickle.dump(rv, f)
+        comm.barrier()
+        comm.close()
+        return
     if case == "c1":
         from tests import gold
         AD, DP = gold.c1()

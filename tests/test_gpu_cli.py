@@ -146,3 +146,36 @@ def test_cli_with_a_communicator_writes_the_same_files(tmp_path, capsys, monkeyp
         assert open(plain + "/" + name).read() == open(shared + "/" + name).read()
     for name in ("prob_singlet.tsv.gz", "prob_doublet.tsv.gz"):
         assert gzip.open(plain + "/" + name).read() == gzip.open(shared + "/" + name).read()
+
+
+def test_cli_nGPU_launches_its_own_ranks(tmp_path):
+    """``vireo --nGPU 2`` with no launcher around it: the command starts one process per rank
+    (vireo_amd/launch.py; the GPU counterpart of the reference's -p / nproc, vireo_wrap.py:74-91),
+    the ranks share the restarts, rank 0 writes.  Two ranks on the ONE device of the test box
+    (VIREO_DEVICE=0, host-socket communicator: RCCL refuses two ranks on a device): the files
+    equal the reference command's byte for byte, like the single-process run's."""
+    import subprocess
+    import sys
+    from vireo_amd import _lib
+    _lib.require_gpu()
+    mode = "mode1_noGT"
+    out = str(tmp_path / "ngpu2")
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(HERE), VIREO_COMM="tcp", VIREO_DEVICE="0",
+               VIREO_RESTART_BATCH="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "vireo_amd.vireo"] + MODES[mode] +
+                       ["-o", out, "--randSeed", "2", "--noPlot", "--nGPU", "2"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert p.stdout.count("[vireo] All done") == 1          # rank 0 speaks for all
+    ref = os.path.join(GOLD, mode)
+    for name in ("summary.tsv", "donor_ids.tsv"):
+        assert open(out + "/" + name).read() == open(ref + "/" + name).read(), name
+    for name in ("prob_singlet.tsv.gz", "prob_doublet.tsv.gz", "GT_donors.vireo.vcf.gz"):
+        assert gzip.open(out + "/" + name, "rt").read() == gzip.open(ref + "/" + name, "rt").read(), name
+    # a rank that fails takes the command down with a non-zero code instead of a hang
+    bad = subprocess.run([sys.executable, "-m", "vireo_amd.vireo", "-c", str(tmp_path / "nowhere"),
+                          "-N", "4", "-o", out + "_bad", "--nGPU", "2"],
+                         env=env, capture_output=True, text=True, timeout=300, cwd=os.path.dirname(HERE))
+    assert bad.returncode != 0

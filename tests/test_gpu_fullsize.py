@@ -322,15 +322,19 @@ def test_config4_restart_search_n_init32(va):
         np.testing.assert_allclose(g.ID_prob, st.ID_prob, rtol=RTOL, atol=1e-290)
         np.testing.assert_allclose(Lg, L, rtol=1e-9)
         np.testing.assert_allclose(elbo_gpu, elbo_ref, rtol=RTOL)
-        # (a restart stopped after 20 iterations is not converged: where two donor columns still
-        #  describe the same donor, its cells sit between them, the two largest posteriors equal
-        #  to rounding -- observed: 8 % of the cells of restart 31 -- so the calls are compared
-        #  wherever the oracle's own call is decided by more than the tolerance)
-        top = np.sort(st.ID_prob, axis=1)
-        decided = top[:, -1] - top[:, -2] > 10 * RTOL * top[:, -1]
-        print("restart %d: %.1f %% of the cells decided" % (i, 100 * decided.mean()))
-        assert decided.mean() > 0.5
-        assert np.array_equal(g.ID_prob.argmax(1)[decided], st.ID_prob.argmax(1)[decided])
+        # ALL cells are compared: a restart stopped after 20 iterations is not
+        # converged -- where two donor columns still describe the same donor, its cells sit between
+        # them and the two largest posteriors are equal to rounding (observed: 8 % of the cells of
+        # restart 31) -- so the rule is tie-aware: the GPU's call is the oracle's, or the oracle
+        # itself holds the GPU's donor within 10 x rtol of its own largest posterior
+        ga, oa = g.ID_prob.argmax(1), st.ID_prob.argmax(1)
+        top = st.ID_prob.max(1)
+        at_gpu_call = st.ID_prob[np.arange(M), ga]
+        tie_ok = top - at_gpu_call <= 10 * RTOL * top
+        print("restart %d: %.2f %% of the cells called differently, all of them ties: %s"
+              % (i, 100 * np.mean(ga != oa), bool(np.all(tie_ok[ga != oa]))))
+        assert np.all((ga == oa) | tie_ok)
+        assert np.mean(ga == oa) > 0.5
         del st, g
     # restart 0 is the timing protocol of bench.py (the same seed, the first constructor)
     np.random.seed(1)
@@ -345,6 +349,29 @@ def test_config4_restart_search_n_init32(va):
     assert np.array_equal(rv["theta_mean"], win.beta_mu) and np.array_equal(rv["theta_sum"], win.beta_sum)
     assert rv["LB_doublet"] == win.ELBO_[-1]
     assert rv["doublet_prob"].shape == (M, K * (K - 1) // 2) and not rv["doublet_prob"].any()
+    # The DEFAULT post-step of vireo_wrap (check_doublet=True, vireo_wrap.py:151-156 ->
+    # vireo_doublet.py:11-82) at K = 16: K + K(K-1)/2 = 136 columns (9 sweeps of the cell pass),
+    # 6 genotype classes per donor pair.  Given GT_prob and theta the step is independent per
+    # cell, so the oracle on a 2 000-cell column subset of AD / DP is exact for those cells
+    # (the whole matrix costs the reference > 5 minutes and a 653-MB table).
+    sub = np.sort(np.random.default_rng(3).choice(M, 2000, replace=False))
+    st = O.vireo_new(sub.size, N, K, ID_prob_init=win.ID_prob[sub], GT_prob_init=win.GT_prob,
+                     beta_mu_init=win.beta_mu.copy(), beta_sum_init=win.beta_sum.copy())
+    st.ID_prob, st.GT_prob = win.ID_prob[sub].copy(), win.GT_prob.copy()
+    dp_o, ip_o, llr_o = O.vireo_doublet(st, AD[:, sub], DP[:, sub], doublet_rate_prior=min(0.5, M / 100000))
+    import time
+    t0 = time.perf_counter()
+    dp_g, ip_g, llr_g = va.predict_doublet(win, counts, None)
+    print("predict_doublet at c3 / K = 16: %.3f s" % (time.perf_counter() - t0))
+    assert dp_g.shape == (M, K * (K - 1) // 2) and ip_g.shape == (M, K) and llr_g.shape == (M,)
+    np.testing.assert_allclose(dp_g[sub], dp_o, rtol=RTOL, atol=1e-290)
+    np.testing.assert_allclose(ip_g[sub], ip_o, rtol=RTOL, atol=1e-290)
+    np.testing.assert_allclose(llr_g[sub], llr_o, rtol=RTOL, atol=1e-8)
+    both_g, both_o = np.append(ip_g[sub], dp_g[sub], axis=1), np.append(ip_o, dp_o, axis=1)
+    assert np.array_equal(both_g.argmax(1), both_o.argmax(1))
+    assert np.array_equal(dp_g[sub].sum(1) > 0.9, dp_o.sum(1) > 0.9)        # io_utils.py:104-106's doublet call
+    assert np.allclose(both_g.sum(1), 1.0, rtol=0, atol=1e-12)
+    assert win.ID_prob is ip_g or np.array_equal(win.ID_prob, ip_g)          # the side effect, vireo_doublet.py:71
 
 
 def test_restart_shard_over_rccl_world2(va, tmp_path):

@@ -110,3 +110,103 @@ def test_other_genotype_class_counts(va, monkeypatch, T, lds):
     close(dev.GT_prob, ref.GT_prob)
     close(dev.beta_mu, ref.beta_mu)
     close(dev.beta_sum, ref.beta_sum)
+
+
+# ---------------------------------------------------------------- the sweep's known deviation class
+# Seeds 48 .. 999 of `draw_case` (tests/perf/fuzz_sweep.py; profiles/r05_fuzz_sweep_48_999.log):
+# 929 of 952 cases meet rtol 1e-5 everywhere; the 23 below do not -- 22 clone-mode cases with deep
+# counts (up to 5000 per entry) on their small posteriors, one ASE-mode Vireo case on seven
+# GT_prob entries of ~1e-199.  One update never differs by more than 2e-7; the theta step of the
+# NEXT iteration amplifies it (deep counts: d psi = d s / s times counts of thousands), and what is
+# amplified is the rounding of the reference's three cancelling sums (bmm_model.py:125-129;
+# profiles/r05_bmm_grouping_study.txt).  The cases are pinned by an 80-bit arbiter
+# (tests/golden/make_bmm_arbiter.py -> fuzz_arbiter.npz): the HIP path may not be further from the
+# mathematics than the reference's float64 arithmetic is.
+from tests import gold        # noqa: E402
+
+_ARB = None
+
+
+def _arbiter():
+    global _ARB
+    if _ARB is None:
+        _ARB = gold.load("fuzz_arbiter")
+    return _ARB
+
+
+def _rel_to_exact(x, exact):
+    m = exact > 1e-290
+    r = np.zeros(exact.shape)
+    r[m] = np.abs(x[m] - exact[m]) / exact[m]
+    return r
+
+
+def _held_by_arbiter(name, gpu, orc, exact):
+    e_gpu, e_orc = _rel_to_exact(gpu, exact), _rel_to_exact(orc, exact)
+    bound = max(RTOL, 2.0 * e_orc.max())
+    print("%s: worst relative distance from the 80-bit result: GPU %.2e, oracle %.2e; GPU vs oracle %.2e"
+          % (name, e_gpu.max(), e_orc.max(), _rel_to_exact(gpu, np.where(orc > 1e-290, orc, 0)).max()))
+    assert e_gpu.max() <= bound, (name, e_gpu.max(), e_orc.max())
+    assert e_gpu.max() <= max(RTOL, e_orc.max()), (name, e_gpu.max(), e_orc.max())   # never the further one
+    assert np.all(np.abs(gpu - exact)[exact <= 1e-290] <= 1e-285)
+    return e_gpu.max(), e_orc.max()
+
+
+@pytest.mark.parametrize("seed", [75, 155, 171, 211, 239, 343, 367, 463, 563, 595, 611, 643, 695, 719,
+                                  755, 803, 811, 855, 887, 895, 951, 987])
+def test_known_deviation_cases_vs_arbiter_clone_mode(va, monkeypatch, seed):
+    from vireo_amd.counts import DeviceCounts      # noqa: F401
+    g = _arbiter()
+    AD, DP, K, rng = draw_case(seed)
+    N, M = AD.shape
+    monkeypatch.setenv("VIREO_LDS", "1" if seed % 2 else "0")
+    monkeypatch.setenv("VIREO_LDS_BLOCKS", str(int(rng.choice([1, 16, 1024]))))
+    K = max(K, 2)
+    np.random.seed(seed)
+    init = np.random.rand(M, K)
+    ref = O.bmm_new(M, N, K, ID_prob_init=init.copy())
+    dev = va.BinomMixtureVB(n_cell=M, n_var=N, n_donor=K, ID_prob_init=init.copy())
+    O.bmm_fit_vb(ref, AD, DP, min_iter=2, max_iter=4)
+    dev._fit_BV(AD, DP, min_iter=2, max_iter=4, verbose=False)
+    assert len(dev.ELBO_iters) == len(ref.ELBO_iters) == int(g["s%d_n_exec" % seed]) - 1
+    close(dev.ELBO_iters, ref.ELBO_iters)
+    close(dev.beta_mu, ref.beta_mu)
+    close(dev.beta_sum, ref.beta_sum)
+    assert np.array_equal(dev.ID_prob.argmax(1), ref.ID_prob.argmax(1))
+    exact = g["s%d_ID_prob" % seed]
+    assert np.array_equal(dev.ID_prob.argmax(1), exact.argmax(1))
+    e_gpu, e_orc = _held_by_arbiter("seed %d ID_prob" % seed, dev.ID_prob, ref.ID_prob, exact)
+    assert e_orc > 0.8 * RTOL        # (the case is in this list because the ORACLE is that far from exact)
+
+
+def test_known_deviation_case_vs_arbiter_ase_mode(va, monkeypatch):
+    """seed 537: Vireo, ASE mode, fixed beta_sum, counts up to 5000, K = 19"""
+    from vireo_amd.counts import DeviceCounts
+    seed = 537
+    g = _arbiter()
+    AD, DP, K, rng = draw_case(seed)
+    N, M = AD.shape
+    monkeypatch.setenv("VIREO_LDS", "1")
+    monkeypatch.setenv("VIREO_LDS_BLOCKS", str(int(rng.choice([1, 16, 1024]))))
+    flags = dict(ASE_mode=bool(rng.random() < 0.2), fix_beta_sum=bool(rng.random() < 0.2),
+                 learn_theta=bool(rng.random() < 0.85))
+    assert flags == dict(ASE_mode=True, fix_beta_sum=True, learn_theta=True)
+    counts = DeviceCounts(AD, DP)
+    np.random.seed(seed)
+    ref = O.vireo_new(M, N, K, **flags)
+    np.random.seed(seed)
+    dev = va.Vireo(n_cell=M, n_var=N, n_donor=K, **flags)
+    O.vireo_fit(ref, AD, DP, min_iter=2, max_iter=5, delay_fit_theta=1)
+    dev.fit(counts, None, min_iter=2, max_iter=5, delay_fit_theta=1, verbose=False)
+    assert len(dev.ELBO_) == len(ref.ELBO_) == int(g["s%d_n_exec" % seed]) - 1
+    close(dev.ELBO_, ref.ELBO_)
+    close(dev.ID_prob, ref.ID_prob)
+    close(dev.beta_mu, ref.beta_mu)
+    close(dev.beta_sum, ref.beta_sum)
+    rows = g["s%d_GT_rows" % seed]
+    _held_by_arbiter("seed 537 ID_prob", dev.ID_prob, ref.ID_prob, g["s%d_ID_prob" % seed])
+    _held_by_arbiter("seed 537 GT_prob (%d variants)" % rows.size, dev.GT_prob[rows], ref.GT_prob[rows],
+                     g["s%d_GT_prob" % seed])
+    # outside the kept variants the oracle is within 1e-6 of exact, so the plain tolerance holds there
+    rest = np.setdiff1d(np.arange(N), rows)
+    close(dev.GT_prob[rest], ref.GT_prob[rest])

@@ -132,3 +132,101 @@ def test_two_ranks_one_gpu_config2_with_restart_batches(va, tmp_path, monkeypatc
         one = va.vireo_wrap(counts, None, n_donor=K, n_init=6, random_seed=5, check_doublet=False)
     _same(rvs[0], one)
     assert np.all(np.isfinite(one["LB_list"])) and len(set(one["LB_list"])) > 1
+
+
+@pytest.mark.parametrize("n_init", [32, 13])
+def test_eight_ranks_one_gpu_config2(va, tmp_path, monkeypatch, n_init):
+    """north_star's world: EIGHT ranks (all on device 0), BASELINE.json configs[1] size, n_init =
+    32 (4 restarts per rank, every rank jumps the generator over 28 foreign ones -- configs[3]'s
+    arithmetic) and n_init = 13 (ranks 0-4 own two restarts, ranks 5-7 one: the gathered ELBO
+    array is padded; owner != 0 is likely), restart batches on, LDS-resident passes forced so
+    that a column's sums do not depend on its batch neighbours: every rank returns the bits of
+    the world-1 run (vireo_wrap.py:64-94)."""
+    from vireo_amd import synth
+    from vireo_amd.counts import DeviceCounts
+    from vireo_amd.dist import my_restarts
+    rvs = _run_ranks(tmp_path, 8, "c2", n_init, {"VIREO_LDS": "1"})
+    assert [rv["search"]["restarts"] for rv in rvs] == [len(my_restarts(n_init, r, 8)) for r in range(8)]
+    assert rvs[0]["search"]["batch"] > 1
+    for rv in rvs[1:]:
+        _same(rvs[0], rv)
+        assert np.array_equal(rv["rng_after"][0], rvs[0]["rng_after"][0]) and rv["rng_after"][1] == rvs[0]["rng_after"][1]
+    monkeypatch.setenv("VIREO_LDS", "1")
+    N, M, K, dens = synth.CONFIGS["c2"]
+    w = synth.donor_workload(N, M, K, dens, seed=0)
+    counts = DeviceCounts.from_merged(w["shape"], w["colptr"], w["rowidx"], w["ad"], w["dp"])
+    with contextlib.redirect_stdout(io.StringIO()):
+        one = va.vireo_wrap(counts, None, n_donor=K, n_init=n_init, random_seed=5, check_doublet=False)
+    rng_one = np.random.get_state()
+    _same(rvs[0], one)
+    assert np.array_equal(rvs[0]["rng_after"][0], rng_one[1][:8]) and rvs[0]["rng_after"][1] == int(rng_one[2])
+    best = int(np.argmax(one["LB_list"]))
+    assert len(one["LB_list"]) == n_init and len(set(one["LB_list"])) > 1
+    for r, rv in enumerate(rvs):
+        assert rv["search"]["best"] == best and rv["search"]["owner"] == best % 8
+        assert (rv["search"]["final_iterations"] > 0) == (r == best % 8)      # only the owner refined
+        assert "skip" in rv["phases"]
+
+
+def test_clone_mode_inits_sharded_two_ranks(va, tmp_path, monkeypatch):
+    """``BinomMixtureVB.fit(comm=)`` (SURVEY.md 8e: "BMM: same restart shard";
+    bmm_model.py:242-254): initialisation i on rank i % 2, the ELBOs all-gathered, the owner of
+    the first maximum re-fits and broadcasts.  One initialisation per device model: both ranks
+    return the bits of the world-1 call in this process, which is the reference's
+    (golden mito_bmm_k3_seed1, the notebook's known answer); with the initialisations packed
+    into batches (each rank packs its 25 differently from the 50 of world 1; gather kernels pick
+    their lane layout from the column count): the same to 1e-9."""
+    AD, DP = gold.mito()
+    g = gold.load("mito_bmm_k3_seed1")
+    for batch_env, exact in (({"VIREO_RESTART_BATCH": "1"}, True), ({}, False)):
+        tag = tmp_path / ("b%d" % exact)
+        tag.mkdir()
+        rvs = _run_ranks(tag, 2, "bmm", 50, batch_env)
+        for k, v in batch_env.items():
+            monkeypatch.setenv(k, v)
+        b = va.BinomMixtureVB(n_var=AD.shape[0], n_cell=AD.shape[1], n_donor=3)
+        b.fit(AD, DP, min_iter=30, n_init=50, random_seed=1, verbose=False)
+        rng_one = np.random.get_state()
+        for k in batch_env:
+            monkeypatch.delenv(k)
+        for rv in rvs:
+            for name in ("ID_prob", "beta_mu", "beta_sum", "ELBO_iters", "ELBO_inits"):
+                if exact:
+                    assert np.array_equal(rv[name], getattr(b, name)), name
+                else:
+                    np.testing.assert_allclose(rv[name], getattr(b, name), rtol=1e-9, atol=1e-300)
+                assert np.array_equal(rv[name], rvs[0][name])       # every rank leaves with the same state
+            assert np.array_equal(rv["rng_after"][0], rng_one[1][:8]) and rv["rng_after"][1] == int(rng_one[2])
+            assert len(rv["ELBO_iters"]) == len(g["ELBO_iters"])
+            np.testing.assert_allclose(rv["ELBO_iters"], g["ELBO_iters"], rtol=RTOL)
+            np.testing.assert_allclose(rv["ELBO_inits"], g["ELBO_inits"], rtol=RTOL)
+            np.testing.assert_allclose(rv["ID_prob"], g["ID_prob"], rtol=RTOL, atol=1e-290)
+            assert rv["ELBO_iters"][-1] == pytest.approx(-190779.74335041404, rel=RTOL)
+            assert np.array_equal(rv["ID_prob"].argmax(1), g["ID_prob"].argmax(1))
+
+
+def test_bench_launches_its_own_ranks(va):
+    """``python bench.py --gpus 2`` with no launcher and no WORLD_SIZE in the environment (how the
+    driver starts ``--gpus 1``): the command spawns its two ranks (vireo_amd/launch.py), rank 0
+    prints the ONE JSON line, restart r runs on rank r.  Both ranks on device 0 over the
+    host-socket communicator (RCCL refuses two ranks on one device)."""
+    import json
+    env = dict(os.environ, VIREO_COMM="tcp", VIREO_DEVICE="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    lines = {}
+    for n in (2, 1):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--config", "c2",
+                            "--steps", "20", "--warmup", "5", "--only-headline"],
+                           env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out = [ln for ln in p.stdout.splitlines() if ln.strip()]
+        assert len(out) == 1, p.stdout[-2000:]
+        lines[n] = json.loads(out[0])
+    two, one = lines[2], lines[1]
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["value"] > 0
+    assert len(two["config"]["restart_protocol_elbos"]) == 2
+    # rank 0 iterates restart 0 (= the world-1 run's), rank 1 the second constructor's draws
+    assert two["config"]["restart_protocol_elbos"][0] == one["config"]["restart_protocol_elbos"][0]
+    assert two["config"]["restart_protocol_elbos"][1] != two["config"]["restart_protocol_elbos"][0]
+    assert np.all(np.isfinite(two["config"]["restart_elbos"]))

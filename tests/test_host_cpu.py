@@ -243,6 +243,11 @@ def test_fast_generator_equals_oracle_generator():
         shape, ptr, idx, a, dp = merge_counts(AD, DP)
         assert np.array_equal(ptr, w["colptr"]) and np.array_equal(idx, w["rowidx"])
         assert np.array_equal(a, w["ad"]) and np.array_equal(dp, w["dp"])
+    # clone mode (BASELINE.json configs[4]): the product-side generator bench.py's GPU leg uses
+    for (n, m, k, seed) in [(40, 900, 3, 0), (25, 1200, 8, 5)]:
+        AD, DP = synth.clone_workload(n, m, k, seed=seed)
+        oAD, oDP = O.synth_clone(n, m, k, seed=seed)
+        assert (AD != oAD).nnz == 0 and (DP != oDP).nnz == 0 and AD.nnz == oAD.nnz
 
 
 def test_socket_exchange_world3():
@@ -497,3 +502,59 @@ def test_tcp_comm_three_ranks():
         assert np.array_equal(got, [0.5, 0, 1.5, -1, 2.5, -2])
         assert np.array_equal(b1, np.arange(6.0).reshape(2, 3) * 2) and b1.shape == (2, 3)
         assert np.array_equal(b0, np.zeros(4))
+
+
+# ---------------------------------------------------------------- the launcher (--nGPU / --gpus N)
+_STUB_RANK = r'''
+import os, sys, time
+r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == str(r) and os.environ["MASTER_ADDR"] == "127.0.0.1"
+assert int(os.environ["MASTER_PORT"]) > 0 and os.environ["VIREO_LAUNCHED"] == "1"
+mode = sys.argv[1]
+if mode == "fail" and r == 2:
+    sys.exit(7)
+if mode == "fail":
+    time.sleep(60)          # a rank waiting in a collective for the one that died
+print("rank %d of %d says %s" % (r, w, sys.argv[2]))
+'''
+
+
+def test_launcher_spawns_ranks_and_forwards_rank0(tmp_path):
+    """vireo_amd/launch.py: N copies of a command with the rendezvous environment of
+    torch.distributed.run, rank 0's stdout = the launcher's, the others' on stderr"""
+    import subprocess
+    stub = tmp_path / "stub.py"
+    stub.write_text(_STUB_RANK)
+    code = ("import sys; sys.path.insert(0, %r); from vireo_amd import launch; "
+            "sys.exit(launch.spawn_ranks([sys.executable, %r, 'ok', 'hello'], 4))" % (ROOT, str(stub)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode == 0, p.stderr
+    assert p.stdout == "rank 0 of 4 says hello\n"
+    assert sorted(ln for ln in p.stderr.splitlines() if ln.startswith("rank")) == [
+        "rank %d of 4 says hello" % r for r in (1, 2, 3)]
+
+
+def test_launcher_stops_the_others_when_a_rank_fails(tmp_path):
+    """a failing rank's code is the launcher's, and the ranks that would wait for it forever in
+    a collective are terminated"""
+    import subprocess
+    import time
+    stub = tmp_path / "stub.py"
+    stub.write_text(_STUB_RANK)
+    code = ("import sys; sys.path.insert(0, %r); from vireo_amd import launch; "
+            "sys.exit(launch.spawn_ranks([sys.executable, %r, 'fail', 'x'], 4))" % (ROOT, str(stub)))
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 7
+    assert time.time() - t0 < 30
+    assert "rank 2 exited with code 7" in p.stderr and p.stdout == ""
+
+
+def test_launched_externally_and_device_map():
+    from vireo_amd import launch
+    env = launch.rank_env(3, 8, 29400, base={"PATH": "/bin"}, devices=[0] * 8)
+    assert env["RANK"] == "3" and env["LOCAL_RANK"] == "0" and env["WORLD_SIZE"] == "8"
+    assert env["MASTER_PORT"] == "29400" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    p = launch.free_port()
+    assert 0 < p < 65535

@@ -170,3 +170,27 @@ def test_synthetic_generator_and_fit(tag, shape):
     eq(sing, g["singlet_prob"])
     eq(llr, g["doublet_LLR"])
     eq(st.GT_prob, g["GT_prob_after_doublet"])
+
+
+def test_fuzz_arbiter_fixture_is_the_oracles_problem():
+    """tests/golden/fuzz_arbiter.npz (80-bit end states of the sweep's deviation cases,
+    make_bmm_arbiter.py) against the oracle on two of its smaller cases: same problem, same
+    iteration count, same assignments -- and the oracle's small posteriors ARE 1e-5 ... 1e-4
+    relative away from the exact ones (the deviation class the GPU tests pin)."""
+    from tests.test_gpu_fuzz import draw_case
+    g = gold.load("fuzz_arbiter")
+    assert len(g["bmm_seeds"]) == 22 and list(g["vireo_seeds"]) == [537]
+    for seed, lo, hi in ((343, 5e-6, 5e-5), (695, 4e-5, 2e-4)):
+        AD, DP, K, _ = draw_case(seed)
+        N, M = AD.shape
+        np.random.seed(seed)
+        init = np.random.rand(M, max(K, 2))
+        ref = O.bmm_new(M, N, max(K, 2), ID_prob_init=init.copy())
+        O.bmm_fit_vb(ref, AD, DP, min_iter=2, max_iter=4)
+        exact = g["s%d_ID_prob" % seed]
+        assert exact.shape == ref.ID_prob.shape and len(ref.ELBO_iters) + 1 == int(g["s%d_n_exec" % seed])
+        assert np.array_equal(exact.argmax(1), ref.ID_prob.argmax(1))
+        np.testing.assert_allclose(exact.sum(1), 1.0, rtol=0, atol=1e-12)
+        m = exact > 1e-290
+        dev = np.max(np.abs(ref.ID_prob[m] - exact[m]) / exact[m])
+        assert lo < dev < hi, (seed, dev)

@@ -6,8 +6,9 @@ import numpy as np
 
 from . import _lib
 from .counts import device_counts
+from .dist import LocalComm, gather_restart_elbos, my_restarts
 from .engine import DeviceBatch, DeviceModel
-from .restarts import restart_batch
+from .restarts import LegacyStream, restart_batch
 from .vireo_base import normalize
 
 
@@ -157,23 +158,38 @@ class BinomMixtureVB():
             elif i == max_iter - 1:
                 print("Warning: VB did not converge!\n")
 
-    def _fit_inits_batched(self, counts, dm, n_init, R, max_iter_pre, min_iter=20,
+    def _draw_initial(self):
+        """one ``set_initial`` of the n_init loop (bmm_model.py:243-245) -> the state it leaves"""
+        shape = (self.n_var, self.n_donor)
+        self.set_initial(self.beta_mu_init, self.beta_sum_init, self.ID_prob_init)
+        return (self.ID_prob, np.broadcast_to(self.beta_mu, shape),
+                np.broadcast_to(self.beta_sum, shape))
+
+    def _skip_initials(self, n):
+        """pass over the draws of ``n`` initialisations that other ranks fit: the global legacy
+        stream moves exactly as n ``set_initial`` calls would move it (rand(n_cell, n_donor) each,
+        bmm_model.py:81-82; nothing when ID_prob_init is given)"""
+        if n > 0 and self.ID_prob_init is None:
+            LegacyStream().skip(n * self.n_cell * self.n_donor)
+
+    def _fit_inits_batched(self, counts, dm, n_init, mine, R, max_iter_pre, min_iter=20,
                            epsilon_conv=1e-2, verbose=True):
-        """The n_init short fits of ``fit`` (bmm_model.py:241-252), R at a time in one device
-        model (vrx_model_cfg.n_batch): same draws in the same order, same prints, the best
-        state moves to ``dm`` on the device.  -> best (ID_prob, beta_mu, beta_sum, ELBO_iters)"""
+        """This rank's share ``mine`` of the n_init short fits of ``fit`` (bmm_model.py:241-252),
+        R at a time in one device model (vrx_model_cfg.n_batch): same draws in the same order,
+        same prints, the best state stays on the device (a snapshot of ``dm``).
+        -> ({restart: ELBO}, (ELBO, restart, trace) of the first maximum or None)"""
         db = DeviceBatch(counts, _lib.KIND_BMM, self.n_donor, R, fix_beta_sum=self.fix_beta_sum)
         self._push_prior(db)
-        shape = (self.n_var, self.n_donor)
-        best_trace = None
-        for base in range(0, n_init, R):
-            ids = list(range(base, min(base + R, n_init)))
+        local, best = {}, None
+        consumed = 0
+        for base in range(0, len(mine), R):
+            ids = mine[base:base + R]
             first = None
             for slot in range(R):
                 if slot < len(ids):
-                    self.set_initial(self.beta_mu_init, self.beta_sum_init, self.ID_prob_init)
-                    state = (self.ID_prob, np.broadcast_to(self.beta_mu, shape),
-                             np.broadcast_to(self.beta_sum, shape))
+                    self._skip_initials(ids[slot] - consumed)
+                    consumed = ids[slot] + 1
+                    state = self._draw_initial()
                     first = first or state
                 else:
                     state = first          # idle slots repeat the batch's first restart
@@ -183,41 +199,71 @@ class BinomMixtureVB():
                 trace, it = traces[slot], int(its[slot])
                 if verbose:
                     self._warn(trace, it, min_iter, max_iter_pre)
-                self.ELBO_inits.append(trace[:it][-1])
-                if i == 0 or self.ELBO_inits[-1] > np.max(self.ELBO_inits[:-1]):
+                local[i] = trace[:it][-1]
+                if best is None or local[i] > best[0]:            # first max wins
                     db.copy_to(dm, slot)
                     dm.snapshot()
-                    best_trace = trace[:it] + 0
+                    best = (local[i], i, trace[:it] + 0)
+        self._skip_initials(n_init - consumed)
         db.close()
-        dm.restore()
-        self._pull(dm)
-        return (self.ID_prob, self.beta_mu, self.beta_sum, best_trace)
+        return local, best
+
+    def _fit_inits_single(self, counts, dm, n_init, mine, max_iter_pre, **kwargs):
+        """the same, one restart per device model (problems with no idle columns)"""
+        local, best = {}, None
+        consumed = 0
+        for i in mine:
+            self._skip_initials(i - consumed)
+            consumed = i + 1
+            self.set_initial(self.beta_mu_init, self.beta_sum_init, self.ID_prob_init)
+            self._fit_BV(counts, None, max_iter=max_iter_pre, _dm=dm, **kwargs)
+            local[i] = self.ELBO_iters[-1]
+            if best is None or local[i] > best[0]:
+                dm.snapshot()
+                best = (local[i], i, self.ELBO_iters + 0)
+        self._skip_initials(n_init - consumed)
+        return local, best
 
     def fit(self, AD, DP, n_init=10, max_iter=200, max_iter_pre=100,
-            random_seed=None, **kwargs):
+            random_seed=None, comm=None, **kwargs):
         """VB with multiple initialisations (bmm_model.py:204-263): n_init short fits
-        (max_iter_pre), keep the best by ELBO_iters[-1] (strictly greater), re-fit it
-        (max_iter), add the binomial-coefficient constant.  kwargs -> _fit_BV
-        (min_iter=20, epsilon_conv=1e-2, verbose=True)."""
+        (max_iter_pre), keep the best by ELBO_iters[-1] (strictly greater = the first maximum),
+        re-fit it (max_iter), add the binomial-coefficient constant.  kwargs -> _fit_BV
+        (min_iter=20, epsilon_conv=1e-2, verbose=True).
+
+        ``comm`` (vireo_amd/dist.py) shards the initialisations like ``vireo_wrap``'s restarts
+        (SURVEY.md 8e): initialisation i on rank i % world -- every rank walks the whole random
+        stream and forms only its own draws --, one all-gather of the n_init ELBOs, the owner of
+        the first maximum runs the final fit and broadcasts the state; every rank returns with the
+        same attributes, bit for bit those of the world-1 call."""
+        comm = LocalComm() if comm is None else comm
         if random_seed is not None:
             np.random.seed(random_seed)
         counts = device_counts(AD, DP)
         const = counts.binom_const()
         dm = self._device_model(counts, None)
-        self.ELBO_inits = []
-        R = restart_batch(self.n_donor, n_init, counts.nnz, wide=False)
+        mine = my_restarts(n_init, comm.rank, comm.world)
+        R = restart_batch(self.n_donor, len(mine), counts.nnz, wide=False)
         if R > 1:
-            best = self._fit_inits_batched(counts, dm, n_init, R, max_iter_pre, **kwargs)
-        for i in range(n_init if R == 1 else 0):
-            self.set_initial(self.beta_mu_init, self.beta_sum_init, self.ID_prob_init)
-            self._fit_BV(counts, None, max_iter=max_iter_pre, _dm=dm, **kwargs)
-            self.ELBO_inits.append(self.ELBO_iters[-1])
-            if i == 0 or (self.ELBO_iters[-1] > np.max(self.ELBO_inits[:-1])):
-                best = (self.ID_prob + 0, self.beta_mu + 0, self.beta_sum + 0,
-                        self.ELBO_iters + 0)
-        self.set_initial(best[1], best[2], best[0])
-        self.ELBO_iters = best[3]
-        self._fit_BV(counts, None, max_iter=max_iter, _dm=dm, **kwargs)
+            local, best = self._fit_inits_batched(counts, dm, n_init, mine, R, max_iter_pre, **kwargs)
+        else:
+            local, best = self._fit_inits_single(counts, dm, n_init, mine, max_iter_pre, **kwargs)
+        elbo_inits = gather_restart_elbos(comm, n_init, local)
+        winner = int(np.argmax(elbo_inits))           # bmm_model.py:248-251: the first maximum
+        owner = winner % comm.world
+        if comm.rank == owner:
+            assert best is not None and best[1] == winner
+            dm.restore()
+            self._pull(dm)
+            self.set_initial(self.beta_mu, self.beta_sum, self.ID_prob)
+            self.ELBO_iters = best[2]
+            self._fit_BV(counts, None, max_iter=max_iter, _dm=dm, **kwargs)
         dm.close()
+        if comm.world > 1:
+            for name in ("ID_prob", "beta_mu", "beta_sum"):
+                setattr(self, name, comm.bcast(getattr(self, name), owner))
+            n = comm.bcast(np.array([float(len(self.ELBO_iters))]), owner)
+            trace = self.ELBO_iters if comm.rank == owner else np.zeros(int(n[0]))
+            self.ELBO_iters = comm.bcast(trace, owner)
         self.ELBO_iters = self.ELBO_iters + const
-        self.ELBO_inits = np.array(self.ELBO_inits) + const
+        self.ELBO_inits = np.array(elbo_inits) + const

@@ -7,14 +7,21 @@ on rank i % world -- and the ONLY exchange on the path is an all-gather of the p
 ELBOs (a few hundred bytes over RCCL/xGMI) plus a broadcast of the winner's state.
 
 Backends
-  RcclComm   libvireo_hip.so's RCCL communicator (GPU box)
+  RcclComm   libvireo_hip.so's RCCL communicator (one rank per GPU; the production path)
+  TcpComm    the same three calls over host sockets (star through rank 0) for ranks that SHARE a
+             device, which RCCL refuses: ``VIREO_COMM=tcp`` (the one-GPU test box runs the shard
+             at world 2 and 8 this way, every fit on the real kernels)
   LocalComm  world size 1
-(the CPU-only tests of the sharding logic bring their own gloo communicator with the same
-three methods: tests/gloo_comm.py)
+``make_comm`` picks one from the environment a launcher left (torch.distributed.run or
+vireo_amd/launch.py).  (The CPU-only tests of the sharding logic bring their own gloo
+communicator with the same three methods: tests/gloo_comm.py)
 """
 import ctypes as C
 import os
+import socket
+import struct
 import sys
+import time
 
 import numpy as np
 
@@ -92,6 +99,131 @@ class RcclComm:
         if self._h:
             _lib.lib().vrx_comm_destroy(self._h)
             self._h = C.c_void_p()
+
+
+_HELLO = b"VRXTCP1"
+
+
+def _send(sock, arr):
+    raw = np.ascontiguousarray(arr, dtype=np.float64).tobytes()
+    sock.sendall(struct.pack("<q", len(raw)) + raw)
+
+
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        part = sock.recv(min(1 << 20, n - len(buf)))
+        if not part:
+            raise ConnectionError("peer closed the connection")
+        buf += part
+    return bytes(buf)
+
+
+def _recv(sock):
+    (n,) = struct.unpack("<q", _recv_exact(sock, 8))
+    return np.frombuffer(_recv_exact(sock, n), dtype=np.float64).copy()
+
+
+class TcpComm:
+    """rank 0 listens on (addr, port); ranks 1 .. world-1 connect and stay connected."""
+
+    def __init__(self, rank, world, port, addr="127.0.0.1", timeout=300.0):
+        self.rank, self.world = int(rank), int(world)
+        self._peers = {}          # rank 0: {rank: socket}; others: {0: socket}
+        if self.world == 1:
+            return
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(self.world)
+            srv.settimeout(timeout)
+            try:
+                while len(self._peers) < self.world - 1:
+                    conn, _ = srv.accept()
+                    conn.settimeout(timeout)
+                    msg = _recv_exact(conn, len(_HELLO) + 4)
+                    peer = int.from_bytes(msg[len(_HELLO):], "little")
+                    if msg[:len(_HELLO)] != _HELLO or not 0 < peer < self.world or peer in self._peers:
+                        conn.close()
+                        continue
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    self._peers[peer] = conn
+            finally:
+                srv.close()
+        else:
+            deadline = time.time() + timeout
+            while True:
+                try:
+                    s = socket.create_connection((addr, port), timeout=5.0)
+                    break
+                except OSError:
+                    if time.time() > deadline:
+                        raise TimeoutError("rank 0 never listened on %s:%d" % (addr, port))
+                    time.sleep(0.1)
+            s.settimeout(timeout)
+            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            s.sendall(_HELLO + self.rank.to_bytes(4, "little"))
+            self._peers[0] = s
+
+    def allgather(self, local):
+        local = np.ascontiguousarray(local, dtype=np.float64).ravel()
+        if self.world == 1:
+            return local.copy()
+        if self.rank == 0:
+            parts = [local] + [_recv(self._peers[r]) for r in range(1, self.world)]
+            out = np.concatenate(parts)
+            for r in range(1, self.world):
+                _send(self._peers[r], out)
+            return out
+        _send(self._peers[0], local)
+        return _recv(self._peers[0])
+
+    def bcast(self, arr, root):
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        if self.world == 1:
+            return a.copy()
+        root = int(root)
+        if self.rank == 0:
+            flat = a.ravel() if root == 0 else _recv(self._peers[root])
+            for r in range(1, self.world):
+                if r != root:
+                    _send(self._peers[r], flat)
+            return flat.reshape(a.shape).copy()
+        if self.rank == root:
+            _send(self._peers[0], a.ravel())
+            return a.copy()
+        return _recv(self._peers[0]).reshape(a.shape)
+
+    def barrier(self):
+        self.allgather(np.zeros(1))
+
+    def close(self):
+        for s in self._peers.values():
+            try:
+                s.close()
+            except OSError:
+                pass
+        self._peers = {}
+
+
+def make_comm(rank=None, world=None, device=None, force_rccl=False):
+    """The communicator the environment asks for: LocalComm at world 1 (unless ``force_rccl``
+    or VIREO_FORCE_RCCL=1: the RCCL path on a 1-GPU box), TcpComm with VIREO_COMM=tcp (rendezvous on
+    MASTER_ADDR : VIREO_TCP_PORT or MASTER_PORT + 2), else RcclComm (unique id over MASTER_PORT + 1)."""
+    r, w, d = env_rank_world()
+    rank = r if rank is None else rank
+    world = w if world is None else world
+    device = d if device is None else device
+    kind = os.environ.get("VIREO_COMM", "rccl").lower()
+    if kind not in ("rccl", "tcp"):
+        raise _lib.VrxError("VIREO_COMM must be 'rccl' or 'tcp', not %r" % kind)
+    if kind == "tcp" and world > 1:
+        port = int(os.environ.get("VIREO_TCP_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 2))
+        return TcpComm(rank, world, port, addr=os.environ.get("MASTER_ADDR", "127.0.0.1"))
+    if world > 1 or force_rccl or os.environ.get("VIREO_FORCE_RCCL") == "1":
+        return RcclComm(rank, world, device, socket_exchange(rank, world))
+    return LocalComm()
 
 
 def socket_exchange(rank, world, addr=None, port=None, timeout=600.0):

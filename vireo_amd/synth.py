@@ -92,3 +92,18 @@ def as_scipy(w):
                     shape=w["shape"])
     AD.eliminate_zeros()
     return AD, DP
+
+
+def clone_workload(N=200, M=200000, K=8, seed=0):
+    """BASELINE.json configs[4] (BinomMixtureVB clone mode; generator fixed by SURVEY.md
+    section 8(d)): 90 % dense, DP ~ Poisson(50), allele frequencies ~ Beta(0.3, 3) per
+    (variant, clone).  Same draws in the same order as ``oracle.vireo_oracle.synth_clone``
+    (tested equal in tests/test_host_cpu.py) -> (AD, DP) as scipy CSC."""
+    rng = np.random.default_rng(seed)
+    mask = rng.random((N, M)) < 0.9
+    dp = rng.poisson(50, (N, M)) * mask
+    del mask
+    z = rng.integers(0, K, M)
+    af = rng.beta(0.3, 3, (N, K))
+    ad = rng.binomial(dp, af[:, z])
+    return csc_matrix(ad), csc_matrix(dp)

@@ -18,7 +18,8 @@ import numpy as np
 
 from . import __version__
 from .counts import device_counts
-from .dist import RcclComm, env_rank_world, socket_exchange
+from . import launch
+from .dist import LocalComm, env_rank_world, make_comm
 from .io_utils import match_donor_VCF, read_cellSNP, read_vartrix, write_donor_id
 from .vcf_utils import (GenoINFO_maker, load_VCF, parse_donor_GPb, read_sparse_GeneINFO,
                         write_VCF)
@@ -65,6 +66,9 @@ _MODEL_OPTIONS = [
      "not available in vireo_amd (experimental upstream)"),
     (("--nproc", "-p"), "nproc", int, 1,
      "accepted; the restarts run on the GPU [default: %default]"),
+    (("--nGPU",), "n_gpu", int, 1,
+     "GPUs of this node to share the restarts over: the command starts one process per GPU "
+     "(restart i on GPU i % nGPU, one RCCL all-gather picks the best) [default: %default]"),
 ]
 
 
@@ -159,6 +163,22 @@ def main(argv=None):
         print("use -h or --help for help on argument.")
         sys.exit(1)
 
+    # --nGPU N: the GPU counterpart of the reference's -p / nproc (a multiprocessing.Pool over the
+    # restarts, vireo_wrap.py:74-91).  This process becomes the launcher of N copies of itself
+    # (vireo_amd/launch.py); under an external launcher (torch.distributed.run) the flag is moot.
+    if options.n_gpu is not None and options.n_gpu > 1 and not launch.launched_externally():
+        here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ)
+        env["PYTHONPATH"] = here + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+        sys.stdout.flush()
+        sys.exit(launch.spawn_ranks([sys.executable, "-c",
+                                     "from vireo_amd.vireo import main; main()"] + list(argv),
+                                    options.n_gpu, env=env))
+
+    rank, world, local = env_rank_world()
+    if world > 1 and rank != 0:
+        sys.stdout = open(os.devnull, "w")                          # rank 0 speaks for all
+
     if options.out_dir is None:                                    # vireo.py:96-106
         print("Warning: no outDir provided, we use $cellFilePath/vireo.")
         out_dir = os.path.dirname(os.path.abspath(options.cell_data)) + "/vireo"
@@ -183,15 +203,14 @@ def main(argv=None):
     n_donor, learn_GT, donor_GPb = donors["n_donor"], donors["learn_GT"], donors["GPb"]
     donor_names, donor_vcf = donors["names"], donors["vcf"]
 
-    # Launched once per GPU (python -m torch.distributed.run --nproc-per-node N -m vireo_amd.vireo
-    # ...; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) the restarts are shared
-    # out over the ranks; every rank computes the same result and rank 0 writes the files.
-    rank, world, local = env_rank_world()
-    comm = None
-    if world > 1 or os.environ.get("VIREO_CLI_FORCE_RCCL") == "1":    # (the latter: a 1-GPU test)
-        if rank != 0:
-            sys.stdout = open(os.devnull, "w")                      # rank 0 speaks for all
-        comm = RcclComm(rank, world, local, socket_exchange(rank, world))
+    # Launched once per GPU (--nGPU N, or python -m torch.distributed.run --nproc-per-node N -m
+    # vireo_amd.vireo ...; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) the
+    # restarts are shared out over the ranks; every rank computes the same result and rank 0
+    # writes the files.
+    comm = make_comm(rank, world, local,                           # (the flag: a 1-GPU test of the RCCL path)
+                     force_rccl=os.environ.get("VIREO_CLI_FORCE_RCCL") == "1")
+    if isinstance(comm, LocalComm):
+        comm = None
 
     counts = device_counts(cell_dat['AD'], cell_dat['DP'])         # one upload for everything
     n_vars = counts.n_vars()                                        # vireo.py:191
