@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/vireo_hip.h"
@@ -50,6 +51,10 @@ struct DevBuf {
         n = count;
         if (count == 0) return hipSuccess;
         return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    }
+    void swap(DevBuf& o) {
+        std::swap(p, o.p);
+        std::swap(n, o.n);
     }
     hipError_t upload(const T* src, size_t count, hipStream_t s) {
         hipError_t e = alloc(count);

@@ -1340,6 +1340,11 @@ struct vrx_model {
     int n_cell_part = 0;         // cell partials of the kernel that ran last (softmax or fused cell pass)
     bool theta_pending = false;  // stage-1 partials wait for the finalisation inside vrx_gt_update
     DevBuf<double> part_theta, part_gt, part_cell, part_th;
+    // two-level theta reduction (vrx_theta_partial): VRX_THETA_L2 second-level partials per restart
+    // and the groups' tickets; th_fold = stage-1 blocks per group (0: one level)
+    DevBuf<double> part_theta2;
+    DevBuf<unsigned int> th_tickets;
+    int th_fold = 0;
     DevBuf<double> d_elbo, d_parts;
     int64_t trace_cap = 0;  // ELBO slots per restart in d_elbo
     DevBuf<int32_t> ctl;  // device-side loop control (VRX_CTL_*)
@@ -1385,9 +1390,18 @@ static int ensure_trace(vrx_model* m, int64_t n) {
     if (n <= m->trace_cap) return VRX_OK;
     VRX_REQUIRE(n < ((int64_t)1 << 31), "max_iter too large");
     VRX_HIP(hipStreamSynchronize(m->p->stream));
-    int64_t cap = m->trace_cap;
+    int64_t cap = std::max<int64_t>(m->trace_cap, 1);
     while (cap < n) cap *= 2;
-    VRX_HIP(m->d_elbo.alloc((size_t)m->R * (size_t)cap));
+    // into a temporary: a failed allocation (huge max_iter) must leave the old trace and its
+    // capacity in place -- the model stays usable and the call returns an error code
+    DevBuf<double> grown;
+    const hipError_t e = grown.alloc((size_t)m->R * (size_t)cap);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // (the runtime keeps a failed call's code for the next hipGetLastError: clear it)
+        vrx_set_error("ELBO trace of %lld iterations x %d restarts: %s", (long long)cap, m->R, hipGetErrorString(e));
+        return VRX_ERR_HIP;
+    }
+    m->d_elbo.swap(grown);
     m->trace_cap = cap;
     return VRX_OK;
 }
@@ -1502,6 +1516,16 @@ extern "C" int vrx_model_create(vrx_problem* p, const vrx_model_cfg* cfg, vrx_mo
         VRX_HIP(m->GT.alloc((size_t)m->NKt * m->T));
         VRX_HIP(m->psi.alloc(3 * th));  // [R][3][rows][T]; th counts the R restarts
         VRX_HIP(m->part_theta.alloc((size_t)m->R * m->nb_theta * 2 * VRX_MAXT));
+        // large problems: groups of nb_theta / VRX_THETA_L2 stage-1 blocks fold themselves (the
+        // last block of a group), so that vrx_gt_update can finalise theta (VIREO_THETA_TWO_LEVEL=0: off)
+        if (!cfg->ase_mode && m->nb_theta % VRX_THETA_L2 == 0 && m->nb_theta / VRX_THETA_L2 >= 2 &&
+            m->nb_theta / VRX_THETA_L2 <= VRX_THETA_FOLD_MAX &&
+            env_int("VIREO_THETA_TWO_LEVEL", 1)) {
+            m->th_fold = m->nb_theta / VRX_THETA_L2;
+            VRX_HIP(m->part_theta2.alloc((size_t)m->R * VRX_THETA_L2 * 2 * VRX_MAXT));
+            VRX_HIP(m->th_tickets.alloc((size_t)m->R * VRX_THETA_L2));
+            VRX_HIP(hipMemsetAsync(m->th_tickets.p, 0, (size_t)m->R * VRX_THETA_L2 * sizeof(unsigned int), s));
+        }
         m->n_th_part = cfg->ase_mode ? m->nb_throws : 1;
     } else {
         m->n_th_part = m->nb_nk;
@@ -2217,19 +2241,22 @@ static int theta_step(vrx_model* m, int update, bool defer_final = false) {
                 m->NK, m->T, reinterpret_cast<double2*>(m->S.p), np,
                 reinterpret_cast<const double2*>(m->RV.p), m->s_pending && tv.virt ? tv.n_vrows : 0,
                 m->s_pending && tv.virt && tv.split ? tv.vptr.p : nullptr,
-                m->GT.p, m->part_theta.p, m->batch(), m->ctl.p);
+                m->GT.p, m->part_theta.p, m->part_theta2.p, m->th_tickets.p, m->th_fold, m->batch(), m->ctl.p);
             VRX_HIP(hipGetLastError());
             m->s_pending = false;
         }
+        // what the finalisation sums: the stage-1 partials, or the groups' second-level ones
+        const int fin_n = m->th_fold > 1 ? VRX_THETA_L2 : m->nb_theta;
+        const double* fin_part = m->th_fold > 1 ? m->part_theta2.p : m->part_theta.p;
         // Worth it only while the partials are few: every block of vrx_gt_update re-reads them
         // (c2, 157 partials: 43.4 -> 41.9 us per iteration; c3, 1024 partials = 128 KB per
         // block: 0.994 -> 1.012 ms, so large problems keep the separate one-block kernel).
         static const int fuse_max = env_int("VIREO_FUSE_THETA_MAX_PARTS", 256);
-        if (update && defer_final && m->nb_theta <= fuse_max) {
+        if (update && defer_final && fin_n <= fuse_max) {
             m->theta_pending = true;
         } else {
-            vrx_theta_final<<<m->R, VRX_BLOCK, 0, s>>>(m->nb_theta, m->T, update, c.fix_beta_sum,
-                                                     m->part_theta.p, m->prior1.p, m->prior2.p,
+            vrx_theta_final<<<m->R, VRX_BLOCK, 0, s>>>(fin_n, m->T, update, c.fix_beta_sum,
+                                                     fin_part, m->prior1.p, m->prior2.p,
                                                      m->mu.p, m->sm.p, m->psi.p, m->part_th.p, m->ctl.p);
         }
         m->w_valid = false;
@@ -2248,9 +2275,9 @@ static int gt_step(vrx_model* m, int learn) {
     VrxThetaFuse F{};
     if (m->theta_pending) {
         F.on = 1;
-        F.n_part = m->nb_theta;
+        F.n_part = m->th_fold > 1 ? VRX_THETA_L2 : m->nb_theta;
         F.fix_sum = m->cfg.fix_beta_sum;
-        F.part = m->part_theta.p;
+        F.part = m->th_fold > 1 ? m->part_theta2.p : m->part_theta.p;
         F.prior1 = m->prior1.p;
         F.prior2 = m->prior2.p;
         F.mu = m->mu.p;
@@ -2403,7 +2430,13 @@ extern "C" int vrx_model_fit(vrx_model* m, int32_t max_iter, int32_t min_iter, d
     // Polls are PIPELINED: batch b + 1 is enqueued before the host waits for the control words
     // batch b left, so the device never idles between batches (a 20-iteration restart used to
     // pay five drained queues).  VIREO_FIT_PIPELINE=0: wait before enqueuing, as before.
-    const int pipeline = env_int("VIREO_FIT_PIPELINE", 1);  // (read per call: the tests switch it)
+    // A batch enqueued behind the one that stopped costs its launches (batch x ~5-10 no-op kernels,
+    // drained by the final synchronisation): on launch-bound problems that is more than the drained
+    // queues it saves (c2, 32 one-restart fits: 24.8 ms pipelined against 23.1 ms,
+    // profiles/r05_ab_pipeline_small_problems.txt), so the default pipelines only where an
+    // iteration is long against a launch -- the criterion restarts.restart_batch uses.
+    // VIREO_FIT_PIPELINE=1 / 0 forces it on / off (read per call: the tests switch it).
+    const int pipeline = env_int("VIREO_FIT_PIPELINE", m->p->nnz * (int64_t)m->Kt >= ((int64_t)1 << 24) ? 1 : 0);
     const int R = m->R;  // elbo_trace [R][max_iter], it_out [R], warn_flags [R]
     // two pinned read-back buffers of R * VRX_CTL_WORDS <= 64 words inside h_pin (64 doubles)
     int32_t* hbuf[2] = {reinterpret_cast<int32_t*>(m->h_pin), reinterpret_cast<int32_t*>(m->h_pin) + 64};

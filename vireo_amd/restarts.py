@@ -137,8 +137,7 @@ class DeviceRestarts:
         # from the thread that draws them) while the current one fits.  VIREO_STAGE_UPLOADS=0: off
         self.can_stage = (self.batch == 1 and template.n_donor <= 128 and template.n_GT <= 128
                           and os.environ.get("VIREO_STAGE_UPLOADS", "1") != "0")
-        if self.can_stage:
-            self.dm.stage_reserve()
+        self._stage_ready = False     # the two staging buffers are reserved by the first ``stage`` call
         self._n_staged = 0
         # a staging buffer is free again once ``run`` has taken its content into the model's
         # state: the producer thread waits for that (two buffers = two slots)
@@ -213,6 +212,11 @@ class DeviceRestarts:
         buf = self._n_staged & 1
         self._n_staged += 1
         with _phase("stage"):
+            if not self._stage_ready:
+                # (two extra copies of the (ID, GT) state, ~90 MB at c3: only a search that really
+                #  draws both arrays per restart pays for them)
+                self.dm.stage_reserve()
+                self._stage_ready = True
             self.dm.stage_raw(buf, ID_raw, GT_raw)
         return Staged(buf)
 

@@ -190,31 +190,33 @@ def _search(counts, plan, comm, max_iter_init, delay_fit_theta, kwargs, restarts
     # the generator runs one restart ahead on a helper thread: the Mersenne Twister (host, serial)
     # and the fit (device) overlap; the helper is the only user of the stream meanwhile
     try:
-        for im, ID_raw, GT_raw in _one_ahead(draws(), depth=batch):
-            args = (im, ID_raw, GT_raw, ID0, GT0_first if im == 0 else GT0, max_iter_init,
-                    delay_fit_theta)
-            if batch > 1:
-                runner.submit(*args)         # fitted `batch` at a time
-            else:
-                local[im] = runner.run(*args)
-    except BaseException:
-        if hasattr(runner, "cancel"):        # (the helper thread may be waiting for a staging buffer)
-            runner.cancel()
-        raise
-    if batch > 1:
-        local.update(runner.flush())
-    if restarts_mod.PHASES is not None:
-        restarts_mod.PHASES["search_wall"] = time.perf_counter() - t_search
-    with _phase("gather"):
-        elbo_all = gather_restart_elbos(comm, plan.n_init, local)
-    best = int(np.argmax(elbo_all))              # first max wins, vireo_wrap.py:90-91
-    owner = best % comm.world
-    model = runner.winner(best, refine=plan.n_extra == 0) if comm.rank == owner else tmpl
-    LAST_SEARCH.clear()
-    LAST_SEARCH.update(restarts=len(local), restart_iterations=getattr(runner, "iterations", 0),
-                       final_iterations=getattr(runner, "final_iterations", 0), best=best,
-                       owner=owner, batch=batch)
-    runner.close()
+        try:
+            for im, ID_raw, GT_raw in _one_ahead(draws(), depth=batch):
+                args = (im, ID_raw, GT_raw, ID0, GT0_first if im == 0 else GT0, max_iter_init,
+                        delay_fit_theta)
+                if batch > 1:
+                    runner.submit(*args)         # fitted `batch` at a time
+                else:
+                    local[im] = runner.run(*args)
+        except BaseException:
+            if hasattr(runner, "cancel"):        # (the helper thread may be waiting for a staging buffer)
+                runner.cancel()
+            raise
+        if batch > 1:
+            local.update(runner.flush())
+        if restarts_mod.PHASES is not None:
+            restarts_mod.PHASES["search_wall"] = time.perf_counter() - t_search
+        with _phase("gather"):
+            elbo_all = gather_restart_elbos(comm, plan.n_init, local)
+        best = int(np.argmax(elbo_all))              # first max wins, vireo_wrap.py:90-91
+        owner = best % comm.world
+        model = runner.winner(best, refine=plan.n_extra == 0) if comm.rank == owner else tmpl
+        LAST_SEARCH.clear()
+        LAST_SEARCH.update(restarts=len(local), restart_iterations=getattr(runner, "iterations", 0),
+                           final_iterations=getattr(runner, "final_iterations", 0), best=best,
+                           owner=owner, batch=batch)
+    finally:
+        runner.close()       # device models and staging buffers go now, not at garbage collection
     with _phase("broadcast"):
         _bcast_model(comm, model, owner)
     return model, elbo_all
