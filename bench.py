@@ -238,6 +238,62 @@ def c3_skew_leg(device, K, uniform_ms, steps=100):
                 lds_passes=bool(info["lds_variant"] and info["lds_cell"]), kernel_info=info)
 
 
+def e2e_leg(w, K, n_init=8):
+    """The `vireo` COMMAND end to end at the headline size (vireoSNP/vireo.py:109-242): a cellSNP
+    folder on disk (two MatrixMarket files of ~1e8 entries, a VCF of the variants, the barcodes)
+    -> loaders -> device problem -> vireo_wrap(n_init restarts, doublets) -> donor_ids.tsv,
+    summary.tsv, prob_*.tsv.gz, GT_donors.vireo.vcf.gz.  Wall seconds of the command and of its
+    phases (wrappers around the command's own calls); the folder is written beforehand (not part
+    of the command) and removed afterwards."""
+    import shutil
+    import tempfile
+    from vireo_amd import synth
+    from vireo_amd import vireo as cli
+    root = tempfile.mkdtemp(prefix="vireo_e2e_")
+    phases = {}
+
+    def timed(mod, name, key):
+        fn = getattr(mod, name)
+
+        def wrapper(*a, **k):
+            t0 = time.perf_counter()
+            try:
+                return fn(*a, **k)
+            finally:
+                phases[key] = phases.get(key, 0.0) + time.perf_counter() - t0
+        setattr(mod, name, wrapper)
+        return fn
+
+    saved = []
+    try:
+        t0 = time.perf_counter()
+        nbytes = synth.write_cellsnp_folder(w, root + "/cells")
+        t_write = time.perf_counter() - t0
+        for name, key in (("load_cells", "load (VCF + 2 MatrixMarket files -> CSC)"),
+                          ("device_counts", "device problem (merge + upload + both tiled streams)"),
+                          ("vireo_wrap", "vireo_wrap (restarts, final fit, doublets)"),
+                          ("write_donor_id", "write donor_ids / summary / prob tables"),
+                          ("write_VCF", "write GT_donors.vireo.vcf.gz")):
+            saved.append((name, timed(cli, name, key)))
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()) as out:
+            cli.main(["-c", root + "/cells", "-N", str(K), "-o", root + "/out", "--randSeed", "1",
+                      "-M", str(n_init), "--noPlot"])
+        wall = time.perf_counter() - t0
+        files = sorted(os.listdir(root + "/out"))
+        summary = open(root + "/out/summary.tsv").read().split("\n")[1:-1]
+    finally:
+        for name, fn in saved:
+            setattr(cli, name, fn)
+        shutil.rmtree(root, ignore_errors=True)
+    N, M = w["shape"]
+    return dict(workload="`vireo -c <cellSNP folder> -N %d -M %d --randSeed 1` on the headline data written to "
+                         "disk: N=%d x M=%d, %.2f GB of input files" % (K, n_init, N, M, nbytes / 1e9),
+                wall_s=wall, phases_s={k: round(v, 3) for k, v in phases.items()},
+                other_s=round(wall - sum(phases.values()), 3), folder_written_in_s=round(t_write, 2),
+                output_files=files, summary=summary, log_tail=out.getvalue().strip().split("\n")[-1])
+
+
 def c5_gpu_leg(device, steps=50):
     """BASELINE.json configs[4]: BinomMixtureVB clone mode, N=200 variants x M=200k cells, K=8
     clones (bmm_model.py:178-201: one iteration = theta update, E[log lik], ID update, ELBO).
@@ -471,6 +527,10 @@ def main():
     if solo and not args.no_side_legs and args.config == "c3":
         c3_skew = c3_skew_leg(local, K, (float(np.median(repeats)), nnz))
 
+    e2e = None
+    if solo and not args.no_side_legs and args.config == "c3":
+        e2e = e2e_leg(w, K)
+
     # ---- CPU legs (rank 0): the oracle beside the GPU results formed above --------------------
     if c5 is not None:
         c5 = c5_cpu_leg(c5, c5_data)
@@ -602,6 +662,7 @@ def main():
             "c2": c2,
             "c5": c5,
             "c3_skew": c3_skew,
+            "e2e": e2e,
             "ms_per_step_repeats": {"runs": [round(x, 4) for x in repeats],
                                     "min": round(min(repeats), 4), "median": round(float(np.median(repeats)), 4),
                                     "max": round(max(repeats), 4),

@@ -295,6 +295,12 @@ int vrx_merge_counts(int64_t n_var, int64_t n_cell, const void* ad_ptr, const vo
                      int32_t* dp, int n_threads);
 int vrx_mtx_read(const char* path, int64_t nnz, int32_t* row, int32_t* col, int32_t* val,
                  int n_threads);
+/* The inverse of vrx_mtx_read: a `coordinate integer general` file from 0-based COO arrays, in
+ * the given order (the format of cellSNP's cellSNP.tag.{AD,DP}.mtx that read_cellSNP loads,
+ * io_utils.py:57; the reference itself never writes one).  Multi-threaded formatting; used by
+ * bench.py's end-to-end leg and the parser's round-trip test.  Host only. */
+int vrx_mtx_write(const char* path, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                  const int32_t* row, const int32_t* col, const int32_t* val);
 
 /* ---- text writers of the command (host only) ----------------------------------------------
  * vrx_write_table: prob_singlet.tsv / prob_doublet.tsv of write_donor_id (io_utils.py:147-170):

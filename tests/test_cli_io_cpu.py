@@ -81,3 +81,33 @@ def test_writers_layout(tmp_path):
     assert summ[0] == "Var1\tFreq" and sum(int(l.split("\t")[1]) for l in summ[1:] if l) == 952
     assert open(tmp_path / "_log.txt").read().startswith("logLik: %.3e\n" % g["LB_doublet"])
     assert os.path.exists(tmp_path / "prob_singlet.tsv.gz")
+
+
+def test_mtx_writer_round_trip(tmp_path, monkeypatch):
+    """vrx_mtx_write (bench.py's end-to-end leg writes 1e8-entry cellSNP matrices with it) against
+    the library's own parser and against scipy.io.mmread: same shape, same entries in file order;
+    and the synthetic cellSNP folder loads back to the workload it was written from."""
+    import ctypes as C
+    from scipy.io import mmread
+    from vireo_amd import _lib, io_utils, synth
+    monkeypatch.setenv("VIREO_WRITER_CHUNK_BYTES", "4096")      # many chunks, several threads
+    rng = np.random.default_rng(0)
+    n = 20000
+    row = rng.integers(0, 700, n).astype(np.int32)
+    col = rng.integers(0, 90, n).astype(np.int32)
+    val = rng.integers(1, 5000, n).astype(np.int32)
+    path = str(tmp_path / "m.mtx")
+    i32 = C.POINTER(C.c_int32)
+    _lib.check(_lib.lib().vrx_mtx_write(path.encode(), 700, 90, n, row.ctypes.data_as(i32),
+                                        col.ctypes.data_as(i32), val.ctypes.data_as(i32)))
+    got = io_utils.read_mtx(path)
+    assert got.shape == (700, 90) and np.array_equal(got.row, row) and np.array_equal(got.col, col)
+    assert np.array_equal(got.data, val)
+    ref = mmread(path)
+    assert (ref.tocsc() != got.tocsc()).nnz == 0
+    w = synth.donor_workload(300, 200, 3, 0.05, seed=1)
+    synth.write_cellsnp_folder(w, str(tmp_path / "cells"))
+    dat = io_utils.read_cellSNP(str(tmp_path / "cells"))
+    AD, DP = synth.as_scipy(w)
+    assert (dat["AD"] != AD).nnz == 0 and (dat["DP"] != DP).nnz == 0
+    assert len(dat["samples"]) == 200 and len(dat["variants"]) == 300

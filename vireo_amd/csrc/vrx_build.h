@@ -33,6 +33,9 @@ struct VrxTileArgs {  // one orientation's tiled-stream geometry, by value to th
     int RW, NR, G, U, n_slab, slab_rows, form, PH, bit_shift, pairing, xor_partner;
     uint32_t f1_base, pad_word;
     int64_t n_wave;
+#ifdef VRX_CAP_PROBE
+    int cap;  // TIMING PROBE ONLY (scratch builds, -DVRX_CAP_PROBE): words kept per (row, slab); the rest is DROPPED
+#endif
 };
 
 // ------------------------------------------------------------------------------------
@@ -239,6 +242,9 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_build_count(VrxTileArgs A, int3
                     const int ca = vrx_chunks(x.x), cb = vrx_chunks((int64_t)x.y - x.x);
                     if (A.form == 1) {
                         n += ca + cb;
+#ifdef VRX_CAP_PROBE
+                        if (A.cap > 0 && n > A.cap) n = A.cap;
+#endif
                     } else {
                         n += ca;
                         n2 += cb;
@@ -285,7 +291,18 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_build_offsets(VrxTileArgs A, co
 // the words of one segment, in the order of build_tiled: f(word) for every entry / chunk
 template <class F>
 __device__ __forceinline__ void vrx_segment_words(const VrxTileArgs& A, int64_t lo, int64_t hi, int step,
-                                                  int64_t base, int ph, F&& f) {
+                                                  int64_t base, int ph, F&& f0) {
+#ifdef VRX_CAP_PROBE
+    int left = A.cap > 0 ? A.cap : INT32_MAX;
+    auto f = [&](uint32_t wd) {
+        if (left > 0) {
+            --left;
+            f0(wd);
+        }
+    };
+#else
+    F& f = f0;
+#endif
     for (int64_t e = lo; e < hi; e += step) {
         const int2 x = A.val[e];
         const uint32_t loc = (uint32_t)(A.idx[e] - base);

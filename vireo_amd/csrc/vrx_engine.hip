@@ -544,6 +544,9 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
         A.f1_base = f1_base;
         A.pad_word = pad_word;
         A.n_wave = n_wave;
+#ifdef VRX_CAP_PROBE
+        A.cap = t.virt ? env_int("VIREO_CAP_PROBE_VAR", 0) : env_int("VIREO_CAP_PROBE_CELL", 0);
+#endif
         const int64_t n_pos = n_wave * t.n_slab * RW, nsr = (int64_t)t.n_slab * NR * PH;
         VRX_REQUIRE(n_pos < INT32_MAX * (int64_t)VRX_BLOCK, "tiled stream: too many segments");
         VRX_HIP(seg_lo.alloc((size_t)n_pos));
@@ -1340,11 +1343,6 @@ struct vrx_model {
     int n_cell_part = 0;         // cell partials of the kernel that ran last (softmax or fused cell pass)
     bool theta_pending = false;  // stage-1 partials wait for the finalisation inside vrx_gt_update
     DevBuf<double> part_theta, part_gt, part_cell, part_th;
-    // two-level theta reduction (vrx_theta_partial): VRX_THETA_L2 second-level partials per restart
-    // and the groups' tickets; th_fold = stage-1 blocks per group (0: one level)
-    DevBuf<double> part_theta2;
-    DevBuf<unsigned int> th_tickets;
-    int th_fold = 0;
     DevBuf<double> d_elbo, d_parts;
     int64_t trace_cap = 0;  // ELBO slots per restart in d_elbo
     DevBuf<int32_t> ctl;  // device-side loop control (VRX_CTL_*)
@@ -1516,16 +1514,6 @@ extern "C" int vrx_model_create(vrx_problem* p, const vrx_model_cfg* cfg, vrx_mo
         VRX_HIP(m->GT.alloc((size_t)m->NKt * m->T));
         VRX_HIP(m->psi.alloc(3 * th));  // [R][3][rows][T]; th counts the R restarts
         VRX_HIP(m->part_theta.alloc((size_t)m->R * m->nb_theta * 2 * VRX_MAXT));
-        // large problems: groups of nb_theta / VRX_THETA_L2 stage-1 blocks fold themselves (the
-        // last block of a group), so that vrx_gt_update can finalise theta (VIREO_THETA_TWO_LEVEL=0: off)
-        if (!cfg->ase_mode && m->nb_theta % VRX_THETA_L2 == 0 && m->nb_theta / VRX_THETA_L2 >= 2 &&
-            m->nb_theta / VRX_THETA_L2 <= VRX_THETA_FOLD_MAX &&
-            env_int("VIREO_THETA_TWO_LEVEL", 1)) {
-            m->th_fold = m->nb_theta / VRX_THETA_L2;
-            VRX_HIP(m->part_theta2.alloc((size_t)m->R * VRX_THETA_L2 * 2 * VRX_MAXT));
-            VRX_HIP(m->th_tickets.alloc((size_t)m->R * VRX_THETA_L2));
-            VRX_HIP(hipMemsetAsync(m->th_tickets.p, 0, (size_t)m->R * VRX_THETA_L2 * sizeof(unsigned int), s));
-        }
         m->n_th_part = cfg->ase_mode ? m->nb_throws : 1;
     } else {
         m->n_th_part = m->nb_nk;
@@ -2241,22 +2229,19 @@ static int theta_step(vrx_model* m, int update, bool defer_final = false) {
                 m->NK, m->T, reinterpret_cast<double2*>(m->S.p), np,
                 reinterpret_cast<const double2*>(m->RV.p), m->s_pending && tv.virt ? tv.n_vrows : 0,
                 m->s_pending && tv.virt && tv.split ? tv.vptr.p : nullptr,
-                m->GT.p, m->part_theta.p, m->part_theta2.p, m->th_tickets.p, m->th_fold, m->batch(), m->ctl.p);
+                m->GT.p, m->part_theta.p, m->batch(), m->ctl.p);
             VRX_HIP(hipGetLastError());
             m->s_pending = false;
         }
-        // what the finalisation sums: the stage-1 partials, or the groups' second-level ones
-        const int fin_n = m->th_fold > 1 ? VRX_THETA_L2 : m->nb_theta;
-        const double* fin_part = m->th_fold > 1 ? m->part_theta2.p : m->part_theta.p;
         // Worth it only while the partials are few: every block of vrx_gt_update re-reads them
         // (c2, 157 partials: 43.4 -> 41.9 us per iteration; c3, 1024 partials = 128 KB per
         // block: 0.994 -> 1.012 ms, so large problems keep the separate one-block kernel).
         static const int fuse_max = env_int("VIREO_FUSE_THETA_MAX_PARTS", 256);
-        if (update && defer_final && fin_n <= fuse_max) {
+        if (update && defer_final && m->nb_theta <= fuse_max) {
             m->theta_pending = true;
         } else {
-            vrx_theta_final<<<m->R, VRX_BLOCK, 0, s>>>(fin_n, m->T, update, c.fix_beta_sum,
-                                                     fin_part, m->prior1.p, m->prior2.p,
+            vrx_theta_final<<<m->R, VRX_BLOCK, 0, s>>>(m->nb_theta, m->T, update, c.fix_beta_sum,
+                                                     m->part_theta.p, m->prior1.p, m->prior2.p,
                                                      m->mu.p, m->sm.p, m->psi.p, m->part_th.p, m->ctl.p);
         }
         m->w_valid = false;
@@ -2275,9 +2260,9 @@ static int gt_step(vrx_model* m, int learn) {
     VrxThetaFuse F{};
     if (m->theta_pending) {
         F.on = 1;
-        F.n_part = m->th_fold > 1 ? VRX_THETA_L2 : m->nb_theta;
+        F.n_part = m->nb_theta;
         F.fix_sum = m->cfg.fix_beta_sum;
-        F.part = m->th_fold > 1 ? m->part_theta2.p : m->part_theta.p;
+        F.part = m->part_theta.p;
         F.prior1 = m->prior1.p;
         F.prior2 = m->prior2.p;
         F.mu = m->mu.p;

@@ -965,3 +965,30 @@ extern "C" int vrx_write_vcf_records(const char* path, const char* head, const c
         s.push_back('\n');
     });
 }
+
+// A `coordinate integer general` MatrixMarket file from 0-based COO arrays, in the given order:
+// the inverse of vrx_mtx_read (cellSNP writes such files; the reference only reads them,
+// io_utils.py:57).  Used by bench.py's end-to-end leg (1e8 entries: NumPy's savetxt needs minutes)
+// and by the parser's round-trip test.
+extern "C" int vrx_mtx_write(const char* path, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                             const int32_t* row, const int32_t* col, const int32_t* val) {
+    if (!path || n_rows < 0 || n_cols < 0 || nnz < 0 || (nnz > 0 && (!row || !col || !val))) {
+        vrx_set_error("vrx_mtx_write: bad argument");
+        return VRX_ERR_ARG;
+    }
+    std::string head = "%%MatrixMarket matrix coordinate integer general\n%\n";
+    put_int(head, n_rows);
+    head.push_back(' ');
+    put_int(head, n_cols);
+    head.push_back(' ');
+    put_int(head, nnz);
+    head.push_back('\n');
+    return write_rows(path, head.c_str(), nnz, 24, false, [&](int64_t e, std::string& s) {
+        put_int(s, (int64_t)row[e] + 1);
+        s.push_back(' ');
+        put_int(s, (int64_t)col[e] + 1);
+        s.push_back(' ');
+        put_int(s, (int64_t)val[e]);
+        s.push_back('\n');
+    });
+}

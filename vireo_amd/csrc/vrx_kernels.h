@@ -26,8 +26,6 @@
 constexpr int VRX_BLOCK = 256;  // 4 wavefronts
 constexpr int VRX_WAVES = VRX_BLOCK / 64;
 constexpr int VRX_MAXT = 8;  // max genotype classes handled by the dense kernels
-constexpr int VRX_THETA_L2 = 256;  // second-level theta partials (= VRX_BLOCK: one per thread of the finalisation)
-constexpr int VRX_THETA_FOLD_MAX = VRX_BLOCK / (2 * 8);  // stage-1 blocks per group at most (a thread per value)
 
 // ------------------------------------------------------------------------------------
 // Device-side loop control.  The host enqueues several iterations at a time; the stop rule of
@@ -1419,8 +1417,8 @@ template <int TT>  // genotype classes: 3 exactly (no per-class branches), or VR
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_partial(
     int64_t NK, int T, double2* S, const uint16_t* __restrict__ npiece,
     const double2* __restrict__ ranges, int64_t n_virtual, const int32_t* __restrict__ vptr,
-    const double* __restrict__ GT, double* part, double* __restrict__ part2,
-    unsigned int* __restrict__ tickets, int fold, VrxBatch B, const int32_t* __restrict__ ctl) {
+    const double* __restrict__ GT, double* __restrict__ part, VrxBatch B,
+    const int32_t* __restrict__ ctl) {
     const int rb = blockIdx.y;
     const int Tn = TT == VRX_MAXT ? T : TT;
     const int stop = ctl[rb * VRX_CTL_WORDS + VRX_CTL_STOP];
@@ -1518,53 +1516,7 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_partial(
                 acc[VRX_MAXT + t] += s2 * g;
             }
     }
-    double* mine = part + ((int64_t)rb * gridDim.x + blockIdx.x) * 2 * VRX_MAXT;
-    if (fold <= 1) {
-        block_sum_store<2 * VRX_MAXT>(acc, mine, VRX_MAXT, T);
-        return;
-    }
-    // Two-level reduction (large problems: gridDim.x = fold * VRX_THETA_L2 stage-1 blocks).  The
-    // blocks x, x + L2, x + 2 L2, ... form group x; whichever of them finishes LAST adds the
-    // group's partials in that order -- exactly the four-stride sum thread x of vrx_theta_final
-    // would form, so the L2 second-level partials continue to the same bits -- and only those
-    // reach the consumer, few enough for vrx_gt_update to finalise theta itself (VrxThetaFuse):
-    // vrx_theta_final, a one-block latency chain, and a kernel boundary leave the iteration.
-    // No agent-scope fence (an L2 write-back of this kernel's 25 MB of S on a multi-XCD part): the
-    // partials are written through (agent-scope relaxed atomic stores = global_store sc1) and
-    // complete -- s_waitcnt vmcnt(0), what a workgroup-scope release is -- before the ticket is
-    // taken; the last block reads them with agent-scope loads (sc1: past its XCD's L2).  Tickets
-    // count up for ever; a stopped restart's blocks all return above, so a group never splits.
-    __shared__ double blk[2 * VRX_MAXT];
-    __shared__ double grp[VRX_THETA_FOLD_MAX][2 * VRX_MAXT];
-    __shared__ int last;
-    block_sum_store<2 * VRX_MAXT>(acc, blk, VRX_MAXT, T);
-    const int g = blockIdx.x % VRX_THETA_L2;
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int t = 0; t < 2 * VRX_MAXT; ++t)
-            if (t % VRX_MAXT < T) __hip_atomic_store(mine + t, blk[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        const unsigned tk = __hip_atomic_fetch_add(tickets + rb * VRX_THETA_L2 + g, 1u, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
-        last = tk % (unsigned)fold == (unsigned)fold - 1u;
-    }
-    __syncthreads();
-    if (!last) return;  // (uniform)
-    // the group's fold x 2T values in ONE round trip (a thread each), then summed in stride order
-    {
-        const int u = threadIdx.x / (2 * VRX_MAXT), t = threadIdx.x % (2 * VRX_MAXT);
-        if (u < fold && t % VRX_MAXT < T)
-            grp[u][t] = __hip_atomic_load(part + ((int64_t)rb * gridDim.x + g + (int64_t)u * VRX_THETA_L2) * 2 * VRX_MAXT + t,
-                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (threadIdx.x < 2 * VRX_MAXT) {
-        const int t = threadIdx.x;
-        double a = 0.0;
-        if (t % VRX_MAXT < T)
-            for (int u = 0; u < fold; ++u) a += grp[u][t];
-        part2[((int64_t)rb * VRX_THETA_L2 + g) * 2 * VRX_MAXT + t] = a;
-    }
+    block_sum_store<2 * VRX_MAXT>(acc, part + ((int64_t)rb * gridDim.x + blockIdx.x) * 2 * VRX_MAXT, VRX_MAXT, T);
 }
 
 // ASE mode: one theta row per variant (vireo_model.py:82,:177 axis=1).  Thread per variant.

@@ -107,3 +107,39 @@ def clone_workload(N=200, M=200000, K=8, seed=0):
     af = rng.beta(0.3, 3, (N, K))
     ad = rng.binomial(dp, af[:, z])
     return csc_matrix(ad), csc_matrix(dp)
+
+
+def write_cellsnp_folder(w, path, n_threads=0):
+    """A cellSNP output folder (what ``read_cellSNP`` loads, io_utils.py:42-59) holding workload
+    ``w`` of ``donor_workload``: cellSNP.tag.AD.mtx / cellSNP.tag.DP.mtx (MatrixMarket coordinate
+    integer, entries variant-major like cellSNP writes them, zeros of AD left out),
+    cellSNP.base.vcf.gz (one record per variant) and cellSNP.samples.tsv.  The matrices are
+    written by the library (vrx_mtx_write: all cores; NumPy's savetxt needs minutes at 1e8
+    entries).  -> bytes written"""
+    import ctypes as C
+    import gzip
+    import os
+    from . import _lib
+    N, M = w["shape"]
+    os.makedirs(path, exist_ok=True)
+    cols = np.repeat(np.arange(M, dtype=np.int32), np.diff(w["colptr"]))
+    order = np.argsort(w["rowidx"], kind="stable")           # variant-major, cells increasing
+    rows, cols = w["rowidx"][order], cols[order]
+    i32 = C.POINTER(C.c_int32)
+    total = 0
+    for name, val in (("AD", w["ad"][order]), ("DP", w["dp"][order])):
+        keep = val > 0
+        r, c, v = (np.ascontiguousarray(x[keep], dtype=np.int32) for x in (rows, cols, val))
+        f = os.path.join(path, "cellSNP.tag.%s.mtx" % name)
+        _lib.check(_lib.lib().vrx_mtx_write(f.encode(), N, M, r.size, r.ctypes.data_as(i32),
+                                            c.ctypes.data_as(i32), v.ctypes.data_as(i32)))
+        total += os.path.getsize(f)
+    f = os.path.join(path, "cellSNP.base.vcf.gz")
+    with gzip.open(f, "wt", compresslevel=1) as fh:
+        fh.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
+        fh.write("".join("1\t%d\t.\tA\tG\t.\tPASS\tAD=1;DP=2;OTH=0\n" % (i + 1) for i in range(N)))
+    total += os.path.getsize(f)
+    f = os.path.join(path, "cellSNP.samples.tsv")
+    with open(f, "w") as fh:
+        fh.write("\n".join("CELL%07d-1" % i for i in range(M)) + "\n")
+    return total + os.path.getsize(f)
