@@ -295,6 +295,15 @@ int vrx_merge_counts(int64_t n_var, int64_t n_cell, const void* ad_ptr, const vo
                      int32_t* dp, int n_threads);
 int vrx_mtx_read(const char* path, int64_t nnz, int32_t* row, int32_t* col, int32_t* val,
                  int n_threads);
+/* The COO arrays of vrx_mtx_read -> CSC: `mmread(...).tocsc()` of read_cellSNP / read_vartrix
+ * (io_utils.py:57,72-73; SciPy's single-threaded coo_tocsr) as a stable counting sort by column
+ * on all cores.  colptr [n_cols + 1], rowidx / data [nnz] (data int64 like mmread's).
+ * *canonical = 1 when every column's rows come out strictly increasing (no duplicates, file was
+ * row-major: what cellSNP writes); 0: the caller must sort / sum duplicates (SciPy does).
+ * Host only. */
+int vrx_coo_to_csc(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* row,
+                   const int32_t* col, const int32_t* val, int64_t* colptr, int32_t* rowidx,
+                   int64_t* data, int32_t* canonical, int n_threads);
 /* The inverse of vrx_mtx_read: a `coordinate integer general` file from 0-based COO arrays, in
  * the given order (the format of cellSNP's cellSNP.tag.{AD,DP}.mtx that read_cellSNP loads,
  * io_utils.py:57; the reference itself never writes one).  Multi-threaded formatting; used by

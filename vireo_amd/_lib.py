@@ -85,6 +85,8 @@ SIGNATURES = {
                                    _P, _P, _P, C.c_int, C.c_int, C.c_int, _I64, _I32, _I32, _I32,
                                    C.c_int]),
     "vrx_mtx_read": (C.c_int, [C.c_char_p, C.c_int64, _I32, _I32, _I32, C.c_int]),
+    "vrx_coo_to_csc": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, _I32, _I32, _I32, _I64, _I32, _I64, _I32,
+                                 C.c_int]),
     "vrx_mtx_write": (C.c_int, [C.c_char_p, C.c_int64, C.c_int64, C.c_int64, _I32, _I32, _I32]),
     "vrx_write_table": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, _P, _D, C.c_int64, C.c_int64,
                                   C.c_char_p, C.c_int32]),

@@ -805,6 +805,82 @@ extern "C" int vrx_merge_counts(int64_t n_var, int64_t n_cell, const void* ad_pt
     return VRX_OK;
 }
 
+// COO (file order of a MatrixMarket file) -> CSC, what `mmread(...).tocsc()` does in read_cellSNP /
+// read_vartrix (vireoSNP/utils/io_utils.py:57,72-73) with SciPy's single-threaded coo_tocsr: at
+// 1e8 entries that conversion, twice, was the longest phase of the whole command.  A stable
+// counting sort by column on all cores: per-thread column histograms over contiguous chunks of
+// the entries, one pass over the columns to turn them into write offsets, an ordered scatter.
+// Entries keep their file order inside a column; *canonical = 1 when the rows of every column
+// come out strictly increasing (cellSNP writes variant-major files: always) -- otherwise the
+// caller lets SciPy sort and sum the duplicates, as the reference would.  data is int64 like
+// mmread's `integer` matrices.
+extern "C" int vrx_coo_to_csc(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* row,
+                              const int32_t* col, const int32_t* val, int64_t* colptr,
+                              int32_t* rowidx, int64_t* data, int32_t* canonical, int n_threads) {
+    if (n_rows < 0 || n_cols < 0 || nnz < 0 || !colptr || !canonical ||
+        (nnz > 0 && (!row || !col || !val || !rowidx || !data))) {
+        vrx_set_error("vrx_coo_to_csc: bad argument");
+        return VRX_ERR_ARG;
+    }
+    int T = n_threads > 0 ? n_threads : (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+    T = (int)std::max<int64_t>(1, std::min<int64_t>(T, nnz / 65536 + 1));
+    std::vector<std::vector<int64_t>> hist((size_t)T, std::vector<int64_t>((size_t)n_cols, 0));
+    std::vector<char> bad((size_t)T, 0);
+    auto over_entries = [&](auto&& f) {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < T; ++t) pool.emplace_back([&, t] { f(nnz * t / T, nnz * (t + 1) / T, t); });
+        for (auto& th : pool) th.join();
+    };
+    over_entries([&](int64_t e0, int64_t e1, int t) {
+        int64_t* h = hist[(size_t)t].data();
+        for (int64_t e = e0; e < e1; ++e) {
+            const int64_t c = col[e], r = row[e];
+            if (c < 0 || c >= n_cols || r < 0 || r >= n_rows) {
+                bad[(size_t)t] = 1;
+                return;
+            }
+            ++h[c];
+        }
+    });
+    for (char b : bad)
+        if (b) {
+            vrx_set_error("vrx_coo_to_csc: an index outside the %lld x %lld matrix", (long long)n_rows,
+                          (long long)n_cols);
+            return VRX_ERR_ARG;
+        }
+    int64_t base = 0;
+    colptr[0] = 0;
+    for (int64_t c = 0; c < n_cols; ++c) {  // thread t's entries of column c start at hist[t][c]
+        for (int t = 0; t < T; ++t) {
+            const int64_t n = hist[(size_t)t][(size_t)c];
+            hist[(size_t)t][(size_t)c] = base;
+            base += n;
+        }
+        colptr[c + 1] = base;
+    }
+    over_entries([&](int64_t e0, int64_t e1, int t) {
+        int64_t* h = hist[(size_t)t].data();
+        for (int64_t e = e0; e < e1; ++e) {
+            const int64_t at = h[col[e]]++;
+            rowidx[at] = row[e];
+            data[at] = val[e];
+        }
+    });
+    std::vector<char> loose(256, 0);
+    over_columns(n_cols, n_threads, [&](int64_t c0, int64_t c1, int tid) {
+        for (int64_t c = c0; c < c1; ++c)
+            for (int64_t e = colptr[c] + 1; e < colptr[c + 1]; ++e)
+                if (rowidx[e] <= rowidx[e - 1]) {
+                    loose[(size_t)(tid & 255)] = 1;
+                    return;
+                }
+    });
+    *canonical = 1;
+    for (char b : loose)
+        if (b) *canonical = 0;
+    return VRX_OK;
+}
+
 // ------------------------------------------------------------------------------------
 // Text writers of the command (vireoSNP/utils/io_utils.py:147-170 prob_singlet.tsv /
 // prob_doublet.tsv; vcf_utils.py:234-296 the donor genotype VCF).  The reference formats every

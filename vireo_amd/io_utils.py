@@ -12,10 +12,29 @@ from itertools import combinations
 import ctypes as C
 
 import numpy as np
-from scipy.sparse import coo_matrix
+from scipy.sparse import coo_matrix, csc_matrix
 
 from . import _lib
 from .vcf_utils import _labels_blob, load_VCF, match_SNPs
+
+
+def _read_mtx_arrays(path, n_threads=0):
+    """-> ((n_rows, n_cols), row, col, val) int32 COO arrays in file order from the library's
+    multi-threaded parser (vrx_mtx_read), or None for what it does not read (gzipped files,
+    symmetric / complex / array storage)"""
+    path = str(path)
+    L = _lib.lib()
+    n_rows, n_cols, nnz = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    if path.endswith(".gz") or L.vrx_mtx_header(path.encode(), C.byref(n_rows), C.byref(n_cols),
+                                                C.byref(nnz)) != 0:
+        return None
+    row = np.empty(nnz.value, dtype=np.int32)
+    col = np.empty(nnz.value, dtype=np.int32)
+    val = np.empty(nnz.value, dtype=np.int32)
+    i32 = C.POINTER(C.c_int32)
+    _lib.check(L.vrx_mtx_read(path.encode(), nnz.value, row.ctypes.data_as(i32),
+                              col.ctypes.data_as(i32), val.ctypes.data_as(i32), int(n_threads)))
+    return (n_rows.value, n_cols.value), row, col, val
 
 
 def read_mtx(path, n_threads=0):
@@ -23,20 +42,40 @@ def read_mtx(path, n_threads=0):
     multi-threaded reader (vrx_mtx_read) instead of scipy.io.mmread (io_utils.py:57): the same
     entries in file order, duplicates kept (``.tocsc()`` sums them, like after mmread).
     Gzipped files and symmetric / complex / array storage fall back to scipy."""
-    path = str(path)
-    L = _lib.lib()
-    n_rows, n_cols, nnz = C.c_int64(0), C.c_int64(0), C.c_int64(0)
-    if path.endswith(".gz") or L.vrx_mtx_header(path.encode(), C.byref(n_rows), C.byref(n_cols),
-                                                C.byref(nnz)) != 0:
+    got = _read_mtx_arrays(path, n_threads)
+    if got is None:
         from scipy.io import mmread
-        return mmread(path)
-    row = np.empty(nnz.value, dtype=np.int32)
-    col = np.empty(nnz.value, dtype=np.int32)
-    val = np.empty(nnz.value, dtype=np.int32)
-    i32 = C.POINTER(C.c_int32)
-    _lib.check(L.vrx_mtx_read(path.encode(), nnz.value, row.ctypes.data_as(i32),
-                              col.ctypes.data_as(i32), val.ctypes.data_as(i32), int(n_threads)))
-    return coo_matrix((val.astype(np.int64), (row, col)), shape=(n_rows.value, n_cols.value))
+        return mmread(str(path))
+    shape, row, col, val = got
+    return coo_matrix((val.astype(np.int64), (row, col)), shape=shape)
+
+
+def read_mtx_csc(path, n_threads=0):
+    """``mmread(path).tocsc()`` (io_utils.py:57) without SciPy's single-threaded COO -> CSC
+    conversion: the library parses the file (vrx_mtx_read) and sorts the entries into columns on
+    all cores (vrx_coo_to_csc).  A file whose columns do not come out strictly increasing
+    (duplicate entries, or not variant-major) goes through SciPy's conversion, which sorts and sums
+    duplicates like the reference's."""
+    got = _read_mtx_arrays(path, n_threads)
+    if got is None:
+        from scipy.io import mmread
+        return mmread(str(path)).tocsc()
+    shape, row, col, val = got
+    nnz = row.size
+    indptr = np.empty(shape[1] + 1, dtype=np.int64)
+    indices = np.empty(nnz, dtype=np.int32)
+    data = np.empty(nnz, dtype=np.int64)
+    canonical = C.c_int32(0)
+    i32, i64 = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    _lib.check(_lib.lib().vrx_coo_to_csc(shape[0], shape[1], nnz, row.ctypes.data_as(i32),
+                                         col.ctypes.data_as(i32), val.ctypes.data_as(i32),
+                                         indptr.ctypes.data_as(i64), indices.ctypes.data_as(i32),
+                                         data.ctypes.data_as(i64), C.byref(canonical), int(n_threads)))
+    if not canonical.value:
+        return coo_matrix((val.astype(np.int64), (row, col)), shape=shape).tocsc()
+    out = csc_matrix((data, indices, indptr), shape=shape)
+    out.has_canonical_format = True                           # (checked column by column in the library)
+    return out
 
 
 def read_cellSNP(dir_name, layers=['AD', 'DP']):
@@ -44,7 +83,7 @@ def read_cellSNP(dir_name, layers=['AD', 'DP']):
     (io_utils.py:42-59)."""
     dat = load_VCF(dir_name + "/cellSNP.base.vcf.gz", load_sample=False, biallelic_only=False)
     for layer in layers:
-        dat[layer] = read_mtx(dir_name + "/cellSNP.tag.%s.mtx" % layer).tocsc()
+        dat[layer] = read_mtx_csc(dir_name + "/cellSNP.tag.%s.mtx" % layer)
     dat['samples'] = np.genfromtxt(dir_name + "/cellSNP.samples.tsv", dtype=str)
     return dat
 
@@ -56,8 +95,8 @@ def read_vartrix(alt_mtx, ref_mtx, cell_file, vcf_file=None):
         dat['variants'] = np.array(dat['variants'])
     else:
         dat = {}
-    dat['AD'] = read_mtx(alt_mtx).tocsc()
-    dat['DP'] = read_mtx(ref_mtx).tocsc() + dat['AD']
+    dat['AD'] = read_mtx_csc(alt_mtx)
+    dat['DP'] = read_mtx_csc(ref_mtx) + dat['AD']
     dat['samples'] = np.genfromtxt(cell_file, dtype=str)
     return dat
 
