@@ -3,7 +3,7 @@
 Run on the GPU box from the repository root:
     python scratch/collect_traffic.py [c3] [profiles/r02]
 Two separate `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE; MI355X_MICROARCH.md, HBM
-section) over `python bench.py --no-cpu --no-c4 --steps 3 --warmup 1`.  Units: both counters are
+section) over `python bench.py --only-headline --steps 3 --warmup 1`.  Units: both counters are
 KiB.  gfx950 correction from the guide: FETCH_SIZE reports exactly half of the bytes of wide
 (16 B / lane) coalesced streaming reads -- every read of both passes -- so it is doubled;
 WRITE_SIZE is taken as is.  The record carries the hash of the kernel sources it was measured on;
@@ -24,7 +24,7 @@ import bench  # noqa: E402
 
 config = sys.argv[1] if len(sys.argv) > 1 else "c3"
 prefix = sys.argv[2] if len(sys.argv) > 2 else "profiles/r04"
-cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu", "--no-c4", "--steps", "3", "--warmup", "1",
+cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--only-headline", "--steps", "3", "--warmup", "1",
        "--config", config]
 if config == "c5":      # BinomMixtureVB clone mode (BASELINE.json configs[4]): its own driver
     cmd = [sys.executable, os.path.join(ROOT, "tests", "perf", "bench_bmm.py"), "--passes-only"]

@@ -1,5 +1,5 @@
 """inter-kernel gaps of one EM iteration from a rocprofv3 kernel trace (run under
-rocprofv3 --kernel-trace --output-format csv -d DIR -- python bench.py --no-cpu --no-c4)
+rocprofv3 --kernel-trace --output-format csv -d DIR -- python bench.py --only-headline)
 usage: gap_trace.py DIR"""
 import collections, csv, glob, sys
 rows = []

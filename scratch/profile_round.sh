@@ -14,7 +14,7 @@ for cfg in c3 c2 c5; do
         python tests/perf/bench_bmm.py > $OUT/${TAG}_bench_${cfg}_under_rocprof.json 2> /tmp/st_$cfg.err)
   else
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$cfg -o $cfg -- \
-        python $REPO/bench.py --no-cpu --no-c4 --steps 100 --warmup 50 --config $cfg > $OUT/${TAG}_bench_${cfg}_under_rocprof.json 2> /tmp/st_$cfg.err
+        python $REPO/bench.py --only-headline --steps 100 --warmup 50 --config $cfg > $OUT/${TAG}_bench_${cfg}_under_rocprof.json 2> /tmp/st_$cfg.err
   fi
   f=$(find /tmp/st_$cfg -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $OUT/${TAG}_${cfg}_kernel_stats.csv
@@ -25,7 +25,7 @@ i=0
 for P in "$P1" "$P2"; do
   i=$((i+1)); rm -rf /tmp/pmc_sq_$i
   timeout 600 rocprofv3 --pmc $P --kernel-trace --output-format csv -d /tmp/pmc_sq_$i -o c3 -- \
-      python $REPO/bench.py --no-cpu --no-c4 --steps 3 --warmup 1 --config c3 > /dev/null 2> /tmp/pmc_sq_$i.err
+      python $REPO/bench.py --only-headline --steps 3 --warmup 1 --config c3 > /dev/null 2> /tmp/pmc_sq_$i.err
 done
 mkdir -p /tmp/pmc_sq_all && cp -r /tmp/pmc_sq_1 /tmp/pmc_sq_2 /tmp/pmc_sq_all/ 2>/dev/null
 python $REPO/scratch/pmc_summary.py /tmp/pmc_sq_all > $OUT/${TAG}_c3_pmc_sq.txt
