@@ -1049,3 +1049,55 @@ def test_fit_loop_and_stepwise_api_agree_on_split_rows(va, monkeypatch):
     np.testing.assert_allclose(a.GT_prob, b.GT_prob, rtol=1e-7, atol=1e-300)
     np.testing.assert_allclose(a.beta_mu, b.beta_mu, rtol=1e-10)       # (observed 3e-12)
     np.testing.assert_allclose(a.beta_sum, b.beta_sum, rtol=1e-10)
+
+
+@pytest.mark.parametrize("case", ["c1", "c2_lds", "batch"])
+def test_elbo_riding_in_the_next_theta_kernel_changes_nothing(va, monkeypatch, case):
+    """Launch-bound problems: the ELBO + stop rule of an iteration are finalised by an extra block
+    of the next iteration's vrx_theta_partial (VIREO_ELBO_RIDE; default on where nnz x columns <
+    2^24) instead of by vrx_elbo_final between the iterations.  Same code on the same partial sums:
+    traces, iteration counts (the stop firing in the middle of a poll batch, at its end, never),
+    warning flags and states must be bitwise those of VIREO_ELBO_RIDE=0 -- for single models (demo
+    data; c2 size on the LDS-resident passes), warm restarts, and a restart batch whose members
+    stop at different iterations."""
+    from vireo_amd import _lib, synth
+    from vireo_amd.counts import DeviceCounts
+    from vireo_amd.engine import DeviceBatch
+    if case == "c1":
+        AD, DP = gold.c1()
+        counts, K = va.DeviceCounts(AD, DP), 4
+        N, M = AD.shape
+    else:
+        if case == "c2_lds":
+            monkeypatch.setenv("VIREO_LDS", "1")
+        Nn, Mm, K, dens = synth.CONFIGS["c2"]
+        w = synth.donor_workload(Nn, Mm, K, dens, seed=0)
+        counts = DeviceCounts.from_merged(w["shape"], w["colptr"], w["rowidx"], w["ad"], w["dp"])
+        N, M = w["shape"]
+    out = {}
+    for ride in ("1", "0"):
+        monkeypatch.setenv("VIREO_ELBO_RIDE", ride)
+        res = []
+        if case == "batch":
+            R = 5
+            db = DeviceBatch(counts, _lib.KIND_VIREO, K, R)
+            db.set_prior(np.full((1, K), 1.0 / K), np.full((1, K, 3), 1.0 / 3), np.array([[0.5, 25.0, 49.5]]),
+                         np.array([[49.5, 25.0, 0.5]]))
+            rng = np.random.default_rng(3)
+            mu, sm = np.linspace(0.01, 0.99, 3)[None, :], np.full((1, 3), 50.0)
+            for r in range(R):
+                db.set_restart(r, rng.random((M, K)), rng.random((N, K, 3)), mu, sm, raw=True)
+            for (mx, mn, dl) in ((40, 5, 3), (9, 5, 0)):
+                tr, it, fl = db.fit(mx, mn, 1e-2, dl)
+                res.append((list(map(tuple, tr)), tuple(it), tuple(fl)))
+            db.close()
+        else:
+            for (mx, mn, dl, eps) in ((200, 5, 3, 1e-2), (20, 5, 0, 1e-2), (7, 2, 1, 1e3), (6, 9, 2, 1e-2), (1, 5, 0, 1e-2)):
+                np.random.seed(6)
+                m = va.Vireo(n_var=N, n_cell=M, n_donor=K)
+                m.fit(counts, None, max_iter=mx, min_iter=mn, delay_fit_theta=dl, epsilon_conv=eps, verbose=False)
+                m.fit(counts, None, max_iter=30, min_iter=3, verbose=False)       # warm restart
+                res.append((tuple(m.ELBO_), m.ID_prob.tobytes(), m.GT_prob.tobytes(), m.beta_mu.tobytes(),
+                            m.beta_sum.tobytes()))
+        out[ride] = res
+    assert out["1"] == out["0"]

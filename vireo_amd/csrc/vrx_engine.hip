@@ -1359,6 +1359,10 @@ struct vrx_model {
     bool w_valid = false;     // W matches (GT, psi) on the device
     bool s_pending = false;   // S still sits in RV as per-range partials (sum fused downstream)
     bool l_pending = false;   // logLik_ID still sits in RC as per-range partials
+    // launch-bound problems: the ELBO of the iteration enqueued last has not been finalised yet --
+    // it rides as an extra block in the next iteration's vrx_theta_partial (VrxElboRide)
+    bool elbo_deferred = false;
+    VrxStopRule elbo_rule{};
     // profiling
     bool prof = false;
     std::vector<hipEvent_t> ev;
@@ -2187,6 +2191,8 @@ static int resolve_LID(vrx_model* m) {
     return VRX_OK;
 }
 
+static VrxElboIn elbo_inputs(vrx_model* m);
+
 // theta update (update=1) or just psi/KL from the current beta (update=0).  defer_final: the
 // caller runs gt_step next, whose kernel finalises the shared theta itself (VrxThetaFuse).
 static int theta_step(vrx_model* m, int update, bool defer_final = false) {
@@ -2225,11 +2231,18 @@ static int theta_step(vrx_model* m, int update, bool defer_final = false) {
             }
             const uint16_t* np = m->s_pending ? tv.npiece.p : nullptr;
             auto* kern = m->T == 3 ? vrx_theta_partial<3> : vrx_theta_partial<VRX_MAXT>;
-            kern<<<dim3(m->nb_theta, m->R), VRX_BLOCK, 0, s>>>(
+            VrxElboRide E{};
+            if (m->elbo_deferred) {  // the previous iteration's ELBO + stop rule: one extra block
+                E.on = 1;
+                E.in = elbo_inputs(m);
+                E.rule = m->elbo_rule;
+                m->elbo_deferred = false;
+            }
+            kern<<<dim3(m->nb_theta + E.on, m->R), VRX_BLOCK, 0, s>>>(
                 m->NK, m->T, reinterpret_cast<double2*>(m->S.p), np,
                 reinterpret_cast<const double2*>(m->RV.p), m->s_pending && tv.virt ? tv.n_vrows : 0,
                 m->s_pending && tv.virt && tv.split ? tv.vptr.p : nullptr,
-                m->GT.p, m->part_theta.p, m->batch(), m->ctl.p);
+                m->GT.p, m->part_theta.p, m->batch(), m->ctl.p, E);
             VRX_HIP(hipGetLastError());
             m->s_pending = false;
         }
@@ -2347,9 +2360,30 @@ static int elbo_step(vrx_model* m, const VrxStopRule& rule) {
 
 // One iteration of _fit_VB (vireo_model.py:257-264) / _fit_BV (bmm_model.py:183-188).
 // Enqueue only; no host synchronisation.
-static int enqueue_iteration(vrx_model* m, bool do_theta, const VrxStopRule& rule) {
+// an ELBO that still waits for a ride is finalised by the kernel of its own after all
+static int flush_elbo(vrx_model* m) {
+    if (!m->elbo_deferred) return VRX_OK;
+    m->elbo_deferred = false;
+    return elbo_step(m, m->elbo_rule);
+}
+
+// shared-theta Vireo updates run vrx_theta_partial, which can carry the previous iteration's ELBO
+static bool elbo_can_ride(const vrx_model* m) {
+    // Only where an iteration is short against a launch (the criterion of the pipelined polls and
+    // of restarts.restart_batch, the other way round): when the rule fires, the next iteration's
+    // variant pass has already run for nothing -- 8 us at c2, 0.3 ms at c3, where one ELBO kernel
+    // per iteration is 1 % of it.  VIREO_ELBO_RIDE=0 / 1 forces it off / on (read per call).
+    const auto& c = m->cfg;
+    if (c.kind != VRX_KIND_VIREO || c.ase_mode || !c.learn_theta) return false;
+    return env_int("VIREO_ELBO_RIDE", m->p->nnz * (int64_t)m->Kt < ((int64_t)1 << 24) ? 1 : 0) != 0;
+}
+
+// defer_elbo: the caller enqueues an iteration WITH the theta update right behind this one
+static int enqueue_iteration(vrx_model* m, bool do_theta, const VrxStopRule& rule, bool defer_elbo = false) {
     int rc;
     const auto& c = m->cfg;
+    if (m->elbo_deferred && !(c.kind == VRX_KIND_VIREO && do_theta && !c.ase_mode))
+        if ((rc = flush_elbo(m))) return rc;  // (not reached by the callers below: they defer only in front of a ride)
     if (c.kind == VRX_KIND_BMM) {
         if ((rc = variant_pass(m, true))) return rc;
         if ((rc = theta_step(m, 1))) return rc;  // also refreshes W (digamma tables)
@@ -2376,10 +2410,16 @@ static int enqueue_iteration(vrx_model* m, bool do_theta, const VrxStopRule& rul
         if ((rc = cell_pass(m, true))) return rc;  // range sum fused into the softmax kernel
         if ((rc = softmax_step(m, 1))) return rc;
     }
+    if (defer_elbo) {  // finalised by the next iteration's vrx_theta_partial (theta_step)
+        m->elbo_deferred = true;
+        m->elbo_rule = rule;
+        return VRX_OK;
+    }
     return elbo_step(m, rule);                 // ELBO + the stop rule, on the device
 }
 
 static int reset_ctl(vrx_model* m) {  // stop flag, stop iteration, warn flags (tickets stay 0)
+    m->elbo_deferred = false;  // (a call that failed half-way may have left one waiting: dropped)
     VRX_HIP(hipMemsetAsync(m->ctl.p, 0, (size_t)m->R * VRX_CTL_WORDS * sizeof(int32_t), m->p->stream));
     return VRX_OK;
 }
@@ -2422,6 +2462,7 @@ extern "C" int vrx_model_fit(vrx_model* m, int32_t max_iter, int32_t min_iter, d
     // iteration is long against a launch -- the criterion restarts.restart_batch uses.
     // VIREO_FIT_PIPELINE=1 / 0 forces it on / off (read per call: the tests switch it).
     const int pipeline = env_int("VIREO_FIT_PIPELINE", m->p->nnz * (int64_t)m->Kt >= ((int64_t)1 << 24) ? 1 : 0);
+    const bool ride = elbo_can_ride(m);
     const int R = m->R;  // elbo_trace [R][max_iter], it_out [R], warn_flags [R]
     // two pinned read-back buffers of R * VRX_CTL_WORDS <= 64 words inside h_pin (64 doubles)
     int32_t* hbuf[2] = {reinterpret_cast<int32_t*>(m->h_pin), reinterpret_cast<int32_t*>(m->h_pin) + 64};
@@ -2439,8 +2480,10 @@ extern "C" int vrx_model_fit(vrx_model* m, int32_t max_iter, int32_t min_iter, d
             rule.eps = eps;
             const bool do_theta = m->cfg.kind == VRX_KIND_VIREO && m->cfg.learn_theta &&
                                   it >= delay_fit_theta;
+            // (the last iteration of a batch finalises its ELBO itself: the poll reads its stop word)
+            const bool defer = ride && it + 1 < upto && it + 1 >= delay_fit_theta;
             int rc2;
-            if ((rc2 = enqueue_iteration(m, do_theta, rule))) return rc2;
+            if ((rc2 = enqueue_iteration(m, do_theta, rule, defer))) return rc2;
         }
         next = upto;
         VRX_HIP(hipMemcpyAsync(hbuf[nb & 1], m->ctl.p, (size_t)R * VRX_CTL_WORDS * sizeof(int32_t),
@@ -2496,11 +2539,13 @@ extern "C" int vrx_model_run_iters(vrx_model* m, int32_t n_iter, int32_t theta_f
     int rc;
     if ((rc = reset_ctl(m))) return rc;
     if ((rc = prepare(m))) return rc;
+    const bool ride = elbo_can_ride(m);
     VRX_HIP(hipEventRecord(m->t0, s));
     for (int it = 0; it < n_iter; ++it) {
         const bool do_theta = m->cfg.kind == VRX_KIND_VIREO && m->cfg.learn_theta &&
                               it >= theta_from_iter;
-        if ((rc = enqueue_iteration(m, do_theta, no_rule(it)))) return rc;
+        const bool defer = ride && it + 1 < n_iter && it + 1 >= theta_from_iter;
+        if ((rc = enqueue_iteration(m, do_theta, no_rule(it), defer))) return rc;
     }
     VRX_HIP(hipEventRecord(m->t1, s));
     VRX_HIP(hipStreamSynchronize(s));

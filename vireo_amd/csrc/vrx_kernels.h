@@ -1155,6 +1155,16 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_pieces_wave(
 // (one load per lane), the longest ~100 terms.  (Measured at c3 size, dense kernels per iteration:
 // the consumers' own per-thread loop over the terms 0.20 ms; one wavefront per element 0.27 ms --
 // 400 k waves of a few dependent loads each; this form: see DESIGN.md 4.2.)
+// Two properties a caller must know:
+//  * ORDER.  The terms are added strided over 8 lanes and then by a butterfly; the consumers that
+//    form S / logLik_ID explicitly (vrx_s_from_virtual, vrx_sum_pieces: the step-wise API,
+//    vrx_model_step) add the same terms sequentially.  A fit and the same iterations driven step by
+//    step therefore round differently on split rows: 1e-12 on the ELBO, 3e-9 on small posteriors
+//    after six iterations (tests/test_gpu_parity.py::test_fit_loop_and_stepwise_api_agree_on_split_rows).
+//  * NOT IDEMPOTENT.  The sum overwrites slot 0 of the row's first piece, which is one of its
+//    terms: a second call on the same partial array would count the other terms twice.  The host
+//    calls it once per pass output, right before the one consumer that reads the array, and clears
+//    s_pending / l_pending there (theta_step, softmax_step in vrx_engine.hip).
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_fold_split(
     int64_t n_split, const int32_t* __restrict__ split_rows, int width, int64_t n_vrows,
     const int32_t* __restrict__ vptr, const uint16_t* __restrict__ npiece, double* partial,
@@ -1268,6 +1278,109 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_slots(int64_t n_multi, int 
     for (int q = multi_ptr[j]; q < multi_ptr[j + 1]; ++q) s += partial[(int64_t)q * per + c];
     out[(int64_t)multi_row[j] * per + c] = s;
 }
+
+// ------------------------------------------------------------------------------------
+// ELBO finalisation of one restart (get_ELBO, vireo_model.py:222-248; the stop rule of _fit_VB,
+// :266-274) as a block-level routine: the body of vrx_elbo_final further down, and -- on
+// launch-bound problems -- of the extra block that rides in the NEXT iteration's
+// vrx_theta_partial (VrxElboRide).
+// ------------------------------------------------------------------------------------
+struct VrxElboIn {  // by value; per restart r: partial arrays r * n_*_part on, trace r * trace_stride on
+    const double *cell_part, *gt_part, *th_part;
+    int n_cell_part, n_gt_part, n_th_part;
+    double *elbo, *parts;  // elbo: the trace (slot rule.it is written)
+    int64_t trace_stride;
+};
+
+// All first loads -- the stop word, the previous ELBO, and the first sweep of each partial array --
+// are requested together: the block is otherwise five dependent memory round trips long.
+__device__ __forceinline__ void vrx_elbo_final_block(const double* cell_part, int n_cell_part,
+                                                     const double* gt_part, int n_gt_part,
+                                                     const double* th_part, int n_th_part,
+                                                     double* elbo_out, double* parts_out,
+                                                     const VrxStopRule& rule, int32_t* ctl) {
+    __shared__ double tot[4];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const int stop = ctl[VRX_CTL_STOP];
+    const bool judge = rule.active && rule.it > rule.min_iter;
+    double prev = 0.0;
+    if (threadIdx.x == 0 && judge) prev = elbo_out[rule.it - 1];
+    // the loads of 8 strides are issued together (one memory round trip instead of 8), the
+    // additions keep the order of the plain strided loop
+    constexpr int UN = 8;
+    const int tid = threadIdx.x;
+    double2 vc[UN];
+    double vg[UN], vt[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+        const int b = tid + u * VRX_BLOCK;
+        vc[u] = b < n_cell_part ? reinterpret_cast<const double2*>(cell_part)[b] : make_double2(0.0, 0.0);
+        vg[u] = b < n_gt_part ? gt_part[b] : 0.0;
+        vt[u] = b < n_th_part ? th_part[b] : 0.0;
+    }
+    if (stop) return;
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+        acc[0] += vc[u].x;
+        acc[1] += vc[u].y;
+    }
+    for (int b0 = tid + UN * VRX_BLOCK; b0 < n_cell_part; b0 += UN * VRX_BLOCK) {
+        double2 v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int b = b0 + u * VRX_BLOCK;
+            v[u] = b < n_cell_part ? reinterpret_cast<const double2*>(cell_part)[b]
+                                   : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            acc[0] += v[u].x;
+            acc[1] += v[u].y;
+        }
+    }
+    auto strided = [&](const double* p, int n, const double (&v0)[UN], double& a) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) a += v0[u];
+        for (int b0 = tid + UN * VRX_BLOCK; b0 < n; b0 += UN * VRX_BLOCK) {
+            double v[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int b = b0 + u * VRX_BLOCK;
+                v[u] = b < n ? p[b] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) a += v[u];
+        }
+    };
+    strided(gt_part, n_gt_part, vg, acc[2]);
+    strided(th_part, n_th_part, vt, acc[3]);
+    block_sum_store<4>(acc, tot);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double cur = tot[0] - tot[1] - tot[2] - tot[3];
+        elbo_out[rule.it] = cur;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) parts_out[i] = tot[i];
+        // the stop rule of _fit_VB / _fit_BV (vireo_model.py:266-274, bmm_model.py:190-199)
+        if (judge) {
+            if (cur < prev - 1e-6) {
+                ctl[VRX_CTL_WARN] |= 1;
+            } else if (rule.it == rule.max_iter - 1) {
+                ctl[VRX_CTL_WARN] |= 2;
+            } else if (cur - prev < rule.eps) {
+                ctl[VRX_CTL_IT] = rule.it;
+                __threadfence();
+                ctl[VRX_CTL_STOP] = 1;
+            }
+        }
+    }
+}
+
+struct VrxElboRide {  // by value to vrx_theta_partial: on = 1 adds the ELBO block of the previous iteration
+    int on;
+    VrxElboIn in;
+    VrxStopRule rule;
+};
 
 // ------------------------------------------------------------------------------------
 // theta  (Vireo.update_theta_size, vireoSNP/utils/vireo_model.py:165-185)
@@ -1418,16 +1531,32 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_partial(
     int64_t NK, int T, double2* S, const uint16_t* __restrict__ npiece,
     const double2* __restrict__ ranges, int64_t n_virtual, const int32_t* __restrict__ vptr,
     const double* __restrict__ GT, double* __restrict__ part, VrxBatch B,
-    const int32_t* __restrict__ ctl) {
+    int32_t* ctl, VrxElboRide E) {
     const int rb = blockIdx.y;
     const int Tn = TT == VRX_MAXT ? T : TT;
+    // Launch-bound problems: the ELBO (and stop rule) of the PREVIOUS iteration is finalised here by
+    // one extra block at the end of the grid instead of by a kernel of its own between two
+    // iterations -- vrx_elbo_final is a one-block latency chain of ~4.5 us plus a kernel boundary, a
+    // fifth of a c2-sized iteration.  Nothing that ran since that iteration's last kernel has
+    // touched the model's state (the variant pass and this kernel write S and partial sums only),
+    // and the next kernel that does, vrx_gt_update, starts after this one has ended and sees the
+    // stop word; blocks of this launch that see it early just return.
+    const int nb = (int)gridDim.x - E.on;
+    if (E.on && (int)blockIdx.x == nb) {
+        vrx_elbo_final_block(E.in.cell_part + (int64_t)rb * E.in.n_cell_part * 2, E.in.n_cell_part,
+                             E.in.gt_part + (int64_t)rb * E.in.n_gt_part, E.in.n_gt_part,
+                             E.in.th_part + (int64_t)rb * E.in.n_th_part, E.in.n_th_part,
+                             E.in.elbo + rb * E.in.trace_stride, E.in.parts + rb * 4, E.rule,
+                             ctl + rb * VRX_CTL_WORDS);
+        return;
+    }
     const int stop = ctl[rb * VRX_CTL_WORDS + VRX_CTL_STOP];
     const int64_t NKt = NK * B.R;
     double acc[2 * VRX_MAXT];
 #pragma unroll
     for (int t = 0; t < 2 * VRX_MAXT; ++t) acc[t] = 0.0;
     // (the variant of an element without a 64-bit division per element, as in vrx_gt_update)
-    const int64_t stride = (int64_t)gridDim.x * VRX_BLOCK;
+    const int64_t stride = (int64_t)nb * VRX_BLOCK;
     const int64_t step_n = stride / B.K;
     const int step_k = (int)(stride - step_n * B.K);
     const int64_t i0 = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
@@ -1516,7 +1645,7 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_partial(
                 acc[VRX_MAXT + t] += s2 * g;
             }
     }
-    block_sum_store<2 * VRX_MAXT>(acc, part + ((int64_t)rb * gridDim.x + blockIdx.x) * 2 * VRX_MAXT, VRX_MAXT, T);
+    block_sum_store<2 * VRX_MAXT>(acc, part + ((int64_t)rb * nb + blockIdx.x) * 2 * VRX_MAXT, VRX_MAXT, T);
 }
 
 // ASE mode: one theta row per variant (vireo_model.py:82,:177 axis=1).  Thread per variant.
@@ -1892,97 +2021,6 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_bmm_theta(int64_t NK, int updat
 // ELBO  = LB_p - KL_ID - KL_GT - KL_theta  (vireo_model.py:247-248, bmm_model.py:175)
 // One block; each term is the fixed-order sum of a partial array.
 // ------------------------------------------------------------------------------------
-struct VrxElboIn {  // by value; per restart r: partial arrays r * n_*_part on, trace r * trace_stride on
-    const double *cell_part, *gt_part, *th_part;
-    int n_cell_part, n_gt_part, n_th_part;
-    double *elbo, *parts;  // elbo: the trace (slot rule.it is written)
-    int64_t trace_stride;
-};
-
-// All first loads -- the stop word, the previous ELBO, and the first sweep of each partial array --
-// are requested together: the block is otherwise five dependent memory round trips long.
-__device__ __forceinline__ void vrx_elbo_final_block(const double* cell_part, int n_cell_part,
-                                                     const double* gt_part, int n_gt_part,
-                                                     const double* th_part, int n_th_part,
-                                                     double* elbo_out, double* parts_out,
-                                                     const VrxStopRule& rule, int32_t* ctl) {
-    __shared__ double tot[4];
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    const int stop = ctl[VRX_CTL_STOP];
-    const bool judge = rule.active && rule.it > rule.min_iter;
-    double prev = 0.0;
-    if (threadIdx.x == 0 && judge) prev = elbo_out[rule.it - 1];
-    // the loads of 8 strides are issued together (one memory round trip instead of 8), the
-    // additions keep the order of the plain strided loop
-    constexpr int UN = 8;
-    const int tid = threadIdx.x;
-    double2 vc[UN];
-    double vg[UN], vt[UN];
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-        const int b = tid + u * VRX_BLOCK;
-        vc[u] = b < n_cell_part ? reinterpret_cast<const double2*>(cell_part)[b] : make_double2(0.0, 0.0);
-        vg[u] = b < n_gt_part ? gt_part[b] : 0.0;
-        vt[u] = b < n_th_part ? th_part[b] : 0.0;
-    }
-    if (stop) return;
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-        acc[0] += vc[u].x;
-        acc[1] += vc[u].y;
-    }
-    for (int b0 = tid + UN * VRX_BLOCK; b0 < n_cell_part; b0 += UN * VRX_BLOCK) {
-        double2 v[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int b = b0 + u * VRX_BLOCK;
-            v[u] = b < n_cell_part ? reinterpret_cast<const double2*>(cell_part)[b]
-                                   : make_double2(0.0, 0.0);
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            acc[0] += v[u].x;
-            acc[1] += v[u].y;
-        }
-    }
-    auto strided = [&](const double* p, int n, const double (&v0)[UN], double& a) {
-#pragma unroll
-        for (int u = 0; u < UN; ++u) a += v0[u];
-        for (int b0 = tid + UN * VRX_BLOCK; b0 < n; b0 += UN * VRX_BLOCK) {
-            double v[UN];
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int b = b0 + u * VRX_BLOCK;
-                v[u] = b < n ? p[b] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < UN; ++u) a += v[u];
-        }
-    };
-    strided(gt_part, n_gt_part, vg, acc[2]);
-    strided(th_part, n_th_part, vt, acc[3]);
-    block_sum_store<4>(acc, tot);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const double cur = tot[0] - tot[1] - tot[2] - tot[3];
-        elbo_out[rule.it] = cur;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) parts_out[i] = tot[i];
-        // the stop rule of _fit_VB / _fit_BV (vireo_model.py:266-274, bmm_model.py:190-199)
-        if (judge) {
-            if (cur < prev - 1e-6) {
-                ctl[VRX_CTL_WARN] |= 1;
-            } else if (rule.it == rule.max_iter - 1) {
-                ctl[VRX_CTL_WARN] |= 2;
-            } else if (cur - prev < rule.eps) {
-                ctl[VRX_CTL_IT] = rule.it;
-                __threadfence();
-                ctl[VRX_CTL_STOP] = 1;
-            }
-        }
-    }
-}
-
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_elbo_final(VrxElboIn e, VrxStopRule rule, int32_t* ctl) {
     const int r = blockIdx.x;  // one block per restart of the batch
     vrx_elbo_final_block(e.cell_part + (int64_t)r * e.n_cell_part * 2, e.n_cell_part,
