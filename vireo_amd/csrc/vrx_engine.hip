@@ -2369,13 +2369,15 @@ static int flush_elbo(vrx_model* m) {
 
 // shared-theta Vireo updates run vrx_theta_partial, which can carry the previous iteration's ELBO
 static bool elbo_can_ride(const vrx_model* m) {
-    // Only where an iteration is short against a launch (the criterion of the pipelined polls and
-    // of restarts.restart_batch, the other way round): when the rule fires, the next iteration's
-    // variant pass has already run for nothing -- 8 us at c2, 0.3 ms at c3, where one ELBO kernel
-    // per iteration is 1 % of it.  VIREO_ELBO_RIDE=0 / 1 forces it off / on (read per call).
+    // Only where an iteration is short against a launch: when the rule fires, the next iteration's
+    // variant pass has already run for nothing -- 8 us at c2 (a 29-us iteration minus 3 us, every
+    // iteration), 0.3 ms at c3 (where one ELBO kernel per iteration is 1 % of it and a fit would
+    // need > 30 iterations to win the wasted pass back).  Measured gain at nnz x columns = 2 / 8 /
+    // 16 / 32 M: 10.5 / 6 / 4 / 2.8 % per iteration (profiles/r05_ab_elbo_ride_small_problems.txt);
+    // the default stops at 2^25.  VIREO_ELBO_RIDE=0 / 1 forces it off / on (read per call).
     const auto& c = m->cfg;
     if (c.kind != VRX_KIND_VIREO || c.ase_mode || !c.learn_theta) return false;
-    return env_int("VIREO_ELBO_RIDE", m->p->nnz * (int64_t)m->Kt < ((int64_t)1 << 24) ? 1 : 0) != 0;
+    return env_int("VIREO_ELBO_RIDE", m->p->nnz * (int64_t)m->Kt < ((int64_t)1 << 25) ? 1 : 0) != 0;
 }
 
 // defer_elbo: the caller enqueues an iteration WITH the theta update right behind this one
