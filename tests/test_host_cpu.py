@@ -173,6 +173,42 @@ def test_sharded_wrap_gloo_wider_than_n_init(tmp_path):
     assert sorted(fits) == [0, 2]     # the restart and its refinement on rank 0, nothing on rank 1
 
 
+def test_sharded_clone_mode_gloo_world2(tmp_path):
+    """``BinomMixtureVB.fit(comm=)`` with 2 ranks over gloo (fits replaced by the CPU oracle):
+    initialisation i on rank i % 2, every rank walks the whole random stream, the ELBOs are
+    all-gathered, the owner of the first maximum re-fits and broadcasts -- both ranks return the
+    single-process result, which is the reference's golden output (the notebook's known answer),
+    and leave the global stream where the reference's loop would (bmm_model.py:242-254).
+    n_init = 7: ranks own 4 and 3 initialisations (a padded gather)."""
+    from oracle import vireo_oracle as O
+    g = gold.load("mito_bmm_k3_seed1")
+    for n_init, exact_gold in ((50, True), (7, False)):
+        port = _free_port()
+        outs = [str(tmp_path / ("bmm%d_rank%d.pkl" % (n_init, r))) for r in range(2)]
+        env = dict(os.environ, PYTHONPATH=ROOT)
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker_bmm.py"),
+                                   str(r), "2", str(port), outs[r], str(n_init)], env=env) for r in range(2)]
+        for p in procs:
+            assert p.wait(timeout=600) == 0
+        rvs = [pickle.load(open(o, "rb")) for o in outs]
+        for name in ("ID_prob", "beta_mu", "beta_sum", "ELBO_iters", "ELBO_inits"):
+            assert np.array_equal(rvs[0][name], rvs[1][name]), name
+            if exact_gold:
+                assert np.array_equal(rvs[0][name], g[name]), name
+        assert np.array_equal(rvs[0]["rng_after"][0], rvs[1]["rng_after"][0]) and rvs[0]["rng_after"][1] == rvs[1]["rng_after"][1]
+        # the shard: n_init / 2 short fits per rank (rounded up on rank 0), + the final fit on the owner
+        fits = sorted(rv["n_fits_on_rank"] for rv in rvs)
+        assert sum(fits) == n_init + 1 and fits[1] - fits[0] <= 2
+        if exact_gold:
+            assert rvs[0]["ELBO_iters"][-1] == -190779.74335041404      # examples/vireoSNP_clones.ipynb
+        else:                                                           # against the oracle's own loop
+            AD, DP = gold.mito()
+            st = O.bmm_new(AD.shape[1], AD.shape[0], 3)
+            O.bmm_fit(st, AD, DP, n_init=n_init, random_seed=1, min_iter=30)
+            assert np.array_equal(rvs[0]["ELBO_inits"], st.ELBO_inits)
+            assert np.array_equal(rvs[0]["ID_prob"], st.ID_prob) and np.array_equal(rvs[0]["ELBO_iters"], st.ELBO_iters)
+
+
 def test_generator_jump_equals_stepping():
     """LegacyStream.skip over far distances jumps (polynomial of the MT19937 transition matrix,
     vrx_host.cpp) instead of stepping: bitwise the state stepping leaves, for the skips a restart
@@ -558,3 +594,19 @@ def test_launched_externally_and_device_map():
     assert env["MASTER_PORT"] == "29400" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     p = launch.free_port()
     assert 0 < p < 65535
+
+
+def test_bench_side_legs_cannot_cost_the_headline(capsys):
+    """bench.py's side legs (c2, c5, doublet, c3_skew, e2e) are wrapped: an exception inside one
+    becomes an {"error": ...} entry of the JSON line, never a lost headline"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.side_leg("ok", lambda x: {"v": x + 1}, 1) == {"v": 2}
+    out = bench.side_leg("broken", lambda: 1 / 0)
+    assert set(out) == {"error"} and "ZeroDivisionError" in out["error"] and "broken" in out["error"]
+    assert "broken leg failed" in capsys.readouterr().err
+    B = bench.algorithmic_bytes(100000, 50000, 16, 3, 99006675)      # SURVEY.md 8(d): 2.58 GB at c3
+    assert B["total"] == B["variant"] + B["cell"] + B["dense"] and abs(B["total"] - 2.5816e9) < 1e6
+    assert B["cell"] == 12 * 99006675 + 4 * 50001 + 16 * 100000 * 16 + 8 * 50000 * 16

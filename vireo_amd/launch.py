@@ -82,6 +82,11 @@ def spawn_ranks(argv, world, devices=None, poll=0.05, grace=5.0, env=None):
             if live:
                 time.sleep(poll)
     finally:
+        # (reached with live ranks only when this process is being torn down -- KeyboardInterrupt,
+        #  an exception above: ask them to stop, then insist)
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
         deadline = time.time() + grace
         for p in procs:
             if p.poll() is None:
