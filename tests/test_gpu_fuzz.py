@@ -114,7 +114,7 @@ def test_other_genotype_class_counts(va, monkeypatch, T, lds):
 
 # ---------------------------------------------------------------- the sweep's known deviation class
 # Seeds 48 .. 999 of `draw_case` (tests/perf/fuzz_sweep.py; profiles/r05_fuzz_sweep_48_999.log):
-# 929 of 952 cases meet rtol 1e-5 everywhere; the 23 below do not -- 22 clone-mode cases with deep
+# 929 of 952 cases meet rtol 1e-5 everywhere (seeds 1000 .. 2999: 1944 of 2000); the 23 below do not -- 22 clone-mode cases with deep
 # counts (up to 5000 per entry) on their small posteriors, one ASE-mode Vireo case on seven
 # GT_prob entries of ~1e-199.  One update never differs by more than 2e-7; the theta step of the
 # NEXT iteration amplifies it (deep counts: d psi = d s / s times counts of thousands), and what is
@@ -153,7 +153,8 @@ def _held_by_arbiter(name, gpu, orc, exact):
 
 
 @pytest.mark.parametrize("seed", [75, 155, 171, 211, 239, 343, 367, 463, 563, 595, 611, 643, 695, 719,
-                                  755, 803, 811, 855, 887, 895, 951, 987])
+                                  755, 803, 811, 855, 887, 895, 951, 987,
+                                  1003, 1263, 2907])      # (the worst three of the second sweep, 1000 .. 2999)
 def test_known_deviation_cases_vs_arbiter_clone_mode(va, monkeypatch, seed):
     from vireo_amd.counts import DeviceCounts      # noqa: F401
     g = _arbiter()
@@ -170,8 +171,12 @@ def test_known_deviation_cases_vs_arbiter_clone_mode(va, monkeypatch, seed):
     dev._fit_BV(AD, DP, min_iter=2, max_iter=4, verbose=False)
     assert len(dev.ELBO_iters) == len(ref.ELBO_iters) == int(g["s%d_n_exec" % seed]) - 1
     close(dev.ELBO_iters, ref.ELBO_iters)
-    close(dev.beta_mu, ref.beta_mu)
-    close(dev.beta_sum, ref.beta_sum)
+    if "s%d_beta_sum" % seed in g:      # (seed 1263: one beta_sum entry of the oracle is 1.2e-5 off, too)
+        _held_by_arbiter("seed %d beta_mu" % seed, dev.beta_mu, ref.beta_mu, g["s%d_beta_mu" % seed])
+        _held_by_arbiter("seed %d beta_sum" % seed, dev.beta_sum, ref.beta_sum, g["s%d_beta_sum" % seed])
+    else:
+        close(dev.beta_mu, ref.beta_mu)
+        close(dev.beta_sum, ref.beta_sum)
     assert np.array_equal(dev.ID_prob.argmax(1), ref.ID_prob.argmax(1))
     exact = g["s%d_ID_prob" % seed]
     assert np.array_equal(dev.ID_prob.argmax(1), exact.argmax(1))
@@ -179,18 +184,21 @@ def test_known_deviation_cases_vs_arbiter_clone_mode(va, monkeypatch, seed):
     assert e_orc > 0.8 * RTOL        # (the case is in this list because the ORACLE is that far from exact)
 
 
-def test_known_deviation_case_vs_arbiter_ase_mode(va, monkeypatch):
-    """seed 537: Vireo, ASE mode, fixed beta_sum, counts up to 5000, K = 19"""
+@pytest.mark.parametrize("seed", [537, 1648, 2260])
+def test_known_deviation_cases_vs_arbiter_vireo(va, monkeypatch, seed):
+    """seed 537: ASE mode, fixed beta_sum, counts up to 5000, K = 19 (seven GT_prob entries of ~1e-199
+    off by 1.7e-5); 1648 / 2260 (second sweep): shared theta, counts up to 2047 / 4999 -- 2260 with
+    172 GT_prob entries and one ID_prob entry beyond 1e-5"""
     from vireo_amd.counts import DeviceCounts
-    seed = 537
     g = _arbiter()
     AD, DP, K, rng = draw_case(seed)
     N, M = AD.shape
-    monkeypatch.setenv("VIREO_LDS", "1")
+    monkeypatch.setenv("VIREO_LDS", "1" if seed % 2 else "0")
     monkeypatch.setenv("VIREO_LDS_BLOCKS", str(int(rng.choice([1, 16, 1024]))))
     flags = dict(ASE_mode=bool(rng.random() < 0.2), fix_beta_sum=bool(rng.random() < 0.2),
                  learn_theta=bool(rng.random() < 0.85))
-    assert flags == dict(ASE_mode=True, fix_beta_sum=True, learn_theta=True)
+    if seed == 537:
+        assert flags == dict(ASE_mode=True, fix_beta_sum=True, learn_theta=True)
     counts = DeviceCounts(AD, DP)
     np.random.seed(seed)
     ref = O.vireo_new(M, N, K, **flags)
@@ -200,12 +208,11 @@ def test_known_deviation_case_vs_arbiter_ase_mode(va, monkeypatch):
     dev.fit(counts, None, min_iter=2, max_iter=5, delay_fit_theta=1, verbose=False)
     assert len(dev.ELBO_) == len(ref.ELBO_) == int(g["s%d_n_exec" % seed]) - 1
     close(dev.ELBO_, ref.ELBO_)
-    close(dev.ID_prob, ref.ID_prob)
     close(dev.beta_mu, ref.beta_mu)
     close(dev.beta_sum, ref.beta_sum)
     rows = g["s%d_GT_rows" % seed]
-    _held_by_arbiter("seed 537 ID_prob", dev.ID_prob, ref.ID_prob, g["s%d_ID_prob" % seed])
-    _held_by_arbiter("seed 537 GT_prob (%d variants)" % rows.size, dev.GT_prob[rows], ref.GT_prob[rows],
+    _held_by_arbiter("seed %d ID_prob" % seed, dev.ID_prob, ref.ID_prob, g["s%d_ID_prob" % seed])
+    _held_by_arbiter("seed %d GT_prob (%d variants)" % (seed, rows.size), dev.GT_prob[rows], ref.GT_prob[rows],
                      g["s%d_GT_prob" % seed])
     # outside the kept variants the oracle is within 1e-6 of exact, so the plain tolerance holds there
     rest = np.setdiff1d(np.arange(N), rows)
