@@ -309,6 +309,47 @@ def test_socket_exchange_world3():
     assert got == {0: payload, 1: payload, 2: payload}
 
 
+def test_tcp_comm_world3_and_make_comm(monkeypatch):
+    """vireo_amd.dist.TcpComm (VIREO_COMM=tcp: the communicator of ranks that share one device):
+    all-gather, broadcast from every root and barrier with three ranks; make_comm's choices from
+    the launcher's environment."""
+    import multiprocessing as mp
+    from vireo_amd import _lib, dist
+    port = _free_port()
+
+    def worker(rank, q):
+        from vireo_amd.dist import TcpComm
+        c = TcpComm(rank, 3, port, timeout=60)
+        got = c.allgather(np.array([rank, 10.0 * rank]))
+        big = np.arange(5000, dtype=np.float64).reshape(50, 100) * (rank + 1)
+        b = [c.bcast(big, root) for root in (0, 1, 2)]
+        c.barrier()
+        c.close()
+        q.put((rank, got, [x[3, 7] for x in b], [x.shape for x in b]))
+
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, q)) for r in (2, 0, 1)]
+    for p in procs:
+        p.start()
+    res = {r: (g, v, sh) for r, g, v, sh in (q.get(timeout=120) for _ in range(3))}
+    for p in procs:
+        p.join(timeout=30)
+    for r in range(3):
+        g, v, sh = res[r]
+        assert list(g) == [0.0, 0.0, 1.0, 10.0, 2.0, 20.0]
+        assert v == [307.0, 614.0, 921.0] and sh == [(50, 100)] * 3      # root's array on every rank
+    # make_comm: world 1 -> LocalComm; an unknown backend is an error; tcp at world 1 is local too
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "VIREO_COMM", "VIREO_FORCE_RCCL"):
+        monkeypatch.delenv(k, raising=False)
+    assert isinstance(dist.make_comm(), dist.LocalComm)
+    monkeypatch.setenv("VIREO_COMM", "tcp")
+    assert isinstance(dist.make_comm(), dist.LocalComm)
+    monkeypatch.setenv("VIREO_COMM", "mpi")
+    with pytest.raises(_lib.VrxError):
+        dist.make_comm()
+
+
 def test_legacy_stream_continues_numpy_bit_for_bit():
     """vrx_mt19937_random_sample (host C): the doubles np.random.rand would give, at every
     alignment of the 624-word state, mixed with skips and with real np.random calls."""
