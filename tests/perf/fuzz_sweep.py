@@ -1,6 +1,6 @@
 """The random-case comparison of tests/test_gpu_fuzz.py for any seed range (MI355X).
 
-    python tests/perf/fuzz_sweep.py LO HI [OUTDIR]
+    python tests/perf/fuzz_sweep.py LO HI [OUTDIR [KINDS]]      KINDS: keep the device results of these kinds only (vireo,bmm)
 
 One line per case on stdout (kind, shape, K, largest count, iterations, worst relative error per
 compared array), `MISS` where an array misses rtol 1e-5 against the oracle; for every miss the
@@ -79,6 +79,7 @@ def run_case(seed):
 def main():
     lo, hi = int(sys.argv[1]), int(sys.argv[2])
     outdir = sys.argv[3] if len(sys.argv) > 3 else None
+    keep_kinds = sys.argv[4].split(",") if len(sys.argv) > 4 else ("vireo", "bmm")
     if outdir:
         os.makedirs(outdir, exist_ok=True)
     n = {"vireo": 0, "bmm": 0}
@@ -97,7 +98,7 @@ def main():
             "  ".join("%s %.2e(%d)" % (k, v[0], v[1]) for k, v in r["errs"].items())), flush=True)
         if r["miss"]:
             missed[r["kind"]].append(seed)
-            if outdir:
+            if outdir and r["kind"] in keep_kinds:
                 np.savez(os.path.join(outdir, "seed_%d.npz" % seed), **keep)
     print("SUMMARY seeds %d..%d: %d vireo cases, %d miss %s; %d bmm cases, %d miss %s; errors %s"
           % (lo, hi - 1, n["vireo"], len(missed["vireo"]), missed["vireo"], n["bmm"],
