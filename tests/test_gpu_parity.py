@@ -1051,6 +1051,40 @@ def test_fit_loop_and_stepwise_api_agree_on_split_rows(va, monkeypatch):
     np.testing.assert_allclose(a.beta_sum, b.beta_sum, rtol=1e-10)
 
 
+def test_elbo_riding_in_clone_mode_changes_nothing(va, monkeypatch):
+    """the same for ``BinomMixtureVB``: the rider sits in vrx_bmm_theta, which itself writes the
+    KL_theta partials -- two halves of the buffer, the rider reads the one the launch does not write.
+    Default: fits with min_iter >= 12 (bmm_model.py:178 runs 20) at any size.  Bitwise equal with
+    VIREO_ELBO_RIDE=0 / 1: single fits that stop by the rule, at max_iter and in the middle of a poll
+    batch; ``fit(n_init=...)`` with batched initialisations; the LDS-resident passes with the fused
+    range sum (16 lanes per element: a different number of KL partials than the first, non-fused call)."""
+    from vireo_amd import synth
+    AD, DP = gold.mito()
+    cAD, cDP = synth.clone_workload(60, 3000, 5, seed=2)
+    out = {}
+    for ride in ("1", "0"):
+        monkeypatch.setenv("VIREO_ELBO_RIDE", ride)
+        res = []
+        for (A, D, K, lds) in ((AD, DP, 3, "0"), (cAD, cDP, 5, "0"), (cAD, cDP, 5, "1")):
+            monkeypatch.setenv("VIREO_LDS", lds)
+            for (mx, mn, eps) in ((200, 20, 1e-2), (25, 30, 1e-2), (40, 3, 10.0), (1, 20, 1e-2)):
+                np.random.seed(3)
+                b = va.BinomMixtureVB(n_var=A.shape[0], n_cell=A.shape[1], n_donor=K)
+                b._fit_BV(A, D, max_iter=mx, min_iter=mn, epsilon_conv=eps, verbose=False)
+                b._fit_BV(A, D, max_iter=30, min_iter=20, verbose=False)          # continues from the state
+                res.append((tuple(b.ELBO_iters), b.ID_prob.tobytes(), b.beta_mu.tobytes(), b.beta_sum.tobytes()))
+            b = va.BinomMixtureVB(n_var=A.shape[0], n_cell=A.shape[1], n_donor=K)
+            b.fit(A, D, n_init=7, min_iter=20, max_iter_pre=40, random_seed=5, verbose=False)
+            res.append((tuple(b.ELBO_iters), tuple(b.ELBO_inits), b.ID_prob.tobytes(), b.beta_mu.tobytes()))
+            # the step-wise API reads the KL_theta partials of the half written last
+            np.random.seed(3)
+            b = va.BinomMixtureVB(n_var=A.shape[0], n_cell=A.shape[1], n_donor=K)
+            b.update_theta_size(A, D)
+            res.append((b.get_ELBO(A, D), b.beta_mu.tobytes()))
+        out[ride] = res
+    assert out["1"] == out["0"]
+
+
 @pytest.mark.parametrize("case", ["c1", "c2_lds", "batch"])
 def test_elbo_riding_in_the_next_theta_kernel_changes_nothing(va, monkeypatch, case):
     """Launch-bound problems: the ELBO + stop rule of an iteration are finalised by an extra block

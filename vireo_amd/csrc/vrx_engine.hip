@@ -1343,6 +1343,11 @@ struct vrx_model {
     int n_cell_part = 0;         // cell partials of the kernel that ran last (softmax or fused cell pass)
     bool theta_pending = false;  // stage-1 partials wait for the finalisation inside vrx_gt_update
     DevBuf<double> part_theta, part_gt, part_cell, part_th;
+    // clone mode: vrx_bmm_theta WRITES the KL_theta partials, so the ELBO block that rides in it
+    // (VrxElboRide) must read the previous iteration's from another buffer: two halves of part_th,
+    // th_cur = the half written last (Vireo: always 0)
+    size_t th_cap = 0;
+    int th_cur = 0;
     DevBuf<double> d_elbo, d_parts;
     int64_t trace_cap = 0;  // ELBO slots per restart in d_elbo
     DevBuf<int32_t> ctl;  // device-side loop control (VRX_CTL_*)
@@ -1524,8 +1529,9 @@ extern "C" int vrx_model_create(vrx_problem* p, const vrx_model_cfg* cfg, vrx_mo
     }
     // (clone mode with the range sum fused into vrx_bmm_theta runs 16 lanes per element: 16x the blocks)
     const size_t th_cap = (size_t)m->R * (cfg->kind == VRX_KIND_VIREO ? m->n_th_part : (m->NK * 16 + VRX_BLOCK - 1) / VRX_BLOCK + 1);
-    VRX_HIP(m->part_th.alloc(th_cap));
-    VRX_HIP(hipMemsetAsync(m->part_th.p, 0, th_cap * sizeof(double), s));
+    m->th_cap = th_cap;
+    VRX_HIP(m->part_th.alloc(th_cap * (cfg->kind == VRX_KIND_BMM ? 2 : 1)));
+    VRX_HIP(hipMemsetAsync(m->part_th.p, 0, th_cap * (cfg->kind == VRX_KIND_BMM ? 2 : 1) * sizeof(double), s));
     m->trace_cap = kTraceInit;
     VRX_HIP(m->d_elbo.alloc((size_t)m->R * m->trace_cap));
     VRX_HIP(m->ctl.alloc((size_t)m->R * VRX_CTL_WORDS));
@@ -2208,12 +2214,20 @@ static int theta_step(vrx_model* m, int update, bool defer_final = false) {
     if (c.kind == VRX_KIND_BMM) {
         // (fused range sum: 16 lanes per element; the KL partials are zero-filled past nb_nk blocks' worth)
         const unsigned nb = bmm_fuse ? (unsigned)((m->NK * 16 + VRX_BLOCK - 1) / VRX_BLOCK) : (unsigned)m->nb_nk;
+        VrxElboRide E{};
+        if (m->elbo_deferred) {  // the previous iteration's ELBO + stop rule: one extra block, reading
+            E.on = 1;            // the KL_theta partials of the half this launch does not write
+            E.in = elbo_inputs(m);
+            E.rule = m->elbo_rule;
+            m->elbo_deferred = false;
+        }
+        m->th_cur ^= 1;
         m->n_th_part = (int)nb;
-        vrx_bmm_theta<<<dim3(nb, m->R), VRX_BLOCK, 0, s>>>(
+        vrx_bmm_theta<<<dim3(nb + E.on, m->R), VRX_BLOCK, 0, s>>>(
             m->NK, update, c.fix_beta_sum, reinterpret_cast<double2*>(m->S.p),
             bmm_fuse ? tvar.npiece.p : nullptr, reinterpret_cast<const double2*>(m->RV.p), m->prior1.p,
             m->prior2.p, m->prior_rows == 1 ? 0 : 1, m->mu.p, m->sm.p, m->W.p, m->K, m->wform,
-            m->part_th.p, m->batch(), m->ctl.p);
+            m->part_th.p + (size_t)m->th_cur * m->th_cap, m->batch(), m->ctl.p, E);
         if (bmm_fuse) m->s_pending = false;
         m->w_valid = true;
     } else if (c.ase_mode) {
@@ -2298,7 +2312,7 @@ static VrxElboIn elbo_inputs(vrx_model* m) {
     VrxElboIn e;
     e.cell_part = m->part_cell.p;
     e.gt_part = m->part_gt.p;
-    e.th_part = m->part_th.p;
+    e.th_part = m->part_th.p + (size_t)m->th_cur * m->th_cap;
     e.n_cell_part = m->n_cell_part;  // (of the kernel that formed them last)
     e.n_gt_part = m->cfg.kind == VRX_KIND_VIREO ? m->nb_gt : 0;
     e.n_th_part = m->n_th_part;
@@ -2368,23 +2382,28 @@ static int flush_elbo(vrx_model* m) {
 }
 
 // shared-theta Vireo updates run vrx_theta_partial, which can carry the previous iteration's ELBO
-static bool elbo_can_ride(const vrx_model* m) {
+static bool elbo_can_ride(const vrx_model* m, int min_iter) {
     // Only where an iteration is short against a launch: when the rule fires, the next iteration's
     // variant pass has already run for nothing -- 8 us at c2 (a 29-us iteration minus 3 us, every
     // iteration), 0.3 ms at c3 (where one ELBO kernel per iteration is 1 % of it and a fit would
     // need > 30 iterations to win the wasted pass back).  Measured gain at nnz x columns = 2 / 8 /
     // 16 / 32 M: 10.5 / 6 / 4 / 2.8 % per iteration (profiles/r05_ab_elbo_ride_small_problems.txt);
     // the default stops at 2^25.  VIREO_ELBO_RIDE=0 / 1 forces it off / on (read per call).
+    // Clone mode rides in vrx_bmm_theta; its fits run min_iter >= 20 iterations by default
+    // (bmm_model.py:178), far more than the ~9 a wasted variant pass costs at c5 (62 us against
+    // ~7 us per iteration), so there the rule is min_iter, not size.
     const auto& c = m->cfg;
-    if (c.kind != VRX_KIND_VIREO || c.ase_mode || !c.learn_theta) return false;
-    return env_int("VIREO_ELBO_RIDE", m->p->nnz * (int64_t)m->Kt < ((int64_t)1 << 25) ? 1 : 0) != 0;
+    if (c.kind == VRX_KIND_VIREO && (c.ase_mode || !c.learn_theta)) return false;
+    const bool small = m->p->nnz * (int64_t)m->Kt < ((int64_t)1 << 25);
+    const bool dflt = small || (c.kind == VRX_KIND_BMM && min_iter >= 12);
+    return env_int("VIREO_ELBO_RIDE", dflt ? 1 : 0) != 0;
 }
 
 // defer_elbo: the caller enqueues an iteration WITH the theta update right behind this one
 static int enqueue_iteration(vrx_model* m, bool do_theta, const VrxStopRule& rule, bool defer_elbo = false) {
     int rc;
     const auto& c = m->cfg;
-    if (m->elbo_deferred && !(c.kind == VRX_KIND_VIREO && do_theta && !c.ase_mode))
+    if (m->elbo_deferred && !(c.kind == VRX_KIND_BMM || (do_theta && !c.ase_mode)))
         if ((rc = flush_elbo(m))) return rc;  // (not reached by the callers below: they defer only in front of a ride)
     if (c.kind == VRX_KIND_BMM) {
         if ((rc = variant_pass(m, true))) return rc;
@@ -2464,7 +2483,7 @@ extern "C" int vrx_model_fit(vrx_model* m, int32_t max_iter, int32_t min_iter, d
     // iteration is long against a launch -- the criterion restarts.restart_batch uses.
     // VIREO_FIT_PIPELINE=1 / 0 forces it on / off (read per call: the tests switch it).
     const int pipeline = env_int("VIREO_FIT_PIPELINE", m->p->nnz * (int64_t)m->Kt >= ((int64_t)1 << 24) ? 1 : 0);
-    const bool ride = elbo_can_ride(m);
+    const bool ride = elbo_can_ride(m, min_iter);
     const int R = m->R;  // elbo_trace [R][max_iter], it_out [R], warn_flags [R]
     // two pinned read-back buffers of R * VRX_CTL_WORDS <= 64 words inside h_pin (64 doubles)
     int32_t* hbuf[2] = {reinterpret_cast<int32_t*>(m->h_pin), reinterpret_cast<int32_t*>(m->h_pin) + 64};
@@ -2483,7 +2502,7 @@ extern "C" int vrx_model_fit(vrx_model* m, int32_t max_iter, int32_t min_iter, d
             const bool do_theta = m->cfg.kind == VRX_KIND_VIREO && m->cfg.learn_theta &&
                                   it >= delay_fit_theta;
             // (the last iteration of a batch finalises its ELBO itself: the poll reads its stop word)
-            const bool defer = ride && it + 1 < upto && it + 1 >= delay_fit_theta;
+            const bool defer = ride && it + 1 < upto && (m->cfg.kind == VRX_KIND_BMM || it + 1 >= delay_fit_theta);
             int rc2;
             if ((rc2 = enqueue_iteration(m, do_theta, rule, defer))) return rc2;
         }
@@ -2541,12 +2560,12 @@ extern "C" int vrx_model_run_iters(vrx_model* m, int32_t n_iter, int32_t theta_f
     int rc;
     if ((rc = reset_ctl(m))) return rc;
     if ((rc = prepare(m))) return rc;
-    const bool ride = elbo_can_ride(m);
+    const bool ride = elbo_can_ride(m, 1 << 20);  // (no stop rule here: nothing is ever wasted)
     VRX_HIP(hipEventRecord(m->t0, s));
     for (int it = 0; it < n_iter; ++it) {
         const bool do_theta = m->cfg.kind == VRX_KIND_VIREO && m->cfg.learn_theta &&
                               it >= theta_from_iter;
-        const bool defer = ride && it + 1 < n_iter && it + 1 >= theta_from_iter;
+        const bool defer = ride && it + 1 < n_iter && (m->cfg.kind == VRX_KIND_BMM || it + 1 >= theta_from_iter);
         if ((rc = enqueue_iteration(m, do_theta, no_rule(it), defer))) return rc;
     }
     VRX_HIP(hipEventRecord(m->t1, s));

@@ -1960,9 +1960,20 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_bmm_theta(int64_t NK, int updat
                                                            int prior_full, double* mu, double* sm,
                                                            double* __restrict__ W, int K, int wform,
                                                            double* __restrict__ kl_part, VrxBatch B,
-                                                           const int32_t* __restrict__ ctl) {
+                                                           int32_t* ctl, VrxElboRide E) {
 #pragma clang fp contract(off)
     const int rb = blockIdx.y;
+    // (the previous iteration's ELBO + stop rule as one extra block, as in vrx_theta_partial; its
+    //  KL_theta partials sit in the half of the buffer this launch does not write)
+    const int nb = (int)gridDim.x - E.on;
+    if (E.on && (int)blockIdx.x == nb) {
+        vrx_elbo_final_block(E.in.cell_part + (int64_t)rb * E.in.n_cell_part * 2, E.in.n_cell_part,
+                             E.in.gt_part + (int64_t)rb * E.in.n_gt_part, E.in.n_gt_part,
+                             E.in.th_part + (int64_t)rb * E.in.n_th_part, E.in.n_th_part,
+                             E.in.elbo + rb * E.in.trace_stride, E.in.parts + rb * 4, E.rule,
+                             ctl + rb * VRX_CTL_WORDS);
+        return;
+    }
     if (ctl[rb * VRX_CTL_WORDS + VRX_CTL_STOP]) return;
     mu += (int64_t)rb * NK;
     sm += (int64_t)rb * NK;
@@ -2014,7 +2025,7 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_bmm_theta(int64_t NK, int updat
         vrx_store_w(W, wform, i / K, rb * K + (int)(i % K), B.Kt, d1 - d2, d2 - ds, d1 - ds);
         kl[0] = vrx_beta_kl(s1, s2, q1, q2, d1, d2, ds);
     }
-    block_sum_store<1>(kl, kl_part + (int64_t)rb * gridDim.x + blockIdx.x);
+    block_sum_store<1>(kl, kl_part + (int64_t)rb * nb + blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------
