@@ -1512,6 +1512,12 @@ extern "C" int vrx_model_create(vrx_problem* p, const vrx_model_cfg* cfg, vrx_mo
     VRX_HIP(hipMemsetAsync(m->ID.p, 0, (size_t)(m->M * m->Kt) * sizeof(double), s));
     m->nb_nk = (int)((m->NK + VRX_BLOCK - 1) / VRX_BLOCK);
     m->nb_cell = (int)((m->M * m->KP + VRX_BLOCK - 1) / VRX_BLOCK);
+    {   // vrx_cell_softmax strides over the cells: at most VIREO_SOFTMAX_BLOCKS_PER_CU blocks per CU
+        // (0 = one block per 256 lanes, as before; c5: dense kernels 40.9 -> 38.0 us at 4, 39.0 at 8,
+        //  39.2 at 16; c3: 0.108 -> 0.1055 ms; profiles/r05_ab_softmax_grid.txt)
+        const int cap = env_int("VIREO_SOFTMAX_BLOCKS_PER_CU", 4);
+        if (cap > 0) m->nb_cell = std::min(m->nb_cell, p->n_cu * cap);
+    }
     m->nb_throws = (int)((m->N + VRX_BLOCK - 1) / VRX_BLOCK);
     m->nb_theta = std::min(m->nb_nk, p->n_cu * 4);
     m->nb_gt = std::min(m->nb_nk, p->n_cu * 8);

@@ -2058,16 +2058,24 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_cell_softmax(
     double* __restrict__ part, VrxBatch B, const int32_t* __restrict__ ctl) {
     const int rb = blockIdx.y;
     const int stop = ctl[rb * VRX_CTL_WORDS + VRX_CTL_STOP];
-    const int64_t cell = ((int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x) / KP;
     const int kl = threadIdx.x % KP;
     double acc[2] = {0.0, 0.0};
+    // Grid-stride over the cells: the host caps the grid (8 blocks per CU), a block takes the cell
+    // groups b, b + grid, ... and ends in ONE block sum -- large M paid a prologue (stop word, first
+    // load) and a block reduction per 256 threads, three waves of blocks deep at c5.  Every thread
+    // runs every sweep (`live` guards the work: the group reductions want whole groups).
+    const int64_t cpg = (int64_t)gridDim.x * VRX_BLOCK / KP;  // cells per sweep of the grid
+    const int64_t cell0 = ((int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x) / KP;
+    // (the lane's first column travels together with the stop word: one round trip, not two)
+    const bool pre0 = cell0 < M && npiece == nullptr && kl < K;
+    const double L_pre0 = pre0 ? LID[cell0 * (int64_t)B.Kt + (int64_t)rb * K + kl] : 0.0;
+    if (stop) return;
+    for (int64_t cell = cell0; cell - cell0 + (int64_t)blockIdx.x * VRX_BLOCK / KP < M; cell += cpg) {
     const bool live = cell < M;
     const int64_t row0 = (live ? cell : 0) * (int64_t)B.Kt + (int64_t)rb * K;  // this restart's K columns
     double* Lr = LID + row0;
-    // (the lane's first column travels together with the stop word: one round trip, not two)
-    const bool pre = live && npiece == nullptr && kl < K;
-    const double L_pre = pre ? Lr[kl] : 0.0;
-    if (stop) return;
+    const bool pre = pre0 && cell == cell0;
+    const double L_pre = L_pre0;
     // npiece != null: logLik_ID still sits in the pass's partial arrays [slot][piece][Kt] (n_vrows
     // pieces; vptr == null: piece = cell).  A cell that was cut into several pieces (heavy-tailed
     // data) has been summed by vrx_fold_split.
@@ -2128,6 +2136,7 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_cell_softmax(
             acc[0] += L * p;
             if (p > 0.0) acc[1] += p * (lp - lq);
         }
+    }
     }
     block_sum_store<2>(acc, part + ((int64_t)rb * gridDim.x + blockIdx.x) * 2);
 }
