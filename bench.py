@@ -2,6 +2,7 @@
 """bench.py -- EM iterations/sec of the Vireo VB hot path on MI355X (BASELINE.json metric).
 
   python bench.py [--gpus N] [--steps K=200] [--warmup W=50] [--config c3|mid|c2] [--no-cpu] [--no-c4]
+                  [--comm rccl|tcp]
 
 A step is ONE full coordinate-ascent iteration (theta update, GT update, ID update, ELBO:
 vireoSNP/utils/vireo_model.py:257-264) over the synthetic AD/DP of SURVEY.md 8(d), inputs
@@ -20,6 +21,11 @@ enough: scratch/gap_probe.py); the CPU-oracle legs and the heavy-tailed c3_skew 
 N > 1 (launched by torch.distributed.run, one rank per GPU): every
 rank holds the problem and iterates its own restart (vireo_wrap's restart shard, weak
 scaling); the per-restart ELBOs are all-gathered over RCCL.  Rank 0 prints ONE JSON line.
+The line says which communicator produced it (`comm`: backend rccl | tcp | local, world, RCCL
+version, every rank's device and PCI bus id as all-gathered through that communicator, the timed
+exchanges).  `--comm tcp` (host sockets, ranks sharing one device: a plumbing rehearsal on a 1-GPU
+box) must be asked for on THIS command line: a VIREO_COMM=tcp merely inherited from the environment
+is refused for N > 1, and a line it produces carries "scaling": "plumbing-only", never "weak".
 
 Besides the headline value the line carries
   roofline      the dominant sparse pass against the HBM roofline (HIP events on the library's
@@ -38,6 +44,12 @@ Besides the headline value the line carries
                 c5 with its roofline fraction and the first iterations against the oracle.
   c3_skew       c3's shape with heavy-tailed (log-normal) coverage / depth -- real-data-shaped
                 input -- on the same kernels: ms per iteration, padding, row pieces, imbalance.
+  comm          the communicator's self-description (vireo_amd/dist.py comm_record) and the
+                winner's-state broadcast timed over it: device to device (vrx_comm_bcast_model)
+                against the host-staged route.
+  c3_flags      the flag paths at headline size (ASE_mode, fixed GT from a donor prior, learned GT
+                with a non-uniform prior, fix_beta_sum): ms per iteration and their own
+                algorithmic bytes.
   ms_per_step_repeats   the timed K iterations repeated four more times (min / median / max).
 """
 import argparse
@@ -238,6 +250,74 @@ def c3_skew_leg(device, K, uniform_ms, steps=100):
                 lds_passes=bool(info["lds_variant"] and info["lds_cell"]), kernel_info=info)
 
 
+FLAG_PATHS = ("ase", "fixedGT", "priorGT", "fixsum")
+
+
+def flag_model(flag, N, M, K, GT_true):
+    """the host ``Vireo`` of one flag path at the timing protocol's start (np.random.seed(1))"""
+    from vireo_amd import synth
+    from vireo_amd.vireo_model import Vireo
+    kw = dict(ase=dict(ASE_mode=True), fixedGT=dict(learn_GT=False), priorGT=dict(),
+              fixsum=dict(fix_beta_sum=True))[flag]
+    prior = None
+    if flag == "fixedGT":           # the donors' genotypes are known: `vireo -d donors.vcf` (mode 2)
+        prior = synth.planted_gt_prior(GT_true, 1.0)
+    elif flag == "priorGT":         # known for 90 % of the calls and learned on (mode 4, --forceLearnGT)
+        rng = np.random.default_rng(5)
+        noisy = np.where(rng.random(GT_true.shape) < 0.9, GT_true, rng.integers(0, 3, GT_true.shape))
+        prior = synth.planted_gt_prior(noisy, 0.8)
+    np.random.seed(1)
+    m = Vireo(n_var=N, n_cell=M, n_donor=K, **kw, **(dict(GT_prob_init=prior.copy()) if prior is not None else {}))
+    if prior is not None:
+        m.set_prior(GT_prior=prior)
+    return m
+
+
+def flag_bytes(flag, N, M, K, T, nnz):
+    """SURVEY.md 8(d) for the flag paths: theta as N x T in ASE mode (posterior written, the three
+    digamma tables written and read: 8 N T doubles); a fixed GT is read once and never written;
+    a non-uniform GT_prior adds its N K T table."""
+    B = algorithmic_bytes(N, M, K, T, nnz)
+    extra = {"ase": 8 * 8 * N * T, "fixedGT": -8 * N * K * T, "priorGT": 8 * N * K * T, "fixsum": 0}[flag]
+    return B["total"] + extra
+
+
+def c3_flags_leg(counts, GT_true, K, uniform_ms, steps=50):
+    """The flag paths at headline size -- they take kernels the headline never runs (vrx_theta_ase
+    and per-variant theta tables; W from a fixed genotype table; the GT_prior table inside
+    vrx_gt_update and KL_GT; the fixed-sum theta update): ms per iteration in steady state (20
+    protocol iterations first, theta from the third on) beside the default path's, the per-pass
+    split, and the whole-iteration roofline on the path's own algorithmic bytes."""
+    N, M = counts.shape
+    out = {"workload": "c3 data, one model per flag path from np.random.seed(1); %d iterations after 20; "
+                       "fixedGT: the planted genotypes as GT_prob_init = GT_prior, learn_GT=False (mode 2); "
+                       "priorGT: a prior right for 90 %% of the calls, sharpness 0.8, learn_GT=True (mode 4)" % steps,
+           "default_ms_per_iteration": uniform_ms}
+    for flag in FLAG_PATHS:
+        host = flag_model(flag, N, M, K, GT_true)
+        dm, _ = host._device_model(counts, None)
+        del host
+        dm.run_iters(20, theta_from_iter=PROTOCOL["delay_fit_theta"])
+        t0 = time.perf_counter()
+        tr, _ = dm.run_iters(steps, theta_from_iter=0)
+        ms_it = (time.perf_counter() - t0) / steps * 1e3
+        if not np.all(np.isfinite(tr)):
+            raise RuntimeError("c3_flags leg (%s): a non-finite ELBO in the timed iterations" % flag)
+        dm.profile(True)
+        dm.run_iters(steps, theta_from_iter=0)
+        pm, pn = dm.profile_read()
+        dm.close()
+        nb = flag_bytes(flag, N, M, K, 3, counts.nnz)
+        out[flag] = dict(ms_per_iteration=ms_it, iterations_per_s=1e3 / ms_it,
+                         ratio_to_default=ms_it / uniform_ms,
+                         passes_ms={"variant_pass": pm[0] / max(pn[0], 1), "cell_pass": pm[1] / max(pn[1], 1),
+                                    "dense_kernels": pm[2] / steps},
+                         algorithmic_bytes_per_iteration=nb,
+                         whole_iteration_roofline_frac=nb / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         elbo_last=float(tr[-1]))
+    return out
+
+
 def e2e_leg(w, K, n_init=8):
     """The `vireo` COMMAND end to end at the headline size (vireoSNP/vireo.py:109-242): a cellSNP
     folder on disk (two MatrixMarket files of ~1e8 entries, a VCF of the variants, the barcodes)
@@ -359,6 +439,40 @@ def c5_cpu_leg(out, data):
     return out
 
 
+def comm_leg(comm, device, dm, host):
+    """The communicator's self-description (dist.comm_record: backend, world, RCCL version, every
+    rank's device / PCI bus id all-gathered THROUGH it, the unique-id exchange, a timed all-gather of
+    32 ELBOs) and the winner's-state broadcast of vireo_wrap (vireo_wrap.py:90-94) timed both ways
+    on the timed model's state: device to device (vrx_comm_bcast_model, RCCL only) and the
+    host-staged route (four vrx_comm_bcast_f64 / socket broadcasts of host arrays)."""
+    from vireo_amd import dist as vdist
+    rec = vdist.comm_record(comm, device)
+    if comm.backend == "local":
+        rec["winner_broadcast"] = None
+        return rec
+    arrays = [host.ID_prob, host.GT_prob, np.ascontiguousarray(host.beta_mu), np.ascontiguousarray(host.beta_sum)]
+    nbytes = int(sum(a.nbytes for a in arrays))
+    out = dict(state_bytes=nbytes, root=0)
+    if hasattr(comm, "bcast_model"):
+        us = []
+        for _ in range(3):
+            comm.barrier()
+            t0 = time.perf_counter()
+            comm.bcast_model(dm, 0)
+            us.append((time.perf_counter() - t0) * 1e6)
+        out["device_to_device_us"] = dict(min=round(min(us), 1), runs=[round(x, 1) for x in us])
+    us = []
+    for _ in range(2):
+        comm.barrier()
+        t0 = time.perf_counter()
+        for a in arrays:
+            comm.bcast(a, 0)
+        us.append((time.perf_counter() - t0) * 1e6)
+    out["host_staged_us"] = dict(min=round(min(us), 1), runs=[round(x, 1) for x in us])
+    rec["winner_broadcast"] = out
+    return rec
+
+
 def side_leg(name, fn, *a, **k):
     """a side leg must never cost the run its headline: an exception becomes {"error": ...}"""
     try:
@@ -382,9 +496,23 @@ def main():
                     help="skip the c2 / c5 / c3_skew / doublet legs (N = 1 only anyway)")
     ap.add_argument("--only-headline", action="store_true",
                     help="= --no-cpu --no-c4 --no-side-legs (A/B runs, profiler runs)")
+    ap.add_argument("--comm", choices=("rccl", "tcp"), default=None,
+                    help="tcp: host sockets instead of RCCL, for ranks that share ONE device "
+                         "(a plumbing rehearsal; the line is marked plumbing-only)")
     args = ap.parse_args()
     if args.only_headline:
         args.no_cpu = args.no_c4 = args.no_side_legs = True
+    # The communicator of a multi-GPU line is chosen on THIS command line.  VIREO_COMM=tcp left
+    # behind in an environment would otherwise turn the driver's `bench.py --gpus 8` into a
+    # host-socket run that looks like an RCCL one.
+    inherited = os.environ.get("VIREO_COMM", "").lower()
+    if args.comm is not None:
+        os.environ["VIREO_COMM"] = args.comm        # (the ranks this process spawns inherit it)
+    elif inherited == "tcp" and args.gpus > 1:
+        sys.stderr.write("bench.py: VIREO_COMM=tcp is set in the environment but --comm tcp was not given: "
+                         "refusing to produce a %d-GPU line over host sockets.  Unset VIREO_COMM for the "
+                         "RCCL run, or pass --comm tcp for a one-device plumbing rehearsal.\n" % args.gpus)
+        sys.exit(2)
 
     import __graft_entry__ as entry
     from vireo_amd import launch
@@ -539,6 +667,7 @@ def main():
     prof_runs.sort(key=lambda r: r[0][_lib.KERN_VARIANT_PASS] + r[0][_lib.KERN_CELL_PASS])
     ms, n = prof_runs[1]
     kinfo = dm.info()
+    comm_rec = side_leg("comm", comm_leg, comm, local, dm, host)      # (collective: every rank)
     dm.close()
     if parity_gpu is None:
         proto_dm.close()
@@ -546,6 +675,10 @@ def main():
     c3_skew = None
     if solo and not args.no_side_legs and args.config == "c3":
         c3_skew = side_leg("c3_skew", c3_skew_leg, local, K, (float(np.median(repeats)), nnz))
+
+    c3_flags = None
+    if solo and not args.no_side_legs and args.config == "c3":
+        c3_flags = side_leg("c3_flags", c3_flags_leg, counts, w["GT"], K, float(np.median(repeats)))
 
     e2e = None
     if solo and not args.no_side_legs and args.config == "c3":
@@ -649,7 +782,11 @@ def main():
             "metric": "EM iterations/sec", "value": world * args.steps / wall_max,
             "unit": "EM iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": wall_max / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True,
+            # one restart per rank whatever N is: weak scaling -- when the ranks are GPUs talking
+            # over RCCL.  Ranks that share a device over host sockets only rehearse the plumbing.
+            "scaling": "weak" if world == 1 or comm.backend == "rccl" else "plumbing-only",
+            "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: synthetic sparse AD/DP N=%d variants x M=%d cells, K=%d "
                                    "donors, nnz=%d (SURVEY.md 8d generator, seed 0); one restart "
@@ -681,14 +818,15 @@ def main():
                          "whole_iteration": {"algorithmic_bytes": B["total"],
                                              "achieved_GBs": B["total"] / (wall_max / args.steps) / 1e9,
                                              "frac": B["total"] / (wall_max / args.steps) / 1e9 / HBM_PEAK_GBS}},
+            "comm": comm_rec,
             "preceded_by": preceded_by,
             # what precedes the timed window differs with the flags, so `value` is
             # like-for-like only between lines that carry the same tag
-            "protocol": {"version": "r5", "warmup": args.warmup, "steps": args.steps,
+            "protocol": {"version": "r6", "warmup": args.warmup, "steps": args.steps,
                          "legs_before_timed_region": len(preceded_by),
                          "flags": {"no_cpu": bool(args.no_cpu), "no_c4": bool(args.no_c4),
                                    "no_side_legs": bool(args.no_side_legs)},
-                         "tag": "r5:w%d:k%d:%s" % (args.warmup, args.steps, "+".join(
+                         "tag": "r6:w%d:k%d:%s" % (args.warmup, args.steps, "+".join(
                              x for x, on in (("c2c5", c2 is not None), ("c4", c4 is not None),
                                              ("parity", parity_gpu is not None)) if on) or "bare")},
             "cpu_baseline": cpu,
@@ -697,6 +835,7 @@ def main():
             "c2": c2,
             "c5": c5,
             "c3_skew": c3_skew,
+            "c3_flags": c3_flags,
             "e2e": e2e,
             "ms_per_step_repeats": {"runs": [round(x, 4) for x in repeats],
                                     "min": round(min(repeats), 4), "median": round(float(np.median(repeats)), 4),

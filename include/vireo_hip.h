@@ -43,6 +43,11 @@ int vrx_device_count(int* n);
 /* name / CU count / HBM bytes of a device (for logs and bench.py) */
 int vrx_device_info(int device, char* name, int name_len, int* n_cu, int64_t* hbm_bytes);
 
+/* PCI bus id ("0000:c1:00.0") of a device: the physical GPU behind a rank of the restart shard
+ * (the reference's pool workers are anonymous, vireo_wrap.py:74-83; a multi-GPU record must say
+ * which GPUs it ran on). */
+int vrx_device_pci_bus_id(int device, char* out, int out_len /* >= 16 */);
+
 /* ---- the sparse count matrices -------------------------------------------------------
  * AD and DP (n_var x n_cell), given once, as ONE CSC pattern (the union of both patterns,
  * row indices strictly increasing inside a column) carrying an (ad, dp) pair per entry.
@@ -254,6 +259,14 @@ int vrx_comm_allgather_f64(vrx_comm* c, const double* local, int64_t n_local, do
 int vrx_comm_barrier(vrx_comm* c);
 /* broadcast a host buffer of doubles from `root` (winner's state to rank 0 / everyone) */
 int vrx_comm_bcast_f64(vrx_comm* c, double* buf, int64_t n, int root);
+
+/* info4 = rank, world, device, librccl version code (ncclGetVersion; 0 = unknown) */
+int vrx_comm_info(vrx_comm* c, int32_t* info4);
+/* The winner's state to every rank, DEVICE TO DEVICE: vireo_wrap.py:90-94 continues with
+ * `_models_all[_idx]`; here the owner of the best restart broadcasts ID_prob, GT_prob, beta_mu,
+ * beta_sum straight from its model's HBM buffers into the same buffers of every other rank's model
+ * (one RCCL group call, no host staging).  All ranks pass models of one shape and configuration. */
+int vrx_comm_bcast_model(vrx_comm* c, vrx_model* m, int root);
 
 /* ---- restart initialisation ------------------------------------------------------------
  * Every restart's initial ID_prob / GT_prob comes from NumPy's legacy global stream

@@ -13,7 +13,8 @@ script settles, case by case, which float64 result is closer to the mathematics:
 iterations in 80-bit extended precision (np.longdouble, eps 1.1e-19; SciPy's sparse products
 instantiated for long double; digamma from mpmath at 40 digits).
 
-Run in the build container (no GPU; ~15 minutes on 8 cores):  python tests/golden/make_bmm_arbiter.py
+Run in the build container (no GPU; ~25 minutes on 8 cores from scratch, ARBITER_REBUILD=1; by default only
+the seeds the fixture does not hold yet are computed):  python tests/golden/make_bmm_arbiter.py
 Output: tests/golden/fuzz_arbiter.npz -- per seed the END STATE of the exact run rounded to
 float64: ``s<seed>_ID_prob`` (clone mode: the whole (M, K) posterior); for the Vireo case
 ``s<seed>_ID_prob``, and ``s<seed>_GT_rows`` / ``s<seed>_GT_prob``: the variants kept (every 8th,
@@ -46,6 +47,11 @@ VIREO_SEEDS = [537]
 # 56 more misses of the same class; the oracle up to 3.4e-3 from exact)
 BMM_SEEDS += [1003, 1263, 2907]
 VIREO_SEEDS += [1648, 2260]
+# ... and (round 6) every case of the three sweeps on which the DEVICE itself is further than 1e-5
+# from exact (18 of the 199 misses, all clone mode; profiles/r06_fuzz_deviation_class_199.txt): 563, 1263
+# and 2907 are above, these are the other fifteen.  The GPU test pins the device's distance from exact
+# as an upper bound per seed (tests/test_gpu_fuzz.py::DEVICE_BEYOND_RTOL).
+BMM_SEEDS += [1583, 1919, 2547, 2615, 2967, 3811, 4691, 4895, 6887, 7179, 7383, 7583, 7695, 7867, 7911]
 GT_EVERY = 8
 THETA_SEEDS = [1263]     # cases whose THETA misses 1e-5 too (one beta_sum entry at 1.2e-5): the exact theta is kept
 
@@ -176,14 +182,24 @@ def main():
     if only:
         jobs = [j for j in jobs if j[1] in only]
     store = {}
+    path = os.path.join(HERE, "fuzz_arbiter.npz")
+    if not only and os.path.exists(path) and os.environ.get("ARBITER_REBUILD") != "1":
+        # extend the fixture: seeds it already holds are kept as they are (ARBITER_REBUILD=1: all again)
+        old = np.load(path)
+        store.update({k: old[k] for k in old.files if k not in ("bmm_seeds", "vireo_seeds")})
+        all_jobs = jobs
+        jobs = [j for j in jobs if "s%d_n_exec" % j[1] not in store]
+        print("fixture holds %d of %d cases; computing %d" % (len(all_jobs) - len(jobs), len(all_jobs), len(jobs)))
+    else:
+        all_jobs = jobs
     with mp.Pool(min(8, os.cpu_count() or 1)) as pool:
         for seed, out, note in pool.imap_unordered(_run, jobs):
             print(note, flush=True)
             store.update(out)
-    store["bmm_seeds"] = np.array([s for k, s in jobs if k == "bmm"], dtype=np.int32)
-    store["vireo_seeds"] = np.array([s for k, s in jobs if k == "vireo"], dtype=np.int32)
+    store["bmm_seeds"] = np.array([s for k, s in all_jobs if k == "bmm"], dtype=np.int32)
+    store["vireo_seeds"] = np.array([s for k, s in all_jobs if k == "vireo"], dtype=np.int32)
     if not only:
-        np.savez_compressed(os.path.join(HERE, "fuzz_arbiter.npz"), **store)
+        np.savez_compressed(path, **store)
         print("saved fuzz_arbiter.npz: %d arrays" % len(store))
 
 

@@ -1,6 +1,7 @@
 """The random-case comparison of tests/test_gpu_fuzz.py for any seed range (MI355X).
 
     python tests/perf/fuzz_sweep.py LO HI [OUTDIR [KINDS]]      KINDS: keep the device results of these kinds only (vireo,bmm)
+    python tests/perf/fuzz_sweep.py @FILE 0 [OUTDIR [KINDS]]    the seeds listed in FILE (whitespace / comma separated)
 
 One line per case on stdout (kind, shape, K, largest count, iterations, worst relative error per
 compared array), `MISS` where an array misses rtol 1e-5 against the oracle; for every miss the
@@ -77,14 +78,19 @@ def run_case(seed):
 
 
 def main():
-    lo, hi = int(sys.argv[1]), int(sys.argv[2])
+    if sys.argv[1].startswith("@"):     # a seed list (round 6: the misses of an earlier sweep, for the arbiter)
+        seeds = [int(x) for x in open(sys.argv[1][1:]).read().replace(",", " ").split()]
+        lo, hi = min(seeds), max(seeds) + 1
+    else:
+        lo, hi = int(sys.argv[1]), int(sys.argv[2])
+        seeds = range(lo, hi)
     outdir = sys.argv[3] if len(sys.argv) > 3 else None
     keep_kinds = sys.argv[4].split(",") if len(sys.argv) > 4 else ("vireo", "bmm")
     if outdir:
         os.makedirs(outdir, exist_ok=True)
     n = {"vireo": 0, "bmm": 0}
     missed = {"vireo": [], "bmm": []}
-    for seed in range(lo, hi):
+    for seed in seeds:
         try:
             r, keep = run_case(seed)
         except Exception as e:      # noqa: BLE001 -- a crash is a finding of the sweep too

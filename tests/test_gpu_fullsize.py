@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from oracle import vireo_oracle as O
+from tests import gold
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-5
@@ -71,6 +72,107 @@ def test_config3_fit_properties_and_one_step_parity(va):
     elbo_ref = O.vireo_elbo(st, L)
     m.update_theta_size(counts, None)
     m.update_GT_prob(counts, None)
+    Lg = m.update_ID_prob(counts, None)
+    elbo_gpu = m.get_ELBO(Lg, counts, None)
+    np.testing.assert_allclose(m.beta_mu, st.beta_mu, rtol=RTOL)
+    np.testing.assert_allclose(m.beta_sum, st.beta_sum, rtol=RTOL)
+    np.testing.assert_allclose(m.GT_prob, st.GT_prob, rtol=RTOL, atol=1e-290)
+    np.testing.assert_allclose(m.ID_prob, st.ID_prob, rtol=RTOL, atol=1e-290)
+    np.testing.assert_allclose(Lg, L, rtol=1e-9)
+    np.testing.assert_allclose(elbo_gpu, elbo_ref, rtol=RTOL)
+    assert np.array_equal(m.ID_prob.argmax(1), st.ID_prob.argmax(1))
+
+
+# ---------------------------------------------------------------- the flag paths at headline size
+_C3 = {}
+
+
+def _c3_problem():
+    """the c3 workload, its device problem and its SciPy form, built once for the flag tests"""
+    if not _C3:
+        from vireo_amd import synth
+        from vireo_amd.counts import DeviceCounts
+        N, M, K, dens = synth.CONFIGS["c3"]
+        w = synth.donor_workload(N, M, K, dens, seed=0)
+        _C3["counts"] = DeviceCounts.from_merged(w["shape"], w["colptr"], w["rowidx"], w["ad"], w["dp"])
+        _C3["scipy"] = synth.as_scipy(w)
+        _C3["GT"], _C3["z"] = w["GT"], w["z"]      # the planted genotypes and donors
+    return _C3
+
+
+@pytest.mark.parametrize("flag", ["ase", "fixedGT", "priorGT", "fixsum"])
+def test_config3_flag_paths(va, flag):
+    """the flag paths take other kernels than the headline measures (vrx_theta_ase and
+    the per-variant theta tables; W from a fixed GT; the GT_prior table in vrx_gt_update and KL_GT;
+    the fixed-sum theta update) and had no evidence above 2 600 x 2 200.  At c3 (N=100k x M=50k, K=16):
+      ase      ASE_mode=True                                       (vireo_model.py:82, :177)
+      fixedGT  learn_GT=False, GT_prob_init = GT_prior = the donors' genotypes: the command's mode 2,
+               `vireo -d donors.vcf` (vireo.py:149-205, vireo_model.py:129-137)
+      priorGT  learn_GT=True with a non-uniform GT_prior (mode 4, --forceLearnGT)
+      fixsum   fix_beta_sum=True                                   (vireo_model.py:184)
+    each: the whole timing protocol twice (bitwise repeatable), properties of the fitted state, and ONE
+    oracle iteration from the fitted state against one GPU iteration from it (rtol 1e-5, identical
+    assignments)."""
+    from vireo_amd.synth import planted_gt_prior
+    c3 = _c3_problem()
+    counts, (AD, DP), GT_true, z = c3["counts"], c3["scipy"], c3["GT"], c3["z"]
+    N, M = counts.shape
+    K = 16
+    kw = dict(ase=dict(ASE_mode=True), fixedGT=dict(learn_GT=False), priorGT=dict(), fixsum=dict(fix_beta_sum=True))[flag]
+    prior = None
+    if flag == "fixedGT":
+        prior = planted_gt_prior(GT_true, 1.0)            # (set_prior clips to [1e-5, 1 - 1e-5])
+    elif flag == "priorGT":
+        # a donor VCF that is right for 90 % of the (variant, donor) calls
+        rng = np.random.default_rng(5)
+        noisy = np.where(rng.random(GT_true.shape) < 0.9, GT_true, rng.integers(0, 3, GT_true.shape))
+        prior = planted_gt_prior(noisy, 0.8)
+
+    def fit():
+        np.random.seed(1)
+        init = dict(GT_prob_init=prior.copy()) if prior is not None else {}
+        m = va.Vireo(n_var=N, n_cell=M, n_donor=K, **kw, **init)
+        if prior is not None:
+            m.set_prior(GT_prior=prior.copy())
+        m.fit(counts, None, min_iter=5, max_iter=20, delay_fit_theta=3, verbose=False)
+        return m
+
+    m = fit()
+    m2 = fit()
+    for name in ("ELBO_", "ID_prob", "GT_prob", "beta_mu", "beta_sum"):
+        assert np.array_equal(getattr(m, name), getattr(m2, name)), name
+    assert np.all(np.isfinite(m.ELBO_)) and len(m.ELBO_) >= 5
+    np.testing.assert_allclose(m.ID_prob.sum(1), 1.0, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(m.GT_prob.sum(2), 1.0, rtol=0, atol=1e-12)
+    assert m.beta_mu.shape == ((N, 3) if flag == "ase" else (1, 3))
+    assert np.all((m.beta_mu > 0) & (m.beta_mu < 1)) and np.all(m.beta_sum > 0)
+    if flag == "fixsum":
+        assert np.all(m.beta_sum == 50.0)
+    if flag == "fixedGT":       # the genotypes never move, and with them known the donors are the planted ones
+        m0 = va.Vireo(n_var=N, n_cell=M, n_donor=K, learn_GT=False, GT_prob_init=prior.copy())
+        assert np.array_equal(m.GT_prob, m0.GT_prob)
+        assert np.mean(m.ID_prob.argmax(1) == z) > 0.999
+    lab = m.ID_prob.argmax(1)
+    conf = np.zeros((K, K), int)
+    np.add.at(conf, (z, lab), 1)
+    purity = conf.max(1).sum() / M
+    print("c3 %s: %d ELBO entries, last %.6f, purity %.4f" % (flag, len(m.ELBO_), m.ELBO_[-1], purity))
+    assert purity > (0.9 if flag == "ase" else 0.99)
+    # ONE oracle iteration from the fitted state vs one GPU iteration from the same state
+    st = O.vireo_new(M, N, K, ID_prob_init=m.ID_prob, GT_prob_init=m.GT_prob, beta_mu_init=m.beta_mu.copy(),
+                     beta_sum_init=m.beta_sum.copy(), learn_GT=kw.get("learn_GT", True),
+                     ASE_mode=kw.get("ASE_mode", False), fix_beta_sum=kw.get("fix_beta_sum", False))
+    st.ID_prob, st.GT_prob = m.ID_prob.copy(), m.GT_prob.copy()
+    if prior is not None:
+        O.vireo_prior(st, GT_prior=prior.copy())
+    O.vireo_theta_step(st, AD, DP)
+    if st.learn_GT:
+        O.vireo_gt_step(st, AD, DP)
+    L = O.vireo_id_step(st, AD, DP)
+    elbo_ref = O.vireo_elbo(st, L)
+    m.update_theta_size(counts, None)
+    if m.learn_GT:
+        m.update_GT_prob(counts, None)
     Lg = m.update_ID_prob(counts, None)
     elbo_gpu = m.get_ELBO(Lg, counts, None)
     np.testing.assert_allclose(m.beta_mu, st.beta_mu, rtol=RTOL)
@@ -169,6 +271,60 @@ def test_rccl_communicator_world1(va):
     comm.barrier()
     assert np.array_equal(gather_restart_elbos(comm, 3, {0: 1.0, 1: 7.0, 2: 7.0}), [1, 7, 7])
     comm.close()
+
+
+def test_winner_broadcast_device_to_device_equals_host_route(va):
+    """``vrx_comm_bcast_model`` (ncclBroadcast straight from / into the model's HBM
+    buffers) against the host-staged route of ``_bcast_model`` -- over RCCL at world 1, the most a
+    one-GPU box can run: both leave every rank's model with the root's state, bit for bit, and the
+    device model itself is untouched by the in-place broadcast.  (At world 2 the sharded vireo_wrap of
+    test_restart_shard_over_rccl_world2 takes the device route.)"""
+    import sys
+    import vireo_amd.vireo_wrap            # noqa: F401   (the package exports the function under this name)
+    from vireo_amd.dist import RcclComm, comm_record
+    W = sys.modules["vireo_amd.vireo_wrap"]
+    AD, DP = gold.c1()
+    comm = RcclComm(0, 1, 0, lambda raw: raw)
+    try:
+        rec = comm_record(comm, 0)
+        assert rec["backend"] == "rccl" and rec["world"] == 1 and rec["distinct_gpus"] == 1
+        assert rec["ranks"][0]["pci_bus_id"] and rec["rccl_version_code"] >= 20000
+        for flags in (dict(), dict(ASE_mode=True)):
+            np.random.seed(4)
+            a = va.Vireo(n_var=AD.shape[0], n_cell=AD.shape[1], n_donor=4, **flags)
+            a.fit(AD, DP, max_iter=6, verbose=False)
+            dm, _ = a._device_model(AD, DP)
+            before = [x.copy() for x in dm.get_state()]
+            via_dev = va.Vireo(n_var=AD.shape[0], n_cell=AD.shape[1], n_donor=4, **flags)
+            via_host = va.Vireo(n_var=AD.shape[0], n_cell=AD.shape[1], n_donor=4, **flags)
+            for m in (via_dev, via_host):
+                m.ID_prob, m.GT_prob, m.beta_mu, m.beta_sum = a.ID_prob, a.GT_prob, a.beta_mu, a.beta_sum
+                m.ELBO_ = a.ELBO_
+            W._bcast_model(comm, via_dev, 0, dm=dm, force=True)
+            W._bcast_model(comm, via_host, 0, dm=None, force=True)
+            after = dm.get_state()
+            for x, y in zip(before, after):
+                assert np.array_equal(x, y)
+            for name in ("ID_prob", "GT_prob", "beta_mu", "beta_sum", "ELBO_"):
+                assert np.array_equal(getattr(via_dev, name), getattr(via_host, name)), name
+                assert np.array_equal(getattr(via_dev, name), getattr(a, name)), name
+            dm.close()
+        # clone mode: no genotype layer (three arrays)
+        from vireo_amd import _lib
+        from vireo_amd.engine import DeviceModel
+        mAD, mDP = gold.mito()
+        np.random.seed(2)
+        b = va.BinomMixtureVB(n_var=mAD.shape[0], n_cell=mAD.shape[1], n_donor=3)
+        bdm = b._device_model(mAD, mDP)
+        st = [None if x is None else x.copy() for x in bdm.get_state()]
+        comm.bcast_model(bdm, 0)
+        for x, y in zip(st, bdm.get_state()):
+            assert (x is None and y is None) or np.array_equal(x, y)
+        bdm.close()
+        with pytest.raises(_lib.VrxError):
+            comm.bcast_model(DeviceModel(va.device_counts(mAD, mDP), _lib.KIND_BMM, 3), 1)   # root outside the world
+    finally:
+        comm.close()
 
 
 def test_config3_whole_protocol_trace_vs_oracle(va):

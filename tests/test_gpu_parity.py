@@ -1085,6 +1085,49 @@ def test_elbo_riding_in_clone_mode_changes_nothing(va, monkeypatch):
     assert out["1"] == out["0"]
 
 
+def test_clone_mode_state_after_a_stop_in_the_middle_of_a_poll_batch(va, monkeypatch):
+    """vrx_bmm_theta writes model state (beta_mu, beta_sum, W), so an ELBO riding in
+    it must never be one whose stop rule can fire -- a stop found by the rider would leave theta one
+    update AHEAD of the state ``_fit_BV`` breaks out with (bmm_model.py:190-199).  The state is compared
+    DIRECTLY after a single ``_fit_BV`` (no second fit that would recompute theta from ID_prob), for
+    fits whose rule fires in the middle of a poll batch (iterations min_iter + 2 .. min_iter + 4 of
+    VIREO_FIT_BATCH = 4: not the batch's last, whose ELBO is never deferred): bitwise equal with
+    VIREO_ELBO_RIDE = 1 and 0, and equal to the oracle's state."""
+    from vireo_amd import synth
+    mAD, mDP = gold.mito()
+    cases = [("mito", 3, 5, 2), ("mito", 4, 3, 2), ("mito", 4, 7, 5), ("mito", 5, 3, 2),      # (data, K, seed, min_iter)
+             ((40, 2000, 3, 5), 8, 5, 2), ((60, 3000, 3, 2), 6, 2, 2), ((40, 4000, 6, 11), 6, 11, 3)]
+    # (the oracle stops these at iterations 5, 5, 7, 10, 72, 4, 6: every one inside a poll batch)
+    mid_batch = 0
+    for data, k, seed, mn in cases:
+        A, D = (mAD, mDP) if data == "mito" else synth.clone_workload(data[0], data[1], data[2], seed=data[3])
+        n, m = A.shape
+        res = {}
+        for ride in ("1", "0"):
+            monkeypatch.setenv("VIREO_ELBO_RIDE", ride)
+            np.random.seed(seed)
+            b = va.BinomMixtureVB(n_var=n, n_cell=m, n_donor=k)
+            b._fit_BV(A, D, max_iter=200, min_iter=mn, epsilon_conv=1e-2, verbose=False)
+            res[ride] = b
+        a, b = res["1"], res["0"]
+        assert len(a.ELBO_iters) == len(b.ELBO_iters)
+        for name in ("ELBO_iters", "ID_prob", "beta_mu", "beta_sum"):
+            assert np.array_equal(getattr(a, name), getattr(b, name)), (name, data, seed)
+        it = len(a.ELBO_iters)                  # the iteration the rule fired at (ELBO[:it] is kept)
+        first_end = max(mn + 2, 4) - 1          # last iteration of the first batch
+        if it > first_end and (it - first_end) % 4 != 0 and it < 199:
+            mid_batch += 1
+        np.random.seed(seed)
+        ref = O.bmm_new(m, n, k)
+        O.bmm_fit_vb(ref, A, D, min_iter=mn, max_iter=200)
+        assert len(ref.ELBO_iters) == it
+        close(a.ELBO_iters, ref.ELBO_iters)
+        close(a.beta_mu, ref.beta_mu)
+        close(a.beta_sum, ref.beta_sum)
+        close(a.ID_prob, ref.ID_prob)
+    assert mid_batch >= 5, "the cases of this list no longer stop in the middle of a poll batch"
+
+
 @pytest.mark.parametrize("case", ["c1", "c2_lds", "batch"])
 def test_elbo_riding_in_the_next_theta_kernel_changes_nothing(va, monkeypatch, case):
     """Launch-bound problems: the ELBO + stop rule of an iteration are finalised by an extra block

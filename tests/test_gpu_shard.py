@@ -211,22 +211,58 @@ def test_bench_launches_its_own_ranks(va):
     prints the ONE JSON line, restart r runs on rank r.  Both ranks on device 0 over the
     host-socket communicator (RCCL refuses two ranks on one device)."""
     import json
-    env = dict(os.environ, VIREO_COMM="tcp", VIREO_DEVICE="0")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+    env = dict(os.environ, VIREO_DEVICE="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "VIREO_COMM", "VIREO_FORCE_RCCL"):
         env.pop(k, None)
     lines = {}
     for n in (2, 1):
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--config", "c2",
-                            "--steps", "20", "--warmup", "5", "--only-headline"],
+                            "--steps", "20", "--warmup", "5", "--only-headline", "--comm", "tcp"],
                            env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
         assert p.returncode == 0, p.stderr[-2000:]
         out = [ln for ln in p.stdout.splitlines() if ln.strip()]
         assert len(out) == 1, p.stdout[-2000:]
         lines[n] = json.loads(out[0])
     two, one = lines[2], lines[1]
-    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["value"] > 0
+    # ranks that share a device over host sockets rehearse the plumbing: the line says so
+    assert two["n_gpus"] == 2 and two["scaling"] == "plumbing-only" and two["value"] > 0
+    assert one["scaling"] == "weak" and one["comm"]["backend"] == "local" and one["comm"]["world"] == 1
+    c = two["comm"]
+    assert c["backend"] == "tcp" and c["world"] == 2 and c["distinct_gpus"] == 1
+    assert [r["rank"] for r in c["ranks"]] == [0, 1] and {r["device"] for r in c["ranks"]} == {0}
+    assert c["ranks"][0]["pci_bus_id"] == c["ranks"][1]["pci_bus_id"] and c["ranks"][0]["pid"] != c["ranks"][1]["pid"]
+    assert c["allgather_us"]["median"] > 0 and c["winner_broadcast"]["host_staged_us"]["min"] > 0
+    assert "device_to_device_us" not in c["winner_broadcast"]          # (no device path over sockets)
     assert len(two["config"]["restart_protocol_elbos"]) == 2
     # rank 0 iterates restart 0 (= the world-1 run's), rank 1 the second constructor's draws
     assert two["config"]["restart_protocol_elbos"][0] == one["config"]["restart_protocol_elbos"][0]
     assert two["config"]["restart_protocol_elbos"][1] != two["config"]["restart_protocol_elbos"][0]
     assert np.all(np.isfinite(two["config"]["restart_elbos"]))
+
+
+def test_bench_line_names_its_communicator_rccl_world1(va):
+    """the JSON line says which communicator produced it.  VIREO_FORCE_RCCL=1 takes
+    the RCCL path at world 1 on this one-GPU box: backend rccl, RCCL's version, the rank's device and
+    PCI bus id as all-gathered over RCCL, the unique-id / ncclCommInitRank times, a timed all-gather,
+    and the winner's state broadcast device to device beside the host-staged route."""
+    import json
+    import re
+    env = dict(os.environ, VIREO_FORCE_RCCL="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "VIREO_COMM", "VIREO_DEVICE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c2", "--steps", "20",
+                        "--warmup", "5", "--only-headline"], env=env, capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(out) == 1, p.stdout[-2000:]
+    line = json.loads(out[0])
+    c = line["comm"]
+    assert c["backend"] == "rccl" and c["world"] == 1 and line["scaling"] == "weak"
+    assert re.fullmatch(r"\d+\.\d+\.\d+", c["rccl_version"]) and c["rccl_version_code"] >= 20000
+    assert len(c["ranks"]) == 1 and c["ranks"][0]["rank"] == 0 and c["ranks"][0]["device"] == 0
+    assert re.fullmatch(r"[0-9a-f]{4}:[0-9a-f]{2}:[0-9a-f]{2}\.[0-9a-f]", c["ranks"][0]["pci_bus_id"])
+    assert c["distinct_gpus"] == 1 and c["comm_init_rank_ms"] > 0 and c["unique_id_exchange_ms"] >= 0
+    assert c["allgather_us"]["n_init"] == 32 and c["allgather_us"]["median"] > 0
+    wb = c["winner_broadcast"]
+    assert wb["device_to_device_us"]["min"] > 0 and wb["host_staged_us"]["min"] > 0 and wb["state_bytes"] > 0

@@ -7,6 +7,7 @@ import re
 import socket
 import subprocess
 import sys
+import time
 import ctypes
 
 import numpy as np
@@ -651,3 +652,148 @@ def test_bench_side_legs_cannot_cost_the_headline(capsys):
     B = bench.algorithmic_bytes(100000, 50000, 16, 3, 99006675)      # 2.58 GB at c3
     assert B["total"] == B["variant"] + B["cell"] + B["dense"] and abs(B["total"] - 2.5816e9) < 1e6
     assert B["cell"] == 12 * 99006675 + 4 * 50001 + 16 * 100000 * 16 + 8 * 50000 * 16
+
+
+# ---------------------------------------------------------------- round 6: first contact with a multi-GPU node
+def test_free_port_reserves_the_three_rendezvous_ports():
+    """MASTER_PORT, the unique-id port (+ 1) and the TcpComm harness's port (+ 2) are all free"""
+    import socket
+    from vireo_amd import launch
+    p = launch.free_port()
+    for q in (p, p + 1, p + 2):
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            s.bind(("127.0.0.1", q))
+
+
+def test_tcp_comm_rank0_survives_strangers():
+    """a connection that closes early or never speaks must not abort (or stall) rank 0's
+    accept loop, and a peer cannot announce an absurd message length"""
+    import socket
+    import struct
+    import threading
+    from vireo_amd import dist
+    port = _free_port()
+    out, errs = {}, []
+
+    def rank_main(r):
+        try:
+            c = dist.TcpComm(r, 2, port, timeout=30.0, rdzv_timeout=60.0)
+            out[r] = c.allgather(np.array([float(r)]))
+            c.close()
+        except Exception as e:      # noqa: BLE001
+            errs.append((r, e))
+
+    t0 = threading.Thread(target=rank_main, args=(0,))
+    t0.start()
+    time.sleep(0.3)
+    quick = socket.create_connection(("127.0.0.1", port), timeout=5)
+    quick.close()                                   # closes before saying hello
+    silent = socket.create_connection(("127.0.0.1", port), timeout=5)   # never says anything
+    t1 = threading.Thread(target=rank_main, args=(1,))
+    t1.start()
+    t0.join(60)
+    t1.join(60)
+    silent.close()
+    assert not errs, errs
+    assert list(out[0]) == [0.0, 1.0] and list(out[1]) == [0.0, 1.0]
+    a, b = socket.socketpair()
+    a.sendall(struct.pack("<q", 1 << 40))
+    with pytest.raises(ConnectionError):
+        dist._recv(b)
+    a.close()
+    b.close()
+
+
+def test_winner_rules_follow_numpy_with_nans():
+    """vireo_wrap keeps np.argmax(ELBOs) (vireo_wrap.py:89-90: a NaN wins, the first one);
+    BinomMixtureVB.fit keeps the last i with elbo[i] > np.max(elbo[:i]) (bmm_model.py:248: a NaN
+    freezes the choice).  Every rank applies the rule to ITS restarts in order; the owner of the
+    global winner must end up holding it."""
+    from vireo_amd.bmm_model import _is_record
+    from vireo_amd.dist import first_record, my_restarts
+    from vireo_amd.restarts import _argmax_takes
+    nan = float("nan")
+    rng = np.random.default_rng(3)
+    cases = [[1.0], [1, 3, 2, 3, 5, 4], [2, 2, 1], [nan, 1, 2], [1, nan, 9], [1, 5, nan, 9, nan], [3, 1, 9, nan]]
+    cases += [list(rng.normal(size=n)) for n in (7, 32, 33)]
+    for e in cases:
+        e = np.array(e, dtype=float)
+        # the reference's loop, literally
+        best = None
+        inits = []
+        for i, v in enumerate(e):
+            inits.append(v)
+            if i == 0 or v > np.max(inits[:-1]):
+                best = i
+        assert first_record(e) == best
+        seen, kept = [], None
+        for i, v in enumerate(e):
+            if _is_record(seen, v):
+                kept = i
+            seen.append(v)
+        assert kept == best
+        for world in (1, 2, 3, 8):
+            win = int(np.argmax(e))
+            owner = win % world
+            held = None
+            for i in my_restarts(len(e), owner, world):
+                if _argmax_takes(held, e[i]):
+                    held = (e[i], i)
+            assert held[1] == win, (e, world)
+
+
+def test_bench_refuses_an_inherited_tcp_communicator():
+    """VIREO_COMM=tcp left in an environment must not turn `bench.py --gpus 8` into a
+    host-socket run that looks like an RCCL one -- refused (exit code 2) before anything starts,
+    unless --comm tcp is on the command line itself"""
+    import subprocess
+    env = dict(os.environ, VIREO_COMM="tcp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20",
+                        "--warmup", "5"], capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode == 2 and p.stdout == "" and time.time() - t0 < 60
+    assert "VIREO_COMM=tcp" in p.stderr and "--comm tcp" in p.stderr
+
+
+def test_failing_rccl_initialisation_ends_every_rank_with_the_reason(tmp_path):
+    """First contact: when the RCCL communicator cannot be made (here: no GPU at all -- ncclGetUniqueId
+    fails on rank 0 while rank 1 waits for the id) every rank is gone within 60 s, the launcher
+    returns non-zero, and stderr carries RCCL's error string and the tail of its NCCL_DEBUG=WARN log."""
+    import subprocess
+    from vireo_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible here: the communicator would come up")
+    stub = tmp_path / "rank.py"
+    stub.write_text("import sys\nsys.path.insert(0, %r)\nfrom vireo_amd import dist\n"
+                    "c = dist.make_comm()\nprint('up', c.backend)\n" % ROOT)
+    code = ("import sys; sys.path.insert(0, %r); from vireo_amd import launch; "
+            "sys.exit(launch.spawn_ranks([sys.executable, %r], 4))" % (ROOT, str(stub)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "VIREO_COMM", "NCCL_DEBUG", "NCCL_DEBUG_FILE")}
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=150, env=env)
+    assert p.returncode != 0 and time.time() - t0 < 60
+    assert "up rccl" not in p.stdout
+    assert "failed:" in p.stderr and "NCCL_DEBUG=WARN tail" in p.stderr
+    assert "stopping the other ranks" in p.stderr
+
+
+def test_rccl_init_watchdog_ends_a_rank_that_hangs(tmp_path):
+    """a rank whose ncclCommInitRank neither returns nor fails (a peer died behind the rendezvous) is
+    ended by the watchdog with exit code 3 and a message (the library call is replaced by a sleep)"""
+    import subprocess
+    stub = tmp_path / "hang.py"
+    stub.write_text(
+        "import sys, time\nsys.path.insert(0, %r)\nfrom vireo_amd import dist, _lib\n"
+        "class Fake:\n"
+        "    def vrx_comm_unique_id(self, uid): return 0\n"
+        "    def vrx_comm_create(self, *a): time.sleep(60); return 0\n"
+        "    def vrx_last_error(self): return b''\n"
+        "_lib.lib = lambda: Fake()\n"
+        "dist.RcclComm(0, 1, 0, lambda raw: raw, init_timeout=1.0)\nprint('not reached')\n" % ROOT)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, str(stub)], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 3 and time.time() - t0 < 30
+    assert "ncclCommInitRank had not returned" in p.stderr and "not reached" not in p.stdout

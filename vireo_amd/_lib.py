@@ -39,6 +39,7 @@ SIGNATURES = {
     "vrx_last_error": (C.c_char_p, []),
     "vrx_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "vrx_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), _I64]),
+    "vrx_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "vrx_problem_create": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int64, _I64, _I32, _I32,
                                      _I32, C.POINTER(_P)]),
     "vrx_problem_destroy": (None, [_P]),
@@ -77,6 +78,8 @@ SIGNATURES = {
     "vrx_comm_allgather_f64": (C.c_int, [_P, _D, C.c_int64, _D]),
     "vrx_comm_barrier": (C.c_int, [_P]),
     "vrx_comm_bcast_f64": (C.c_int, [_P, _D, C.c_int64, C.c_int]),
+    "vrx_comm_info": (C.c_int, [_P, _I32]),
+    "vrx_comm_bcast_model": (C.c_int, [_P, _P, C.c_int]),
     "vrx_mt19937_random_sample": (C.c_int, [C.POINTER(C.c_uint32), _I32, _D, C.c_int64]),
     "vrx_mt19937_skip": (C.c_int, [C.POINTER(C.c_uint32), _I32, C.c_int64, C.c_int32]),
     "vrx_np_sum_f32": (C.c_int, [C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_float)]),
@@ -131,6 +134,12 @@ def device_info(device=0):
     mem = C.c_int64(0)
     check(lib().vrx_device_info(device, name, 256, C.byref(cu), C.byref(mem)))
     return dict(name=name.value.decode(), n_cu=cu.value, hbm_bytes=mem.value)
+
+
+def device_pci_bus_id(device=0):
+    buf = C.create_string_buffer(32)
+    check(lib().vrx_device_pci_bus_id(device, buf, 32))
+    return buf.value.decode()
 
 
 def require_gpu():

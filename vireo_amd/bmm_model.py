@@ -6,10 +6,16 @@ import numpy as np
 
 from . import _lib
 from .counts import device_counts
-from .dist import LocalComm, gather_restart_elbos, my_restarts
+from .dist import LocalComm, first_record, gather_restart_elbos, my_restarts
 from .engine import DeviceBatch, DeviceModel
 from .restarts import LegacyStream, restart_batch
 from .vireo_base import normalize
+
+
+def _is_record(seen, value):
+    """``i == 0 or ELBO_iters[-1] > np.max(ELBO_inits[:-1])`` (bmm_model.py:248), NaNs as NumPy
+    treats them: a NaN among the earlier values makes the comparison False for good"""
+    return not seen or bool(value > np.max(seen))
 
 
 class BinomMixtureVB():
@@ -180,7 +186,7 @@ class BinomMixtureVB():
         -> ({restart: ELBO}, (ELBO, restart, trace) of the first maximum or None)"""
         db = DeviceBatch(counts, _lib.KIND_BMM, self.n_donor, R, fix_beta_sum=self.fix_beta_sum)
         self._push_prior(db)
-        local, best = {}, None
+        local, best, seen = {}, None, []
         consumed = 0
         for base in range(0, len(mine), R):
             ids = mine[base:base + R]
@@ -200,17 +206,18 @@ class BinomMixtureVB():
                 if verbose:
                     self._warn(trace, it, min_iter, max_iter_pre)
                 local[i] = trace[:it][-1]
-                if best is None or local[i] > best[0]:            # first max wins
+                if _is_record(seen, local[i]):
                     db.copy_to(dm, slot)
                     dm.snapshot()
                     best = (local[i], i, trace[:it] + 0)
+                seen.append(local[i])
         self._skip_initials(n_init - consumed)
         db.close()
         return local, best
 
     def _fit_inits_single(self, counts, dm, n_init, mine, max_iter_pre, **kwargs):
         """the same, one restart per device model (problems with no idle columns)"""
-        local, best = {}, None
+        local, best, seen = {}, None, []
         consumed = 0
         for i in mine:
             self._skip_initials(i - consumed)
@@ -218,9 +225,10 @@ class BinomMixtureVB():
             self.set_initial(self.beta_mu_init, self.beta_sum_init, self.ID_prob_init)
             self._fit_BV(counts, None, max_iter=max_iter_pre, _dm=dm, **kwargs)
             local[i] = self.ELBO_iters[-1]
-            if best is None or local[i] > best[0]:
+            if _is_record(seen, local[i]):
                 dm.snapshot()
                 best = (local[i], i, self.ELBO_iters + 0)
+            seen.append(local[i])
         self._skip_initials(n_init - consumed)
         return local, best
 
@@ -249,19 +257,30 @@ class BinomMixtureVB():
         else:
             local, best = self._fit_inits_single(counts, dm, n_init, mine, max_iter_pre, **kwargs)
         elbo_inits = gather_restart_elbos(comm, n_init, local)
-        winner = int(np.argmax(elbo_inits))           # bmm_model.py:248-251: the first maximum
+        winner = first_record(elbo_inits)             # bmm_model.py:248-252, NaN rule included
         owner = winner % comm.world
         if comm.rank == owner:
-            assert best is not None and best[1] == winner
+            if best is None or best[1] != winner:
+                # (only a NaN ELBO on ANOTHER rank can do this: the owner applied the reference's
+                #  rule to its own initialisations and could not see that an earlier NaN elsewhere
+                #  had frozen the choice; at world 1 the two always agree)
+                raise _lib.VrxError("initialisation %d is the one bmm_model.py:248 keeps, but rank %d "
+                                    "kept %s (a NaN ELBO among the initialisations: %s)" % (
+                                        winner, comm.rank, "none" if best is None else best[1], elbo_inits))
             dm.restore()
             self._pull(dm)
             self.set_initial(self.beta_mu, self.beta_sum, self.ID_prob)
             self.ELBO_iters = best[2]
             self._fit_BV(counts, None, max_iter=max_iter, _dm=dm, **kwargs)
-        dm.close()
-        if comm.world > 1:
+        if comm.world > 1 and hasattr(comm, "bcast_model"):      # device to device under RCCL
+            comm.bcast_model(dm, owner)
+            if comm.rank != owner:
+                self._pull(dm)
+        elif comm.world > 1:
             for name in ("ID_prob", "beta_mu", "beta_sum"):
                 setattr(self, name, comm.bcast(getattr(self, name), owner))
+        dm.close()
+        if comm.world > 1:
             n = comm.bcast(np.array([float(len(self.ELBO_iters))]), owner)
             trace = self.ELBO_iters if comm.rank == owner else np.zeros(int(n[0]))
             self.ELBO_iters = comm.bcast(trace, owner)

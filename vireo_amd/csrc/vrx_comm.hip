@@ -23,7 +23,12 @@ struct RcclApi {
                               hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t,
                               hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    // optional (absent from very old librccl builds): the detail text behind an error code, the version
+    const char* (*GetLastError)(ncclComm_t) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
 };
 RcclApi g_api;
 std::once_flag g_once;
@@ -46,12 +51,21 @@ bool load_rccl() {
         VRX_SYM(AllGather, "ncclAllGather")
         VRX_SYM(AllReduce, "ncclAllReduce")
         VRX_SYM(Broadcast, "ncclBroadcast")
+        VRX_SYM(GroupStart, "ncclGroupStart")
+        VRX_SYM(GroupEnd, "ncclGroupEnd")
         VRX_SYM(GetErrorString, "ncclGetErrorString")
 #undef VRX_SYM
+        g_api.GetLastError = reinterpret_cast<decltype(g_api.GetLastError)>(dlsym(g_api.lib, "ncclGetLastError"));
+        g_api.GetVersion = reinterpret_cast<decltype(g_api.GetVersion)>(dlsym(g_api.lib, "ncclGetVersion"));
         g_ok = true;
     });
     if (!g_ok) vrx_set_error("RCCL (librccl.so.1) could not be loaded: %s", dlerror());
     return g_ok;
+}
+// what librccl recorded behind the last error code ("" when it has nothing / cannot say)
+const char* rccl_detail() {
+    const char* d = g_api.GetLastError ? g_api.GetLastError(nullptr) : nullptr;
+    return d ? d : "";
 }
 }  // namespace
 
@@ -59,7 +73,8 @@ bool load_rccl() {
     do {                                                                                      \
         ncclResult_t r__ = (expr);                                                            \
         if (r__ != ncclSuccess) {                                                             \
-            vrx_set_error("%s failed: %s", #expr, g_api.GetErrorString(r__));                 \
+            vrx_set_error("%s failed: %s%s%s", #expr, g_api.GetErrorString(r__),              \
+                          rccl_detail()[0] ? " -- " : "", rccl_detail());                     \
             return VRX_ERR_COMM;                                                              \
         }                                                                                     \
     } while (0)
@@ -96,7 +111,8 @@ extern "C" int vrx_comm_create(int device, int rank, int world, const uint8_t* i
     std::memcpy(&u, id, sizeof u);
     ncclResult_t r = g_api.CommInitRank(&c->comm, world, u, rank);
     if (r != ncclSuccess) {
-        vrx_set_error("ncclCommInitRank failed: %s", g_api.GetErrorString(r));
+        vrx_set_error("ncclCommInitRank(rank %d of %d, device %d) failed: %s%s%s", rank, world, device,
+                      g_api.GetErrorString(r), rccl_detail()[0] ? " -- " : "", rccl_detail());
         delete c;
         return VRX_ERR_COMM;
     }
@@ -158,6 +174,46 @@ extern "C" int vrx_comm_bcast_f64(vrx_comm* c, double* buf, int64_t n, int root)
     if (c->rank != root)
         VRX_HIP(hipMemcpyAsync(buf, c->recv.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost,
                                c->stream));
+    VRX_HIP(hipStreamSynchronize(c->stream));
+    return VRX_OK;
+}
+
+// rank, world, device of the communicator and librccl's version code (ncclGetVersion: 10000 major +
+// 100 minor + patch from 2.9 on; 0 when the library does not say): bench.py's `comm` block
+extern "C" int vrx_comm_info(vrx_comm* c, int32_t* info4) {
+    VRX_REQUIRE(c && info4, "vrx_comm_info: null argument");
+    int v = 0;
+    if (g_api.GetVersion && g_api.GetVersion(&v) != ncclSuccess) v = 0;
+    info4[0] = c->rank;
+    info4[1] = c->world;
+    info4[2] = c->device;
+    info4[3] = v;
+    return VRX_OK;
+}
+
+// The winner's state, device to device (vireo_wrap.py:90-94 hands `_models_all[_idx]` on; with one
+// process per GPU the other ranks need it too): ncclBroadcast straight from / into the model's HBM
+// buffers -- ID_prob, GT_prob (Vireo), beta_mu, beta_sum in ONE group call -- with no host staging.
+// Every rank passes a model of the same problem shape and configuration.
+extern "C" int vrx_comm_bcast_model(vrx_comm* c, vrx_model* m, int root) {
+    VRX_REQUIRE(c && m && root >= 0 && root < c->world, "vrx_comm_bcast_model: bad argument");
+    VrxModelBuffers b;
+    int rc = vrx_model_state_buffers(m, c->rank != root, &b);  // (drains the model's stream)
+    if (rc) return rc;
+    VRX_REQUIRE(b.device == c->device, "vrx_comm_bcast_model: the model lives on device %d, the communicator on %d",
+                b.device, c->device);
+    VRX_HIP(hipSetDevice(c->device));
+    VRX_NCCL(g_api.GroupStart());
+    for (int i = 0; i < 4; ++i)
+        if (b.n[i] > 0) {
+            const ncclResult_t r = g_api.Broadcast(b.p[i], b.p[i], b.n[i], ncclDouble, root, c->comm, c->stream);
+            if (r != ncclSuccess) {
+                (void)g_api.GroupEnd();
+                vrx_set_error("ncclBroadcast (model state %d) failed: %s", i, g_api.GetErrorString(r));
+                return VRX_ERR_COMM;
+            }
+        }
+    VRX_NCCL(g_api.GroupEnd());
     VRX_HIP(hipStreamSynchronize(c->stream));
     return VRX_OK;
 }

@@ -136,3 +136,14 @@ struct vrx_problem {
     double binom_sum = 0.0;
     std::vector<int32_t> n_vars;
 };
+
+// vrx_comm.hip broadcasts a model's variational state in place (vrx_comm_bcast_model): the four
+// state arrays of a model -- ID_prob, GT_prob (n = 0 in clone mode), beta_mu, beta_sum -- after the
+// model's stream has drained; will_write: the caller overwrites them (derived tables are then stale).
+// Internal to the library (C++ linkage: not part of the C ABI).
+struct VrxModelBuffers {
+    double* p[4];
+    size_t n[4];
+    int device;
+};
+int vrx_model_state_buffers(vrx_model* m, bool will_write, VrxModelBuffers* out);

@@ -44,6 +44,14 @@ extern "C" int vrx_device_info(int device, char* name, int name_len, int* n_cu,
     return VRX_OK;
 }
 
+// "0000:c1:00.0" of a device: which physical GPU a rank of the restart shard sits on
+// (bench.py's `comm` block lists it per rank)
+extern "C" int vrx_device_pci_bus_id(int device, char* out, int out_len) {
+    VRX_REQUIRE(out && out_len >= 16, "vrx_device_pci_bus_id: buffer of >= 16 bytes needed");
+    VRX_HIP(hipDeviceGetPCIBusId(out, out_len, device));
+    return VRX_OK;
+}
+
 // ------------------------------------------------------------------------------------
 // problem
 // ------------------------------------------------------------------------------------
@@ -1818,6 +1826,25 @@ extern "C" int vrx_model_get_state(vrx_model* m, double* ID_prob, double* GT_pro
     return VRX_OK;
 }
 
+// (internal: vrx_common.h) the state arrays vrx_comm_bcast_model sends / receives in place
+int vrx_model_state_buffers(vrx_model* m, bool will_write, VrxModelBuffers* out) {
+    VRX_REQUIRE(m && out, "vrx_model_state_buffers: null argument");
+    VRX_HIP(hipSetDevice(m->p->device));
+    VRX_HIP(hipStreamSynchronize(m->p->stream));
+    const size_t th = (size_t)(m->R * m->th_rows * m->th_cols);
+    out->p[0] = m->ID.p;
+    out->n[0] = (size_t)(m->M * m->Kt);
+    out->p[1] = m->cfg.kind == VRX_KIND_VIREO ? m->GT.p : nullptr;
+    out->n[1] = m->cfg.kind == VRX_KIND_VIREO ? (size_t)m->NKt * m->T : 0;
+    out->p[2] = m->mu.p;
+    out->n[2] = th;
+    out->p[3] = m->sm.p;
+    out->n[3] = th;
+    out->device = m->p->device;
+    if (will_write) m->w_valid = false;
+    return VRX_OK;
+}
+
 extern "C" int vrx_model_get_loglik(vrx_model* m, double* out) {
     VRX_REQUIRE(m && out, "vrx_model_get_loglik: null argument");
     VRX_HIP(hipSetDevice(m->p->device));
@@ -2395,9 +2422,9 @@ static bool elbo_can_ride(const vrx_model* m, int min_iter) {
     // need > 30 iterations to win the wasted pass back).  Measured gain at nnz x columns = 2 / 8 /
     // 16 / 32 M: 10.5 / 6 / 4 / 2.8 % per iteration (profiles/r05_ab_elbo_ride_small_problems.txt);
     // the default stops at 2^25.  VIREO_ELBO_RIDE=0 / 1 forces it off / on (read per call).
-    // Clone mode rides in vrx_bmm_theta; its fits run min_iter >= 20 iterations by default
-    // (bmm_model.py:178), far more than the ~9 a wasted variant pass costs at c5 (62 us against
-    // ~7 us per iteration), so there the rule is min_iter, not size.
+    // Clone mode rides in vrx_bmm_theta, for the iterations whose stop rule cannot fire (it <=
+    // min_iter, see vrx_model_fit): its fits run min_iter >= 20 iterations by default
+    // (bmm_model.py:178), so there the rule is min_iter, not size -- nothing is ever wasted.
     const auto& c = m->cfg;
     if (c.kind == VRX_KIND_VIREO && (c.ase_mode || !c.learn_theta)) return false;
     const bool small = m->p->nnz * (int64_t)m->Kt < ((int64_t)1 << 25);
@@ -2508,7 +2535,15 @@ extern "C" int vrx_model_fit(vrx_model* m, int32_t max_iter, int32_t min_iter, d
             const bool do_theta = m->cfg.kind == VRX_KIND_VIREO && m->cfg.learn_theta &&
                                   it >= delay_fit_theta;
             // (the last iteration of a batch finalises its ELBO itself: the poll reads its stop word)
-            const bool defer = ride && it + 1 < upto && (m->cfg.kind == VRX_KIND_BMM || it + 1 >= delay_fit_theta);
+            // Clone mode: vrx_bmm_theta WRITES model state (beta_mu, beta_sum, W), and its ordinary
+            // blocks read the stop word before the rider in the same launch has judged the previous
+            // iteration -- a stop found there would leave theta one update ahead of what
+            // bmm_model.py:190-199 breaks out with.  So an ELBO rides only while its rule cannot
+            // fire (it <= min_iter: `judge` of vrx_elbo_final_block is false); from min_iter + 1 on
+            // every iteration finalises its own.  (Vireo's vrx_theta_partial writes S and partial
+            // sums only; the kernels that write state run behind the rider.)
+            const bool defer = ride && it + 1 < upto &&
+                               (m->cfg.kind == VRX_KIND_BMM ? it <= min_iter : it + 1 >= delay_fit_theta);
             int rc2;
             if ((rc2 = enqueue_iteration(m, do_theta, rule, defer))) return rc2;
         }

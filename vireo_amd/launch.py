@@ -25,21 +25,23 @@ def launched_externally():
     return "WORLD_SIZE" in os.environ and "RANK" in os.environ
 
 
-def free_port(addr="127.0.0.1"):
-    """a port p such that p and p + 1 are free now (MASTER_PORT and the unique-id port)"""
+def free_port(addr="127.0.0.1", span=3):
+    """a port p such that p, p + 1 and p + 2 are free now: MASTER_PORT, the RCCL unique-id port
+    (dist.socket_exchange: p + 1) and the rendezvous of the one-device TcpComm harness (p + 2)"""
     for _ in range(64):
         with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
             s.bind((addr, 0))
             p = s.getsockname()[1]
-        if p >= 65535:
+        if p + span - 1 > 65535:
             continue
         try:
-            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s2:
-                s2.bind((addr, p + 1))
+            for q in range(p + 1, p + span):
+                with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s2:
+                    s2.bind((addr, q))
             return p
         except OSError:
             continue
-    raise OSError("no two adjacent free ports on %s" % addr)
+    raise OSError("no %d adjacent free ports on %s" % (span, addr))
 
 
 def rank_env(rank, world, port, addr="127.0.0.1", base=None, devices=None):
@@ -49,7 +51,9 @@ def rank_env(rank, world, port, addr="127.0.0.1", base=None, devices=None):
     env.update(RANK=str(rank), LOCAL_RANK=str(dev), WORLD_SIZE=str(world),
                LOCAL_WORLD_SIZE=str(world), MASTER_ADDR=addr, MASTER_PORT=str(port))
     env[LAUNCH_ENV] = "1"
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: what RCCL needs on this host
+    # dmabuf IPC (the image exports this already; kept for environments that were built by hand:
+    # without it RCCL's hipIpcGetMemHandle fails on hosts whose driver only supports dmabuf IPC)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.pop("VIREO_RDZV_PORT", None)
     return env
 

@@ -98,6 +98,18 @@ def restart_batch(n_donor, n_owned, nnz, wide=True):
     return min(R for R, c in costs.items() if c <= 1.05 * best)
 
 
+def _argmax_takes(best, value):
+    """does ``value`` replace the best restart so far the way ``np.argmax`` over the ELBOs picks it
+    (vireo_wrap.py:89-90)?  The first maximum wins; a NaN counts as the maximum (NumPy's rule), the
+    first one for good -- every rank applies this to its own restarts in restart order, so the owner
+    of the global argmax always holds that restart's state."""
+    if best is None:
+        return True
+    if best[0] != best[0]:            # a NaN is kept
+        return False
+    return value != value or value > best[0]
+
+
 class Staged:
     """raw draws of one restart, already uploaded to staging buffer ``buf`` of the runner's model"""
 
@@ -188,7 +200,7 @@ class DeviceRestarts:
             self.iterations += it + 1
             elbo = traces[slot][:it] + self.const
             self.done[im] = elbo[-1]
-            if self.best is None or elbo[-1] > self.best[0]:     # first max wins
+            if _argmax_takes(self.best, elbo[-1]):
                 with _phase("snapshot"):
                     self.db.copy_to(self.dm, slot)
                     self.dm.snapshot()
@@ -238,7 +250,7 @@ class DeviceRestarts:
             trace, it, _ = self.dm.fit(max_iter, 5, 1e-2, delay_fit_theta)
         self.iterations += it + 1
         elbo = trace[:it] + self.const
-        if self.best is None or elbo[-1] > self.best[0]:     # first max wins
+        if _argmax_takes(self.best, elbo[-1]):
             with _phase("snapshot"):
                 self.dm.snapshot()
             self.best = (elbo[-1], im, elbo)
@@ -247,7 +259,9 @@ class DeviceRestarts:
     def winner(self, im, refine):
         """The host ``Vireo`` of restart ``im`` (which must be this rank's best); with
         ``refine`` the fit is continued to convergence first (vireo_wrap.py:94)."""
-        assert self.best is not None and self.best[1] == im
+        if self.best is None or self.best[1] != im:
+            raise _lib.VrxError("restart %d won the search but this rank kept %s" % (
+                im, "nothing" if self.best is None else "restart %d" % self.best[1]))
         t = self.t
         self.dm.restore()
         t.ELBO_ = np.append(t.ELBO_, self.best[2])

@@ -44,7 +44,8 @@ def _skewed_draw(rng, n, size, sigma):
 
 def donor_workload(N, M, K, density, seed=0, skew=None):
     """-> dict(shape, colptr int64, rowidx int32, ad int32, dp int32) on DP's pattern
-    (duplicate (row, col) draws summed).  skew=(sigma_variant, sigma_cell) replaces the
+    (duplicate (row, col) draws summed), plus the planted structure: GT (N, K) genotype classes
+    and z (M,) donor of every cell.  skew=(sigma_variant, sigma_cell) replaces the
     uniform (variant, cell) draws of the 8(d) generator by log-normal weighted ones (real
     scRNA-seq data: per-variant coverage and per-cell depth are heavy-tailed); it is a
     robustness workload, not a BASELINE.json configuration."""
@@ -82,7 +83,17 @@ def donor_workload(N, M, K, density, seed=0, skew=None):
     colptr = np.zeros(M + 1, dtype=np.int64)
     np.cumsum(np.bincount(col, minlength=M), out=colptr[1:])
     return dict(shape=(N, M), colptr=colptr, rowidx=rowidx,
-                ad=(val >> 32).astype(np.int32), dp=(val & 0xFFFFFFFF).astype(np.int32))
+                ad=(val >> 32).astype(np.int32), dp=(val & 0xFFFFFFFF).astype(np.int32), GT=GT, z=z)
+
+
+def planted_gt_prior(GT, sharp):
+    """(N, K, 3) genotype prior from genotype classes: ``sharp`` on the given class, the rest
+    shared -- what the command makes of a donor VCF's GT / PL field (vireo.py:165-170,
+    vcf_utils.parse_donor_GPb) before ``set_prior`` clips it (vireo_model.py:129-137)."""
+    N, K = GT.shape
+    P = np.full((N, K, 3), (1.0 - sharp) / 2.0)
+    np.put_along_axis(P, GT[:, :, None], sharp, axis=2)
+    return P
 
 
 def as_scipy(w):

@@ -79,12 +79,25 @@ def _template(counts, n_donor, learn_GT, GT_prior, kwargs, **state):
     return m
 
 
-def _bcast_model(comm, model, root):
-    """every rank leaves with the root's fitted state."""
-    if comm.world == 1:
+def _bcast_model(comm, model, root, dm=None, force=False):
+    """every rank leaves with the root's fitted state (the reference continues with
+    ``_models_all[_idx]``, vireo_wrap.py:90-94).
+
+    ``dm``: this rank's device model -- on the root it holds the winner's final state.  Under RCCL
+    the four state arrays then travel DEVICE TO DEVICE (``comm.bcast_model``: ncclBroadcast from /
+    into the models' HBM buffers, one group call) and the other ranks download them once for their
+    result dict; the host route (the root's arrays staged back up, broadcast, downloaded: twice
+    across the host on every rank) stays for communicators without a device path (the one-device
+    TcpComm harness, the CPU tests' gloo).  ``force``: also at world 1 (tests, bench.py's timing)."""
+    if comm.world == 1 and not force:
         return
-    for name in ("ID_prob", "GT_prob", "beta_mu", "beta_sum"):
-        setattr(model, name, comm.bcast(getattr(model, name), root))
+    if dm is not None and hasattr(comm, "bcast_model"):
+        comm.bcast_model(dm, root)
+        if comm.rank != root:
+            model._pull(dm, want_GT=True)
+    else:
+        for name in ("ID_prob", "GT_prob", "beta_mu", "beta_sum"):
+            setattr(model, name, comm.bcast(getattr(model, name), root))
     n = comm.bcast(np.array([float(len(model.ELBO_))]), root)
     trace = model.ELBO_ if comm.rank == root else np.zeros(int(n[0]))
     model.ELBO_ = comm.bcast(trace, root)
@@ -215,10 +228,10 @@ def _search(counts, plan, comm, max_iter_init, delay_fit_theta, kwargs, restarts
         LAST_SEARCH.update(restarts=len(local), restart_iterations=getattr(runner, "iterations", 0),
                            final_iterations=getattr(runner, "final_iterations", 0), best=best,
                            owner=owner, batch=batch)
+        with _phase("broadcast"):     # (before the runner goes: its device model is the broadcast's buffer)
+            _bcast_model(comm, model, owner, dm=getattr(runner, "dm", None))
     finally:
         runner.close()       # device models and staging buffers go now, not at garbage collection
-    with _phase("broadcast"):
-        _bcast_model(comm, model, owner)
     return model, elbo_all
 
 
