@@ -184,6 +184,39 @@ def test_config3_flag_paths(va, flag):
     assert np.array_equal(m.ID_prob.argmax(1), st.ID_prob.argmax(1))
 
 
+def test_four_times_config3_subset_parity(va):
+    """parity at a size the oracle cannot iterate -- N = 200k x M = 100k, K = 16, 4e8
+    entries (4x c3; tests/perf/big_probe.py runs the same check at 1.6e9 and 2.2e9 entries,
+    profiles/r06_big_probe_*.txt).  The whole protocol on the GPU (bitwise repeatable, planted donors
+    recovered), then ONE iteration from the fitted state against the oracle by the column-subset trick
+    (tests/subset_parity.py): theta against the oracle's whole-matrix sums, ``GT_prob`` on 2 000 variants
+    and ``logLik_ID`` / ``ID_prob`` on 2 000 cells, where the oracle on the sub-matrix is exact."""
+    from vireo_amd import synth
+    from vireo_amd.counts import DeviceCounts
+    from tests.subset_parity import one_iteration_subset_check
+    N, M, K = 200000, 100000, 16
+    w = synth.big_workload(N, M, K, 0.02, seed=0)
+    counts = DeviceCounts.from_merged(w["shape"], w["colptr"], w["rowidx"], w["ad"], w["dp"])
+
+    def fit():
+        np.random.seed(1)
+        m = va.Vireo(n_var=N, n_cell=M, n_donor=K)
+        m.fit(counts, None, min_iter=5, max_iter=20, delay_fit_theta=3, verbose=False)
+        return m
+
+    m, m2 = fit(), fit()
+    assert np.array_equal(m.ELBO_, m2.ELBO_) and np.array_equal(m.ID_prob, m2.ID_prob)
+    del m2
+    assert np.all(np.isfinite(m.ELBO_)) and len(m.ELBO_) >= 6
+    lab = m.ID_prob.argmax(1)
+    conf = np.zeros((K, K), int)
+    np.add.at(conf, (w["z"], lab), 1)
+    assert conf.max(1).sum() / M > 0.99
+    par = one_iteration_subset_check(m, counts, w, n_sub=2000)
+    print("4x c3 (nnz %d): %s" % (w["rowidx"].size, par))
+    counts.close()
+
+
 def test_config3_heavy_tailed_data(va):
     """c3's shape with log-normal coverage / depth (synth.C3_SKEW: what real cellSNP matrices look
     like, io_utils.py:42-59; the uniform SURVEY.md 8(d) generator is the kernels' best case): the

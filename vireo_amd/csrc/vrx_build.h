@@ -211,8 +211,8 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_build_pack(int64_t nnz, int fmt
 }
 
 // ---- tiled streams: segment of every (wave, slab, tile position), round lengths ------------------
-__global__ __launch_bounds__(VRX_BLOCK) void vrx_build_count(VrxTileArgs A, int32_t* __restrict__ seg_lo,
-                                                             int32_t* __restrict__ seg_hi,
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_build_count(VrxTileArgs A, uint32_t* __restrict__ seg_lo,
+                                                             uint32_t* __restrict__ seg_hi,
                                                              int32_t* __restrict__ rlen) {
     const int64_t t = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
     const int64_t total = A.n_wave * A.n_slab * A.RW;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_build_count(VrxTileArgs A, int3
         const int sl = (int)(ws % A.n_slab);
         const int64_t w = ws / A.n_slab;
         const int32_t v = A.rowmap[w * A.RW + pos];
-        int32_t lo = 0, hi = 0;
+        uint32_t lo = 0, hi = 0;  // (entry offsets: up to 2^32 - 1 entries per orientation)
         if (v >= 0) {
             const int32_t row = A.vrow_row[v];
             const int64_t r0 = A.ptr[row], r1 = A.ptr[row + 1];
@@ -232,8 +232,8 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_build_count(VrxTileArgs A, int3
             const int64_t end = vrx_lower_bound(A.idx, seg, r1, base + A.slab_rows);
             const int step = A.vptr[row + 1] - A.vptr[row];
             const int off = (int)(((int64_t)(v - A.vptr[row]) + sl) % step);
-            lo = (int32_t)(seg + off);
-            hi = (int32_t)end;
+            lo = (uint32_t)(seg + off);
+            hi = (uint32_t)end;
             for (int64_t e = seg + off; e < end; e += step) {
                 if (A.form == 0) {
                     ++n;
@@ -328,8 +328,8 @@ __device__ __forceinline__ void vrx_segment_words(const VrxTileArgs& A, int64_t 
     }
 }
 
-__global__ __launch_bounds__(VRX_BLOCK) void vrx_build_fill(VrxTileArgs A, const int32_t* __restrict__ seg_lo,
-                                                            const int32_t* __restrict__ seg_hi,
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_build_fill(VrxTileArgs A, const uint32_t* __restrict__ seg_lo,
+                                                            const uint32_t* __restrict__ seg_hi,
                                                             const int32_t* __restrict__ rlen,
                                                             const int32_t* __restrict__ bnd,
                                                             const int64_t* __restrict__ wave_start,

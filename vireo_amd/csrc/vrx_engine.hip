@@ -527,7 +527,9 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
         }
     };
     if (dev) {  // ---- the stream is built on the device --------------------------------------
-        DevBuf<int32_t> d_rowmap, d_vptr, d_vrow, seg_lo, seg_hi, rlen, d_too;
+        DevBuf<int32_t> d_rowmap, d_vptr, d_vrow, rlen, d_too;
+        DevBuf<uint32_t> seg_lo, seg_hi;  // entry offsets (< 2^32: device_build's limit)
+        VRX_REQUIRE(o_nnz < (int64_t)UINT32_MAX, "tiled stream: more than 2^32 - 1 entries");
         VRX_HIP(d_rowmap.upload(rowmap.data(), rowmap.size(), s));
         VRX_HIP(d_vptr.upload(vptr.data(), vptr.size(), s));
         VRX_HIP(d_vrow.upload(vrow_row.data(), vrow_row.size(), s));
@@ -846,7 +848,11 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
     *built = false;
     const int64_t nnz = p->nnz, n_var = p->n_var, n_cell = p->n_cell;
     hipStream_t s = p->stream;
-    if (nnz <= 0 || nnz >= INT32_MAX) return VRX_OK;
+    // Entry ids travel through the transposition as 32-bit sort values and the tiled builder keeps
+    // segment bounds as 32-bit entry offsets: up to 2^32 - 1 entries (r6: was 2^31 - 1, and the slow
+    // host builder took over without a word; 2.2e9 entries are built here in seconds,
+    // profiles/r06_big_probe_*.txt).  Beyond that the host builder below is the path.
+    if (nnz <= 0 || nnz >= (int64_t)UINT32_MAX - 4096) return VRX_OK;
     for (int64_t c = 0; c < n_cell; ++c)
         if (colptr[c + 1] < colptr[c]) {
             vrx_set_error("vrx_problem_create: colptr not monotone at column %lld", (long long)c);
@@ -905,11 +911,11 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
     {
         size_t tmp_bytes = 0;
         VRX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in.p, keys_out.p, vals_in.p,
-                                                   vals_out.p, (int)nnz, 0, bits, s));
+                                                   vals_out.p, (size_t)nnz, 0, bits, s));
         DevBuf<char> tmp;
         VRX_HIP(tmp.alloc(tmp_bytes));
         VRX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, keys_in.p, keys_out.p, vals_in.p,
-                                                   vals_out.p, (int)nnz, 0, bits, s));
+                                                   vals_out.p, (size_t)nnz, 0, bits, s));
         VRX_HIP(hipStreamSynchronize(s));
     }
     keys_in.release();

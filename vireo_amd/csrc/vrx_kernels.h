@@ -1066,6 +1066,12 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
                     const int slice = kl * NQ + (q + g) % NQ;  // 16-B slice of the dense row
                     if (FORM == 1) {  // columns 2*slice, 2*slice + 1 of logLik_ID
                         double* o = dst + row * ld + 2 * slice;
+#ifdef VRX_PROBE_WT_PARTIALS  // TIMING PROBE ONLY (scratch builds): the partial planes written through
+                        if (!PADK) {  //  to memory (sc0 sc1), as a cross-XCD fold inside the pass would need
+                            const vrx_d2 v2 = {acc[r][q][0], acc[r][q][1]};
+                            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(o), "v"(v2) : "memory");
+                        } else
+#endif
                         if (!PADK)
                             *reinterpret_cast<double2*>(o) = make_double2(acc[r][q][0], acc[r][q][1]);
                         else if (PADK == 2) {  // even K and stride: the pair is whole or absent
@@ -1598,7 +1604,11 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_theta_partial(
                 const int np = vptr ? vptr[vr + 1] - (int)v : 1;
                 double t = 0.0;
                 if (np == 1) {
+#ifdef VRX_PROBE_ONE_PLANE  // TIMING PROBE ONLY (scratch builds): as if the pass had left ONE plane per tile
+                    const int nr = 1;
+#else
                     const int nr = npiece[v];
+#endif
                     const double* src = P + v * B.Kt + col;
                     for (int r0 = 0; r0 < nr; r0 += 8) {
                         double x[8];
@@ -2083,7 +2093,11 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_cell_softmax(
     const int np = live && npiece ? (vptr ? vptr[cell + 1] - (int)pv0 : 1) : 0;
     const int64_t col0 = (int64_t)rb * K;
     if (np == 1) {
+#ifdef VRX_PROBE_ONE_PLANE  // TIMING PROBE ONLY (scratch builds)
+        const int n_range = 1;
+#else
         const int n_range = npiece[pv0];
+#endif
         for (int k = kl; k < K; k += KP) {
             // the loads of 8 ranges are issued together (one memory round trip instead of 8);
             // the additions keep the range order

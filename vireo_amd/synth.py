@@ -96,6 +96,56 @@ def planted_gt_prior(GT, sharp):
     return P
 
 
+def big_workload(N, M, K, density, seed=0, threads=32, block_cols=2048):
+    """The 8(d) donor model at sizes where its generator's global sort is the bottleneck (16x c3 and
+    beyond: 1.6e9 ... 2.2e9 entries): the same planted structure (genotype classes GT, donors z,
+    theta = 0.01 / 0.5 / 0.99, dp = 1 + Poisson(1), ad ~ Binomial(dp, theta)) on a Bernoulli(density)
+    pattern drawn column block by column block as geometric GAPS -- positions come out sorted and
+    distinct, so there is nothing to sort or merge -- on several threads (NumPy's generators release
+    the GIL).  NOT the 8(d) generator (its pattern has duplicate draws summed): a size probe, used by
+    tests/perf/big_probe.py and the big-problem test.  -> the dict of ``donor_workload`` (int32
+    rowidx / ad / dp, int64 colptr, GT, z)."""
+    from concurrent.futures import ThreadPoolExecutor
+    root = np.random.default_rng(seed)
+    GT = root.integers(0, 3, (N, K)).astype(np.int8)
+    z = root.integers(0, K, M).astype(np.int32)
+    tv = np.array([0.01, 0.5, 0.99])
+    blocks = [(c0, min(M, c0 + block_cols)) for c0 in range(0, M, block_cols)]
+    seeds = np.random.SeedSequence(seed + 1).spawn(len(blocks))
+
+    def one(i):
+        c0, c1 = blocks[i]
+        rng = np.random.default_rng(seeds[i])
+        L = (c1 - c0) * N                                  # slots of this block, column-major
+        pos = np.zeros(0, dtype=np.int64)
+        at = -1
+        while at < L:                                      # (one round almost always)
+            g = rng.geometric(density, size=int((L - max(at, 0)) * density * 1.02) + 4096)
+            q = at + np.cumsum(g)
+            at = int(q[-1])
+            pos = np.concatenate([pos, q])
+        pos = pos[pos < L]
+        col = pos // N
+        row = (pos - col * N).astype(np.int32)
+        dp = (1 + rng.poisson(1.0, pos.size)).astype(np.int32)
+        th = tv[GT[row, z[c0 + col]]]
+        ad = rng.binomial(dp, th).astype(np.int32)
+        cnt = np.bincount(col, minlength=c1 - c0)
+        return row, ad, dp, cnt
+
+    with ThreadPoolExecutor(max(1, threads)) as ex:
+        parts = list(ex.map(one, range(len(blocks))))
+    colptr = np.zeros(M + 1, dtype=np.int64)
+    np.cumsum(np.concatenate([p[3] for p in parts]), out=colptr[1:])
+    nnz = int(colptr[-1])
+    rowidx, ad, dp = (np.empty(nnz, dtype=np.int32) for _ in range(3))
+    at = 0
+    for row, a, d, _ in parts:
+        rowidx[at:at + row.size], ad[at:at + row.size], dp[at:at + row.size] = row, a, d
+        at += row.size
+    return dict(shape=(N, M), colptr=colptr, rowidx=rowidx, ad=ad, dp=dp, GT=GT.astype(np.int64), z=z.astype(np.int64))
+
+
 def as_scipy(w):
     """(AD, DP) int64 CSC like scipy's coo->csc of the generator (AD's zeros dropped)."""
     DP = csc_matrix((w["dp"].astype(np.int64), w["rowidx"], w["colptr"]), shape=w["shape"])
