@@ -607,7 +607,7 @@ def main():
     # LAST thing the chip does before the warm-up is 20 (rank 0, N = 1: 2 x 20) iterations of
     # this very workload with no host work in between: on this part a 5-ms pause (one 45-MB
     # upload) is enough for the clocks to drop, and the next ~15 ms then run ~10 % slow
-    # (scratch/gap_probe.py).
+    # (scratch/gap_probe.py, DESIGN_HISTORY.md section 6).
     fit_args = (PROTOCOL["max_iter"], PROTOCOL["min_iter"], 1e-2, PROTOCOL["delay_fit_theta"])
     proto_dm, _ = host._device_model(counts, None)
     pert_dm = None

@@ -540,7 +540,7 @@ constexpr int VRX_LDS_U = VRX_LDS_U_DEF;    // entries per trip and group; rows 
 // padded to its own longest row.  ~22 % more slots than the (ad, dp) pair words, but 7 instead of
 // ~15 vector instructions per slot, no conversions, and counts of any size.
 // Probe hooks: the product build defines them away.  A scratch build with -DVRX_PROBE_BUILD includes
-// scratch/vrx_probe.h, which times the bracketed statements with s_memtime.
+// scratch/vrx_probe.h, which times the bracketed statements with s_memtime (DESIGN_HISTORY.md 4.2).
 #ifdef VRX_PROBE_BUILD
 #include "../../scratch/vrx_probe.h"
 #else
@@ -881,7 +881,7 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
                     }
                     if constexpr (NQ == 1) {
                         // EXPERIMENT BUILDS ONLY (-DVRX_LDS_LPE_DEF=8: rounds of 8 rows, 8 lanes and 2
-                        // columns each): one 16-B slice per word and lane
+                        // columns each, DESIGN_HISTORY.md 4.2 r4): one 16-B slice per word and lane
                         vrx_d2 y[NE];
                         if (NE == 4) asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[NE - 1]));
                         if (NE == 3) asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[NE - 1]));
@@ -1160,7 +1160,7 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_sum_pieces_wave(
 // the consumer reads ONE value for the row.  A typical split row has 2-3 pieces x <= 3 slots
 // (one load per lane), the longest ~100 terms.  (Measured at c3 size, dense kernels per iteration:
 // the consumers' own per-thread loop over the terms 0.20 ms; one wavefront per element 0.27 ms --
-// 400 k waves of a few dependent loads each; this form: see DESIGN.md 4.2.)
+// 400 k waves of a few dependent loads each; this form: see DESIGN_HISTORY.md 4.2.)
 // Two properties a caller must know:
 //  * ORDER.  The terms are added strided over 8 lanes and then by a butterfly; the consumers that
 //    form S / logLik_ID explicitly (vrx_s_from_virtual, vrx_sum_pieces: the step-wise API,

@@ -75,7 +75,7 @@ def restart_batch(n_donor, n_owned, nnz, wide=True):
 
     A sweep of the entry stream computes 16 columns whatever n_donor is; restarts packed side by
     side fill whole sweeps.  Cost of a restart-iteration in sweeps, from the measurements in
-    DESIGN.md section 4.4: ceil(R * n_donor / 16) sweeps -- 1.25x each when the column count is odd
+    DESIGN_HISTORY.md section 4.4: ceil(R * n_donor / 16) sweeps -- 1.25x each when the column count is odd
     (element-wise staging of the dense operand) -- divided by R, plus 10 % for a batch running
     until its slowest restart has stopped.  The smallest R within 5 % of the best wins
     (n_donor = 16: 1; 12: 4; 8: 2; 5: 6; 4: 4).  ``wide`` = False (pair-word streams, whose
