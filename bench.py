@@ -413,6 +413,18 @@ def c5_gpu_leg(device, steps=50):
                algorithmic_bytes_per_iteration=bytes_it,
                roofline_frac=bytes_it / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS,
                kernel_info=info)
+    # VERDICT r5 (weak 7): the fraction above is on SURVEY.md 8(d)'s 12 B per entry and orientation; this
+    # path stores ONE 4-B pair word per entry, so the bytes it really moves are far fewer -- say so
+    tpath = os.path.join(ROOT, "profiles", "traffic_c5.json")
+    if os.path.exists(tpath):
+        doc = json.load(open(tpath))
+        if doc.get("kernel_source_hash") == kernel_source_hash():
+            moved = sum(k["traffic_bytes"] for k in doc["kernels"].values())
+            out["passes_measured_traffic"] = dict(
+                bytes_per_iteration=moved, source="profiles/traffic_c5.json (rocprofv3 --pmc, same kernel sources)",
+                passes_GBs_on_measured_traffic=moved / ((out["passes_ms"]["variant_pass"] + out["passes_ms"]["cell_pass"]) * 1e-3) / 1e9,
+                note="the roofline_frac above is on the 8(d) algorithmic bytes (12 B per entry and orientation); the pair-word "
+                     "stream is 4 B per entry, so the passes move this much and are bound on-chip like c3's")
     return out, (AD, DP, first)
 
 
