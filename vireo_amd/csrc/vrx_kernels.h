@@ -839,17 +839,23 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
     int bvec = bw[(int64_t)s_lo * NRV + min(lane, NRV)];
     slab_fetch(s_lo);
     for (int s = s_lo; s < s_hi; ++s) {
+#ifndef VRX_PROBE_NOBAR    // TIMING PROBES ONLY (scratch builds): barriers / slab staging compiled out (racy, wrong results)
         VRX_PROBE(tm_bar1, __syncthreads())  // every wave is done reading the previous slab
+#endif
+#ifndef VRX_PROBE_NOSTAGE
         VRX_PROBE(tm_stage, slab_store())
         if (s + 1 < s_hi) {  // (with the bnd load below: NPF vector loads)
             slab_fetch(s + 1);
             since_fetch = 0;
         }
+#endif
         int bcur[NRV + 1];  // (scalar registers: read from the lanes before the vector is reused)
 #pragma unroll
         for (int i = 0; i <= NRV; ++i) bcur[i] = __builtin_amdgcn_readlane(bvec, i);
         if (s + 1 < s_hi) bvec = bw[(int64_t)(s + 1) * NRV + min(lane, NRV)];
+#ifndef VRX_PROBE_NOBAR
         VRX_PROBE(tm_bar2, __syncthreads())
+#endif
 #pragma unroll
         for (int rv = 0; rv < NRV; ++rv) {
             const int r = rv / PH;
@@ -872,9 +878,17 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
                     uint32_t w[NE];
                     VRX_PROBE_TRIP
                     {
+#ifndef VRX_PROBE_NODMA   // TIMING PROBE ONLY (scratch builds): the stream's LDS-DMA and its waits compiled out
                         if (at >= ring_evt) VRX_PROBE(tm_dma, ring_event())
+#endif
                         // the group's U words are adjacent (padding words fill a short last trip)
+#ifdef VRX_PROBE_NORING   // TIMING PROBE ONLY: no ring read -- every word is the slab's first half row, value 0
+                        uint32_t pw = (uint32_t)VRX_LDS_WAVES * VRX_RING * 4u + ((uint32_t)at & 0x380u);
+                        asm volatile("" : "+v"(pw));
+                        const uint4 q4 = make_uint4(pw, pw ^ 128u, pw, pw ^ 128u);
+#else
                         const uint4 q4 = *reinterpret_cast<const uint4*>(ring + (at & (VRX_RING - 1)) + g * U);
+#endif
                         const uint32_t qq[4] = {q4.x, q4.y, q4.z, q4.w};
 #pragma unroll
                         for (int u = 0; u < NE; ++u) w[u] = qq[u];
