@@ -679,7 +679,10 @@ def main():
     prof_runs.sort(key=lambda r: r[0][_lib.KERN_VARIANT_PASS] + r[0][_lib.KERN_CELL_PASS])
     ms, n = prof_runs[1]
     kinfo = dm.info()
-    comm_rec = side_leg("comm", comm_leg, comm, local, dm, host)      # (collective: every rank)
+    # (collective: every rank.  At N > 1 an exception in it is NOT swallowed like a side leg's: a rank
+    #  that stayed alive after a failed collective would leave the others waiting for it -- it exits,
+    #  the launcher stops the rest, the reason is on stderr)
+    comm_rec = comm_leg(comm, local, dm, host) if world > 1 else side_leg("comm", comm_leg, comm, local, dm, host)
     dm.close()
     if parity_gpu is None:
         proto_dm.close()
