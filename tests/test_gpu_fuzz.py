@@ -152,22 +152,26 @@ def _held_by_arbiter(name, gpu, orc, exact):
     return e_gpu.max(), e_orc.max()
 
 
-# Round 6: all 199 misses of the three sweeps (seeds 48 .. 7999) have been in front of the arbiter
-# (profiles/r06_fuzz_deviation_class_199.txt): the device is the closer one in 199 of 199, and in 18 of
+# Round 6: all 241 misses of the four sweeps (seeds 48 .. 9999, 9 952 cases) have been in front of the arbiter
+# (profiles/r06_fuzz_deviation_class.txt): the device is the closer one in 241 of 241, and in 23 of
 # them -- all clone mode -- the device ITSELF is beyond 1e-5 from exact.  "Closer than the reference" is
-# not "within tolerance", so those 18 are all in the suite with the device's measured distance from
+# not "within tolerance", so those 23 are all in the suite with the device's measured distance from
 # exact pinned as an upper bound (measured value x 1.25: the kernels are deterministic, the margin
 # covers a different VIREO_LDS_BLOCKS draw only).
 DEVICE_BEYOND_RTOL = {563: 3.64e-5, 1263: 5.04e-5, 2907: 2.69e-5, 1583: 1.4e-5, 1919: 3.7e-5, 2547: 1.5e-5,
                       2615: 1.8e-5, 2967: 1.3e-5, 3811: 2.7e-5, 4691: 5.7e-5, 4895: 1.8e-5, 6887: 1.1e-5,
-                      7179: 1.9e-5, 7383: 2.5e-5, 7583: 1.9e-5, 7695: 1.5e-5, 7867: 2.3e-5, 7911: 1.2e-5}
+                      7179: 1.9e-5, 7383: 2.5e-5, 7583: 1.9e-5, 7695: 1.5e-5, 7867: 2.3e-5, 7911: 1.2e-5,
+                      # (the regression sweep of the round's final build, seeds 8000 .. 9999: 42 more misses,
+                      #  the device closer in 42, beyond 1e-5 itself in these five)
+                      8767: 1.1e-5, 9107: 1.1e-5, 9215: 1.7e-5, 9327: 2.1e-5, 9503: 2.0e-5}
 
 
 @pytest.mark.parametrize("seed", [75, 155, 171, 211, 239, 343, 367, 463, 563, 595, 611, 643, 695, 719,
                                   755, 803, 811, 855, 887, 895, 951, 987,
                                   1003, 1263, 2907,       # (the worst three of the second sweep, 1000 .. 2999)
                                   1583, 1919, 2547, 2615, 2967, 3811, 4691, 4895, 6887, 7179, 7383, 7583,
-                                  7695, 7867, 7911])      # (round 6: the device itself beyond 1e-5 from exact)
+                                  7695, 7867, 7911,       # (round 6: the device itself beyond 1e-5 from exact)
+                                  8767, 9107, 9215, 9327, 9503])
 def test_known_deviation_cases_vs_arbiter_clone_mode(va, monkeypatch, seed):
     from vireo_amd.counts import DeviceCounts      # noqa: F401
     g = _arbiter()

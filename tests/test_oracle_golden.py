@@ -179,7 +179,7 @@ def test_fuzz_arbiter_fixture_is_the_oracles_problem():
     relative away from the exact ones (the deviation class the GPU tests pin)."""
     from tests.test_gpu_fuzz import draw_case
     g = gold.load("fuzz_arbiter")
-    assert len(g["bmm_seeds"]) == 40 and list(g["vireo_seeds"]) == [537, 1648, 2260]
+    assert len(g["bmm_seeds"]) == 45 and list(g["vireo_seeds"]) == [537, 1648, 2260]
     for seed, lo, hi in ((343, 5e-6, 5e-5), (695, 4e-5, 2e-4), (2547, 3e-5, 1.3e-4)):     # (2547: one of round 6's fifteen)
         AD, DP, K, _ = draw_case(seed)
         N, M = AD.shape
