@@ -210,6 +210,42 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_build_pack(int64_t nnz, int fmt
     }
 }
 
+// ---- balanced slabs: relabel the contracted indices of every row by its tile's permutation -------
+// key[e] = row << 32 | posmap[tile_of_row[row]][idx[e]]  (row by binary search in ptr), val[e] = e
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_build_relabel(int64_t nnz, int64_t n_rows, int64_t n_contract,
+                                                               const int64_t* __restrict__ ptr,
+                                                               const int32_t* __restrict__ idx,
+                                                               const int32_t* __restrict__ tile_of_row,
+                                                               const int32_t* __restrict__ posmap,
+                                                               uint64_t* __restrict__ keys,
+                                                               uint32_t* __restrict__ vals) {
+    const int64_t e = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    if (e >= nnz) return;
+    int64_t lo = 0, hi = n_rows;  // the last row with ptr[row] <= e
+    while (lo < hi) {
+        const int64_t mid = (lo + hi + 1) >> 1;
+        if (ptr[mid] <= e)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const int32_t t = tile_of_row[lo];
+    const uint32_t pos = t >= 0 ? (uint32_t)posmap[(int64_t)t * n_contract + idx[e]] : (uint32_t)idx[e];
+    keys[e] = ((uint64_t)lo << 32) | pos;
+    vals[e] = (uint32_t)e;
+}
+
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_build_relabel_gather(int64_t nnz, const uint64_t* __restrict__ keys,
+                                                                      const uint32_t* __restrict__ perm,
+                                                                      const int2* __restrict__ val,
+                                                                      int32_t* __restrict__ idx2,
+                                                                      int2* __restrict__ val2) {
+    const int64_t q = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    if (q >= nnz) return;
+    idx2[q] = (int32_t)(keys[q] & 0xffffffffu);
+    val2[q] = val[perm[q]];
+}
+
 // ---- tiled streams: segment of every (wave, slab, tile position), round lengths ------------------
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_build_count(VrxTileArgs A, uint32_t* __restrict__ seg_lo,
                                                              uint32_t* __restrict__ seg_hi,

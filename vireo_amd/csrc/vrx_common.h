@@ -100,6 +100,12 @@ struct TiledStream {
     DevBuf<int64_t> wave_start;
     DevBuf<int32_t> bnd;
     DevBuf<int32_t> rowmap;   // tile position -> piece (-1 = padding), pieces sorted by length
+    // Balanced slabs (r6): which contracted rows share a slab is chosen PER TILE so that the rows of the
+    // tile carry about the same number of words in every slab (the lock-step padding of a round is the
+    // maximum over its 16 rows).  perm[tile][slab * slab_rows + p] = contracted row staged at slab-local
+    // position p (unused positions name row 0); the stream's indices are positions.  Empty: slabs are consecutive rows.
+    DevBuf<int32_t> perm;
+    bool balanced = false;
     DevBuf<int32_t> vptr;     // row -> its pieces [vptr[r], vptr[r+1]) (only when split)
     DevBuf<int32_t> split_rows;  // the rows with more than one piece (vrx_fold_split)
     int64_t n_split = 0;

@@ -560,7 +560,10 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
     const int32_t* __restrict__ bnd, const int32_t* __restrict__ rowmap,
     const int32_t* __restrict__ items, const int32_t* __restrict__ wg_first, int n_slab,
     int slab_rows, int64_t n_contract, int64_t n_rows, const double* __restrict__ X, int K,
-    int ld, double* __restrict__ out, const int32_t* __restrict__ ctl, int n_batch) {
+    int ld, double* __restrict__ out, const int32_t* __restrict__ ctl, int n_batch,
+    const int32_t* __restrict__ perm) {
+    // perm != null (balanced slabs, TiledStream::perm; flat AD/BD instances only): slab s of tile t
+    // holds the contracted rows perm[(t * n_slab + s) * slab_rows + p], p = its slab-local position
     if (vrx_all_stopped(ctl, n_batch)) return;
     // K <= 16 columns of this launch; ld = columns per row of X and out (ld > K: one block of a
     // wider operand, always with PADK = true: the flat slab copy needs contiguous rows)
@@ -582,7 +585,10 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
     // rows / columns they fill are never referenced by a word resp. never stored), so the walk
     // can leave the prefetch in flight while it waits for a chunk of its stream
     constexpr bool PRECISE = FORM != 0 && VRX_LDS_PRECISE;
-    constexpr int NPF = (PADK == 1 ? 2 : 1) * PF + 1;  // (element-wise: 2 loads per unit) + the bnd words of the next slab
+    // (element-wise: 2 loads per unit) + the bnd words of the next slab (+ flat AD/BD instances: the rows the
+    //  wave stages for the slab behind it, TiledStream::perm -- issued whether or not the stream is balanced)
+    constexpr bool GATHER = PADK == 0 && PRECISE;
+    constexpr int NPF = (PADK == 1 ? 2 : 1) * PF + 1 + (GATHER ? 1 : 0);
     extern __shared__ __attribute__((aligned(16))) char vrx_smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (wave-uniform: scalar)
@@ -637,10 +643,27 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
     const int padT = NT / upr * upr, j0 = threadIdx.x % upr, r0 = threadIdx.x / upr;
     const int rstep = padT / upr;
     const bool pad_act = (int)threadIdx.x < padT;
-    auto slab_fetch = [&](int s) {
+    auto slab_fetch = [&](int s, int rvec) {
         const int64_t row0 = (int64_t)s * slab_rows;
         const int64_t rows = min((int64_t)slab_rows, n_contract - row0);
-        if (!PADK) {  // rows are contiguous 16-B units: flat copy
+        if (GATHER && perm) {
+            // balanced slabs: a wave's load i covers the four slab-local rows 4 * wave + 64 i + 0..3; their
+            // contracted rows sit in lanes 32 + 4 i + 0..3 of the vector rows_load fetched a slab ahead
+            const vrx_d2* src = reinterpret_cast<const vrx_d2*>(X);
+            int tid_f = threadIdx.x;
+            asm volatile("" : "+v"(tid_f));
+            const int upr_g = K * XD / 2;  // 16-B units per contracted row (16)
+            const int sel = (32 + ((tid_f & 63) >> 4)) << 2, u15 = tid_f & 15;
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                // (the list holds a valid row at every position: unused ones name row 0)
+                const int rowg = __builtin_amdgcn_ds_bpermute(sel + 16 * i, rvec);
+                pf[i] = src[(uint32_t)(rowg * upr_g + u15)];
+                // two loads' address temporaries at a time: hoisted together they would cost the walk
+                // registers it has not got
+                if (i & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if (!PADK) {  // rows are contiguous 16-B units: flat copy
             const int n16 = (int)(rows * K * XD / 2);
             const vrx_d2* src = reinterpret_cast<const vrx_d2*>(X + row0 * K * XD);
             // (offsets formed again for every slab from an opaque copy of the thread index: hoisted
@@ -836,23 +859,56 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
     // bnd words of a slab: stream offset (a multiple of U*G) | entries in the round's last trip
     // (0 = a full trip) for each (round, phase), then the first word of the next slab: lane i
     // holds word i, ONE vector load a slab ahead (it is part of the prefetch the walk counts)
-    int bvec = bw[(int64_t)s_lo * NRV + min(lane, NRV)];
-    slab_fetch(s_lo);
+    // the record of a slab: lanes 0 .. NRV its bnd words; balanced slabs: lanes 32 .. 63 the contracted rows
+    // this wave stages for the slab BEHIND it (they are needed a slab earlier, by the prefetch)
+    // (scalar bases + 32-bit lane offsets formed from an opaque copy of the lane index: per-lane 64-bit
+    //  pointers kept across the walk would cost registers it has not got)
+    auto bnd_load = [&](int s_b) {
+        int lane_o = threadIdx.x & 63;
+        asm volatile("" : "+v"(lane_o));
+        const int32_t* a = bw + (int64_t)s_b * NRV;
+        return a[(uint32_t)min(lane_o, NRV)];
+    };
+    // balanced slabs: lane 32 + 4 i + q holds the contracted row of slab-local row 4 * wave + 64 i + q of slab
+    // s_p -- the 32 rows this wave stages.  A load of its own (loaded a slab before the prefetch that uses it,
+    // pending until then like the bnd words); issued whether or not the stream is balanced: the number of
+    // loads in flight behind a slab prefetch is one constant (NPF)
+    auto rows_load = [&](int s_p) {
+        int lane_o = threadIdx.x & 63;
+        asm volatile("" : "+v"(lane_o));
+        const int32_t* b = perm ? perm + ((int64_t)tile * n_slab + min(s_p, n_slab - 1)) * slab_rows : bw;
+        const int j = max(lane_o - 32, 0);
+        const int pos = perm ? min(4 * wave + 64 * (j >> 2) + (j & 3), slab_rows - 1) : 0;
+        return b[(uint32_t)pos];
+    };
+    int bvec = bnd_load(s_lo);
+    int rvec = 0;
+    if (GATHER) rvec = rows_load(s_lo);
+    slab_fetch(s_lo, rvec);
+    if (GATHER) rvec = rows_load(s_lo + 1);
     for (int s = s_lo; s < s_hi; ++s) {
 #ifndef VRX_PROBE_NOBAR    // TIMING PROBES ONLY (scratch builds): barriers / slab staging compiled out (racy, wrong results)
         VRX_PROBE(tm_bar1, __syncthreads())  // every wave is done reading the previous slab
 #endif
+        // The slab's bnd words go to scalar registers BEFORE the next slab's prefetch is issued: the
+        // compiler guards the readlanes with a full `s_waitcnt vmcnt(0)` (it cannot count across the loop),
+        // which up to round 5 sat BEHIND the prefetch and drained it on the spot -- one exposed memory round
+        // trip per visit, the 10-14 % a pass spent "staging" (profiles/r06_pass_structure_probes.txt).  Here
+        // it only meets loads of the previous visit, which landed long ago.
+        int bcur[NRV + 1];
+#pragma unroll
+        for (int i = 0; i <= NRV; ++i) bcur[i] = __builtin_amdgcn_readlane(bvec, i);
 #ifndef VRX_PROBE_NOSTAGE
         VRX_PROBE(tm_stage, slab_store())
-        if (s + 1 < s_hi) {  // (with the bnd load below: NPF vector loads)
-            slab_fetch(s + 1);
+        if (s + 1 < s_hi) {  // (with the two loads below: NPF vector loads)
+            slab_fetch(s + 1, rvec);
             since_fetch = 0;
         }
 #endif
-        int bcur[NRV + 1];  // (scalar registers: read from the lanes before the vector is reused)
-#pragma unroll
-        for (int i = 0; i <= NRV; ++i) bcur[i] = __builtin_amdgcn_readlane(bvec, i);
-        if (s + 1 < s_hi) bvec = bw[(int64_t)(s + 1) * NRV + min(lane, NRV)];
+        if (s + 1 < s_hi) {
+            bvec = bnd_load(s + 1);
+            if (GATHER) rvec = rows_load(s + 2);
+        }
 #ifndef VRX_PROBE_NOBAR
         VRX_PROBE(tm_bar2, __syncthreads())
 #endif
