@@ -571,10 +571,25 @@ def main():
     w = synth.donor_workload(N, M, K, dens, seed=0)
     t_gen = time.perf_counter() - t_gen
     nnz = int(w["rowidx"].size)
+    # The headline runs on BALANCED SLABS (vrx_problem_create2, VRX_PROBLEM_BALANCED: which contracted rows
+    # share a slab is chosen per row tile): a one-off effort at problem build, reported
+    # in `host_setup_s` / `config.stream`, that `vireo_wrap` asks for by itself from VIREO_BALANCE_MIN_ITERS
+    # expected iterations on.  The c4 leg below runs on the stream `vireo_wrap`'s own policy picks for its job
+    # (n_init = 32: the default build), and `unbalanced_stream` times the headline's iterations on that one too.
+    from vireo_amd.counts import balance_policy
     t_up = time.perf_counter()
     counts = DeviceCounts.from_merged(w["shape"], w["colptr"], w["rowidx"], w["ad"], w["dp"],
-                                      device=local)
+                                      device=local, balance=os.environ.get("VIREO_BALANCE", "1") != "0")
     t_up = time.perf_counter() - t_up
+    binfo = counts.build_info()
+    c4_iters = -(-32 // world) * 20 + 200
+    counts_job, t_up_default = counts, None
+    if (binfo["balanced_cell"] or binfo["balanced_variant"]) and not balance_policy(None, c4_iters) \
+            and args.config == "c3" and not (args.no_c4 and args.no_side_legs):
+        t_up_default = time.perf_counter()
+        counts_job = DeviceCounts.from_merged(w["shape"], w["colptr"], w["rowidx"], w["ad"], w["dp"],
+                                              device=local, balance=False)
+        t_up_default = time.perf_counter() - t_up_default
 
     # ---- GPU legs that the run executes anyway, BEFORE the timed region ---------------------
     # (the timed K iterations used to open on a chip that had idled through ~20 s of
@@ -603,10 +618,12 @@ def main():
     # (the timed model is resident before the c4 leg: at N > 1, where no parity fits follow, only
     #  the tail of that leg -- the winner's download / broadcast -- separates its fits from the warm-up)
     if not args.no_c4 and args.config == "c3":
-        c4, c4_rv = c4_leg(counts, K, comm)
+        c4, c4_rv = c4_leg(counts_job, K, comm)
+        c4["stream"] = "balanced slabs" if counts_job is counts and binfo["balanced_cell"] else \
+            "default build (what vireo_wrap's policy picks for %d expected iterations)" % c4_iters
         preceded_by.append("c4 leg (vireo_wrap n_init=32 on the same data: ~0.6 s of fits)")
         if solo and not args.no_side_legs:
-            c4["doublet"] = side_leg("doublet", doublet_leg, counts, K, c4_rv)
+            c4["doublet"] = side_leg("doublet", doublet_leg, counts_job, K, c4_rv)
             c4["doublet_s"] = c4["doublet"].get("doublet_s")
             preceded_by.append("doublet step on the c4 winner (3 x predict_doublet, 136 columns)")
         del c4_rv
@@ -686,6 +703,31 @@ def main():
     dm.close()
     if parity_gpu is None:
         proto_dm.close()
+
+    unbalanced = None
+    if solo and counts_job is not counts:
+        def _unbalanced():
+            np.random.seed(1)
+            h = Vireo(n_var=N, n_cell=M, n_donor=K)
+            d2, _ = h._device_model(counts_job, None)
+            d2.run_iters(20, theta_from_iter=PROTOCOL["delay_fit_theta"])
+            t0 = time.perf_counter()
+            d2.run_iters(100, theta_from_iter=0)
+            ms_it = (time.perf_counter() - t0) / 100 * 1e3
+            d2.profile(True)
+            d2.run_iters(50, theta_from_iter=0)
+            pm, pn = d2.profile_read()
+            i2 = d2.info()
+            d2.close()
+            gain_ms = ms_it - float(np.median(repeats))
+            return dict(ms_per_iteration=ms_it, iterations_per_s=1e3 / ms_it,
+                        passes_ms={"variant_pass": pm[0] / max(pn[0], 1), "cell_pass": pm[1] / max(pn[1], 1),
+                                   "dense_kernels": pm[2] / 50},
+                        pad_variant=i2["pad_variant"], pad_cell=i2["pad_cell"], build_s=round(t_up_default, 3),
+                        balanced_build_s=round(t_up, 3), balancing_added_s=round(binfo["balance_seconds"], 3),
+                        break_even_iterations=int(binfo["balance_seconds"] / max(gain_ms, 1e-6) * 1e3) if gain_ms > 0 else None,
+                        note="the same iterations on the default build of the same problem: 100 after 20")
+        unbalanced = side_leg("unbalanced_stream", _unbalanced)
 
     c3_skew = None
     if solo and not args.no_side_legs and args.config == "c3":
@@ -810,7 +852,10 @@ def main():
                        "restart_elbos": [float(x) for x in np.ravel(last_elbos)],
                        "best_restart": int(np.argmax(last_elbos)),
                        "restart_protocol_elbos": [float(x) for x in np.ravel(proto_elbos)],
-                       "host_setup_s": {"generate": round(t_gen, 1), "upload+transpose": round(t_up, 1)}},
+                       "stream": ("balanced slabs (per-tile choice of the contracted rows of a slab; +%.2f s at problem "
+                                  "build)" % binfo["balance_seconds"]) if binfo["balanced_cell"] else "default build",
+                       "build_info": binfo,
+                       "host_setup_s": {"generate": round(t_gen, 1), "upload+transpose": round(t_up, 2)}},
             "roofline": {"bound": "hbm",
                          "kernel": "%s (%s pass)" % (
                              "vrx_spmm_lds<MODE %d, FORM %d>" % (dom == "cell", kinfo["cell_form"] if dom == "cell" else kinfo["var_form"])
@@ -849,6 +894,7 @@ def main():
             "c4": c4,
             "c2": c2,
             "c5": c5,
+            "unbalanced_stream": unbalanced,
             "c3_skew": c3_skew,
             "c3_flags": c3_flags,
             "e2e": e2e,

@@ -60,6 +60,21 @@ int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int64_t nnz,
                        const int32_t* csc_rowidx /* nnz */,
                        const int32_t* ad /* nnz */, const int32_t* dp /* nnz */,
                        vrx_problem** out);
+/* The same with build options.  VRX_PROBLEM_BALANCED: *balanced slabs* -- for problems that run the
+ * LDS-resident passes with AD/BD words and no split rows, the builder chooses PER ROW TILE which
+ * contracted rows share a slab so that every row of the tile carries about the same number of words in
+ * every slab (the passes execute a round of 16 rows at the pace of its longest row: 1.62 -> ~1.2 executed
+ * slots per word at c3, passes 10-17 % shorter).  Costs a one-off ~0.5 s at 1e8 entries, so it pays from a
+ * few thousand iterations on the same problem (vireo_wrap's restarts, vireo_wrap.py:64-94, all run on one);
+ * results differ from the unbalanced build's in summation order only (<= 1e-13 relative per update).
+ * The reference has no counterpart (SciPy's CSC / CSR are what they are). */
+#define VRX_PROBLEM_BALANCED 1
+int vrx_problem_create2(int device, int64_t n_var, int64_t n_cell, int64_t nnz,
+                        const int64_t* csc_colptr, const int32_t* csc_rowidx, const int32_t* ad,
+                        const int32_t* dp, int32_t flags, vrx_problem** out);
+/* info4 = { variant stream balanced (0 | 1), cell stream balanced, seconds the balancing added to the build,
+ * built on the device (0 | 1) } */
+int vrx_problem_build_info(vrx_problem* p, double* info4);
 void vrx_problem_destroy(vrx_problem* p);
 
 /* sum over entries with dp>0 of float32(min(log C(dp,ad), 700)), accumulated in float64.

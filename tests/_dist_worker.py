@@ -80,7 +80,7 @@ def main(rank, world, port, out_path, n_init=4):
 
     W.DeviceRestarts = OracleRestarts
     W.predict_doublet = fake_doublet
-    W.device_counts = lambda a, b=None: fake_counts
+    W.device_counts = lambda a, b=None, **kw: fake_counts
     import io
     import contextlib
     with contextlib.redirect_stdout(io.StringIO()):

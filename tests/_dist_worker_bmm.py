@@ -66,7 +66,7 @@ def main(rank, world, port, out_path, n_init):
 
     fake_counts = types.SimpleNamespace(shape=AD.shape, nnz=DP.nnz, binom_const=lambda: O.binom_const(AD, DP))
     B.DeviceModel = OracleModel
-    B.device_counts = lambda a, b=None: fake_counts
+    B.device_counts = lambda a, b=None, **kw: fake_counts
     B.restart_batch = lambda *a, **k: 1                     # one initialisation per (oracle) model
     b = vireo_amd.BinomMixtureVB(n_var=N, n_cell=M, n_donor=3)
     b.fit(AD, DP, min_iter=30, n_init=n_init, random_seed=1, verbose=False, comm=GlooComm())

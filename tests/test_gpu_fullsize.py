@@ -184,6 +184,51 @@ def test_config3_flag_paths(va, flag):
     assert np.array_equal(m.ID_prob.argmax(1), st.ID_prob.argmax(1))
 
 
+def test_config3_balanced_slabs(va):
+    """The headline configuration on BALANCED SLABS (what bench.py's headline runs on): both streams
+    balanced, a quarter fewer stream slots, the whole protocol bitwise repeatable, within summation-order
+    distance of the default build's (same iteration count, same assignments), planted donors recovered, and
+    ONE iteration from the fitted state against the oracle (theta on the whole matrix, GT / ID on 2 000
+    rows / columns: tests/subset_parity.py)."""
+    from vireo_amd import _lib, synth
+    from vireo_amd.counts import DeviceCounts
+    from vireo_amd.engine import DeviceModel
+    from tests.subset_parity import one_iteration_subset_check
+    N, M, K, dens = synth.CONFIGS["c3"]
+    w = synth.donor_workload(N, M, K, dens, seed=0)
+    cb = DeviceCounts.from_merged(w["shape"], w["colptr"], w["rowidx"], w["ad"], w["dp"], balance=True)
+    cd = DeviceCounts.from_merged(w["shape"], w["colptr"], w["rowidx"], w["ad"], w["dp"], balance=False)
+    ib = cb.build_info()
+    assert ib["balanced_variant"] and ib["balanced_cell"] and ib["device_built"]
+    kb, kd = DeviceModel(cb, _lib.KIND_VIREO, K).info(), DeviceModel(cd, _lib.KIND_VIREO, K).info()
+    print("c3 balanced slabs: +%.2f s at build; stream slots per non-zero %.3f / %.3f against %.3f / %.3f"
+          % (ib["balance_seconds"], kb["pad_variant"], kb["pad_cell"], kd["pad_variant"], kd["pad_cell"]))
+    assert kb["pad_cell"] < 0.85 * kd["pad_cell"] and kb["pad_variant"] < 0.85 * kd["pad_variant"]
+
+    def fit(counts):
+        np.random.seed(1)
+        m = va.Vireo(n_var=N, n_cell=M, n_donor=K)
+        m.fit(counts, None, min_iter=5, max_iter=20, delay_fit_theta=3, verbose=False)
+        return m
+
+    m, m2, d = fit(cb), fit(cb), fit(cd)
+    for name in ("ELBO_", "ID_prob", "GT_prob", "beta_mu", "beta_sum"):
+        assert np.array_equal(getattr(m, name), getattr(m2, name)), name
+    assert len(m.ELBO_) == len(d.ELBO_) and np.array_equal(m.ID_prob.argmax(1), d.ID_prob.argmax(1))
+    # (two summation orders of one unstable trajectory: like GPU against oracle, they part by ~1e-5 in the
+    #  middle of the trace and meet again at its end)
+    rel = np.abs(m.ELBO_ - d.ELBO_) / np.abs(d.ELBO_)
+    assert rel[:6].max() < 1e-9 and rel[-1] < 1e-7 and rel.max() < 5e-5, rel
+    lab = m.ID_prob.argmax(1)
+    conf = np.zeros((K, K), int)
+    np.add.at(conf, (w["z"], lab), 1)
+    assert conf.max(1).sum() / M > 0.99
+    par = one_iteration_subset_check(m, cb, w, n_sub=2000)
+    print("c3 balanced slabs, one iteration vs the oracle:", par)
+    cb.close()
+    cd.close()
+
+
 def test_four_times_config3_subset_parity(va):
     """parity at a size the oracle cannot iterate -- N = 200k x M = 100k, K = 16, 4e8
     entries (4x c3; tests/perf/big_probe.py runs the same check at 1.6e9 and 2.2e9 entries,
@@ -196,7 +241,8 @@ def test_four_times_config3_subset_parity(va):
     from tests.subset_parity import one_iteration_subset_check
     N, M, K = 200000, 100000, 16
     w = synth.big_workload(N, M, K, 0.02, seed=0)
-    counts = DeviceCounts.from_merged(w["shape"], w["colptr"], w["rowidx"], w["ad"], w["dp"])
+    counts = DeviceCounts.from_merged(w["shape"], w["colptr"], w["rowidx"], w["ad"], w["dp"], balance=True)
+    assert counts.build_info()["balanced_cell"] and counts.build_info()["balanced_variant"]
 
     def fit():
         np.random.seed(1)

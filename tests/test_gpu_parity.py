@@ -1178,3 +1178,69 @@ def test_elbo_riding_in_the_next_theta_kernel_changes_nothing(va, monkeypatch, c
                             m.beta_sum.tobytes()))
         out[ride] = res
     assert out["1"] == out["0"]
+
+
+def test_balanced_slabs_small_problem_vs_oracle_and_default_build(va, monkeypatch):
+    """Round 6: *balanced slabs* (vrx_problem_create2 + VRX_PROBLEM_BALANCED) -- which contracted rows share a
+    slab is chosen per row tile (host greedy), the entries are relabelled and re-sorted on the device, the
+    kernel stages a slab through the tile's list.  On a problem small enough for the oracle, with the device
+    builder and the LDS-resident passes forced and several slabs per orientation: both streams are
+    balanced, fewer stream slots than the default build, a whole fit within 1e-5 of the oracle (identical
+    iteration count and assignments), within summation-order distance of the default build, and the build
+    is deterministic (two builds: the same stream checksums; two fits: the same bits)."""
+    from vireo_amd.counts import DeviceCounts
+    from vireo_amd.engine import DeviceModel
+    from vireo_amd import _lib
+    monkeypatch.setenv("VIREO_LDS", "1")
+    monkeypatch.setenv("VIREO_BUILD", "device")
+    monkeypatch.setenv("VIREO_LDS_SPLIT_X10", "60")        # (no row pieces: a stream that splits rows is not balanced)
+    AD, DP = O.synth_donor(2600, 2300, 6, 0.03, seed=3)          # 6 slabs of variants, 3 of double rows of cells
+    N, M = AD.shape
+
+    def build(balance):
+        return DeviceCounts(AD, DP, balance=balance)
+
+    cb, cd = build(True), build(False)
+    ib = cb.build_info()
+    assert ib["balanced_variant"] and ib["balanced_cell"] and ib["device_built"] and ib["balance_seconds"] > 0
+    assert not cd.build_info()["balanced_cell"]
+    kb, kd = DeviceModel(cb, _lib.KIND_VIREO, 6).info(), DeviceModel(cd, _lib.KIND_VIREO, 6).info()
+    assert kb["lds_variant"] and kb["lds_cell"] and (kb["cell_form"], kb["var_form"]) == (1, 3)
+    assert kb["pad_cell"] < kd["pad_cell"] and kb["pad_variant"] < kd["pad_variant"]
+    print("stream slots per non-zero: balanced %.3f / %.3f, default %.3f / %.3f (variant / cell)"
+          % (kb["pad_variant"], kb["pad_cell"], kd["pad_variant"], kd["pad_cell"]))
+    assert build(True).digest() == cb.digest()
+
+    def fit(counts, **kw):
+        np.random.seed(4)
+        m = va.Vireo(n_var=N, n_cell=M, n_donor=6, **kw)
+        m.fit(counts, None, min_iter=5, max_iter=25, delay_fit_theta=2, verbose=False)
+        return m
+
+    for kw in (dict(), dict(ASE_mode=True)):
+        a, a2, d = fit(cb, **kw), fit(cb, **kw), fit(cd, **kw)
+        for name in ("ELBO_", "ID_prob", "GT_prob", "beta_mu", "beta_sum"):
+            assert np.array_equal(getattr(a, name), getattr(a2, name)), name
+        np.random.seed(4)
+        ref = O.vireo_new(M, N, 6, **kw)
+        O.vireo_fit(ref, AD, DP, min_iter=5, max_iter=25, delay_fit_theta=2)
+        assert len(a.ELBO_) == len(ref.ELBO_) == len(d.ELBO_)
+        close(a.ELBO_, ref.ELBO_)
+        close(a.ID_prob, ref.ID_prob)
+        close(a.GT_prob, ref.GT_prob)
+        close(a.beta_mu, ref.beta_mu)
+        close(a.beta_sum, ref.beta_sum)
+        assert np.array_equal(a.ID_prob.argmax(1), ref.ID_prob.argmax(1))
+        np.testing.assert_allclose(a.ELBO_, d.ELBO_, rtol=1e-10)
+        np.testing.assert_allclose(a.ID_prob, d.ID_prob, rtol=1e-7, atol=1e-290)
+    # the doublet step and a 40-column operand (column blocks: the list is not used there) on the balanced problem
+    m = fit(cb)
+    from vireo_amd.vireo_doublet import predict_doublet
+    st = O.vireo_new(M, N, 6, ID_prob_init=m.ID_prob, GT_prob_init=m.GT_prob, beta_mu_init=m.beta_mu.copy(),
+                     beta_sum_init=m.beta_sum.copy())
+    st.ID_prob, st.GT_prob = m.ID_prob.copy(), m.GT_prob.copy()
+    dbl_ref, sing_ref, llr_ref = O.vireo_doublet(st, AD, DP)
+    dbl, sing, llr = predict_doublet(m, cb, None)
+    close(dbl, dbl_ref)
+    close(sing, sing_ref)
+    close(llr, llr_ref, atol=1e-9)

@@ -3,8 +3,7 @@
 * Every instance `launch_lds_one` can pick keeps its registers: no VGPR spill, no scratch
   (the dominant instance spilled 6 VGPRs at the 128-register budget of a 1024-thread
   workgroup).  The report is written to profiles/r04_spmm_lds_resource_usage.txt.
-* The walk of those instances waits for its stream with `s_waitcnt vmcnt(PF + 1)` (`PF + 2` in the flat
-  instances, which also load the rows of a balanced slab) while the prefetch
+* The walk of those instances waits for its stream with `s_waitcnt vmcnt(PF + 1)` (+ 1: the rows of a balanced slab) while the prefetch
   of the next slab is in flight.  That count is only right if the prefetch is EXACTLY PF 16-byte
   loads (2 PF 8-byte loads when staged element-wise) plus the one load of the slab's bnd words,
   all unconditional: checked in the ISA.
@@ -96,18 +95,20 @@ def test_slab_prefetch_is_a_fixed_number_of_loads(isa):
         others = [l for l in between if re.match(r"\s*(global|buffer|flat|scratch)_load", l)
                   and not re.match(unit, l) and not re.match(r"\s*global_load_dword ", l)]
         n_pf = PF if wide else 2 * PF
-        # one 4-byte load of the slab's bnd words; the flat instances (PADK = 0) issue a second one -- the rows
-        # the wave stages for the slab behind it (balanced slabs, TiledStream::perm) -- whether or not the
-        # stream is balanced, so that the count the walk waits with is one constant
-        n_rec = 2 if inst[name]["padk"] == 0 else 1
+        # one 4-byte load of the slab's bnd words and a second one -- the rows the wave stages for the slab
+        # behind it (balanced slabs, TiledStream::perm) -- issued whether or not the stream is balanced, so
+        # that the count the walk waits with is one constant
+        n_rec = 2
         # (the flat instances hold the prefetch twice -- contiguous slab or gathered through the tile's list --
         #  behind one scalar branch on the list pointer: n_pf loads execute either way)
-        alt = 2 if inst[name]["padk"] == 0 else 1
+        alt = 2 if inst[name]["padk"] in (0, 2) else 1      # (element-wise staging selects per load instead)
         assert (n_unit, n_bnd, others) == (alt * n_pf, n_rec, []), (name, n_unit, n_bnd, others)
         if alt == 2:
             units = [i for i, l in enumerate(between) if re.match(unit, l)]
             assert any(re.match(r"\s*s_c?branch", l) for l in between[units[n_pf - 1]:units[n_pf]]), name
         # the loads sit in one block the scalar branch `s + 1 < s_hi` guards: no lane-mask branch
         loads = [i for i, l in enumerate(between) if re.match(r"\s*global_load_dword", l)]
-        assert not any("s_cbranch_exec" in l for l in between[loads[0]:loads[-1] + 1]), name
+        # (EXEC is never narrowed around them: a `s_cbranch_execnz` that the uniform `perm ? ... : ...` selects
+        #  of the element-wise instances leave behind always jumps -- EXEC is full -- and skips no load)
+        assert not any("saveexec" in l or "s_cbranch_execz" in l for l in between[loads[0]:loads[-1] + 1]), name
         assert any("s_waitcnt vmcnt(%d)" % (n_pf + n_rec) in l for l in body), name

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VIREO_LIB", os.path.join(_HERE, "libvireo_hip.so"))  # (override: A/B builds)
 
 KIND_VIREO, KIND_BMM = 0, 1
+PROBLEM_BALANCED = 1
 STEP_THETA, STEP_GT, STEP_ID, STEP_LOGLIK, STEP_ELBO, STEP_SOFTMAX = 1, 2, 3, 4, 5, 6
 KERN_VARIANT_PASS, KERN_CELL_PASS, KERN_DENSE, KERN_COUNT = 0, 1, 2, 3
 UNIQUE_ID_BYTES = 128
@@ -42,6 +43,9 @@ SIGNATURES = {
     "vrx_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "vrx_problem_create": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int64, _I64, _I32, _I32,
                                      _I32, C.POINTER(_P)]),
+    "vrx_problem_create2": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int64, _I64, _I32, _I32,
+                                      _I32, C.c_int32, C.POINTER(_P)]),
+    "vrx_problem_build_info": (C.c_int, [_P, _D]),
     "vrx_problem_destroy": (None, [_P]),
     "vrx_problem_binom_const": (C.c_int, [_P, _D]),
     "vrx_problem_n_vars": (C.c_int, [_P, _I32]),

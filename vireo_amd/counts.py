@@ -87,10 +87,29 @@ def merge_counts(AD, DP):
     return ((n_var, n_cell), colptr, rowidx, ad, dp)
 
 
+def balance_policy(balance=None, expected_iterations=None):
+    """Should the problem be built with *balanced slabs* (``vrx_problem_create2``, VRX_PROBLEM_BALANCED)?
+
+    They shorten the sparse passes by 10-17 % at c3 and cost a one-off ~0.5 s at 1e8 entries, so they pay
+    from a few thousand iterations on the same problem.  ``balance`` True / False decides; None: the
+    environment (VIREO_BALANCE=1 / 0), else on when the caller expects at least VIREO_BALANCE_MIN_ITERS
+    iterations (default 6000; ``vireo_wrap`` announces n_init x max_iter_init + 200).  The library applies the
+    flag only where it can (LDS-resident passes on AD/BD words, no split rows); ``DeviceCounts.build_info``
+    says what was built."""
+    import os
+    if balance is not None:
+        return bool(balance)
+    env = os.environ.get("VIREO_BALANCE")
+    if env in ("0", "1"):
+        return env == "1"
+    need = int(os.environ.get("VIREO_BALANCE_MIN_ITERS", "6000"))
+    return expected_iterations is not None and expected_iterations >= need
+
+
 class DeviceCounts:
     """(AD, DP) on one GPU, in both orientations (C handle ``vrx_problem``)."""
 
-    def __init__(self, AD, DP, device=None, _merged=None):
+    def __init__(self, AD, DP, device=None, _merged=None, balance=None, expected_iterations=None):
         _lib.require_gpu()
         if device is None:
             device = default_device()
@@ -105,21 +124,29 @@ class DeviceCounts:
         self.nnz = int(rowidx.size)
         self.device = device
         self._h = C.c_void_p()
-        _lib.check(_lib.lib().vrx_problem_create(
+        flags = _lib.PROBLEM_BALANCED if balance_policy(balance, expected_iterations) else 0
+        _lib.check(_lib.lib().vrx_problem_create2(
             device, self.n_var, self.n_cell, self.nnz,
             colptr.ctypes.data_as(C.POINTER(C.c_int64)),
             rowidx.ctypes.data_as(C.POINTER(C.c_int32)),
             ad.ctypes.data_as(C.POINTER(C.c_int32)),
-            dp.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(self._h)))
+            dp.ctypes.data_as(C.POINTER(C.c_int32)), flags, C.byref(self._h)))
         self._binom = None
         self._fin = weakref.finalize(self, _lib.lib().vrx_problem_destroy, self._h)
 
     @classmethod
-    def from_merged(cls, shape, colptr, rowidx, ad, dp, device=None):
+    def from_merged(cls, shape, colptr, rowidx, ad, dp, device=None, balance=None, expected_iterations=None):
         """from an already merged CSC pattern carrying (ad, dp) per entry (row indices
         strictly increasing inside each column; validated by the library)."""
-        return cls(None, None, device=device,
+        return cls(None, None, device=device, balance=balance, expected_iterations=expected_iterations,
                    _merged=((int(shape[0]), int(shape[1])), colptr, rowidx, ad, dp))
+
+    def build_info(self):
+        """what the library built: balanced slabs per orientation, the seconds they added, device build"""
+        a = np.zeros(4)
+        _lib.check(_lib.lib().vrx_problem_build_info(self._h, _lib.dptr(a)))
+        return dict(balanced_variant=bool(a[0]), balanced_cell=bool(a[1]), balance_seconds=float(a[2]),
+                    device_built=bool(a[3]))
 
     @property
     def handle(self):
@@ -206,9 +233,10 @@ def default_device():
     return int(os.environ.get("VIREO_DEVICE", os.environ.get("LOCAL_RANK", "0")))
 
 
-def device_counts(AD, DP=None, device=None):
+def device_counts(AD, DP=None, device=None, expected_iterations=None):
     """Accepts a DeviceCounts (returned as is) or an (AD, DP) pair in any of the
-    reference's input formats."""
+    reference's input formats.  ``expected_iterations``: how many iterations the caller will run on the
+    problem (``balance_policy``; only a problem built here takes it into account, a cached one is reused)."""
     if isinstance(AD, DeviceCounts):
         return AD
     if device is None:
@@ -220,7 +248,7 @@ def device_counts(AD, DP=None, device=None):
             digest = digest or _digest(AD, DP)
             if dig == digest:
                 return dc
-    dc = DeviceCounts(AD, DP, device=device)
+    dc = DeviceCounts(AD, DP, device=device, expected_iterations=expected_iterations)
     try:
         entry = (weakref.ref(AD), weakref.ref(DP) if DP is not None else None, device,
                  digest or _digest(AD, DP), dc)

@@ -211,12 +211,12 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_build_pack(int64_t nnz, int fmt
 }
 
 // ---- balanced slabs: relabel the contracted indices of every row by its tile's permutation -------
-// key[e] = row << 32 | posmap[tile_of_row[row]][idx[e]]  (row by binary search in ptr), val[e] = e
+// key[e] = row << pbits | posmap[tile_of_row[row]][idx[e]]  (row by binary search in ptr), val[e] = e
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_build_relabel(int64_t nnz, int64_t n_rows, int64_t n_contract,
                                                                const int64_t* __restrict__ ptr,
                                                                const int32_t* __restrict__ idx,
                                                                const int32_t* __restrict__ tile_of_row,
-                                                               const int32_t* __restrict__ posmap,
+                                                               const int32_t* __restrict__ posmap, int pbits,
                                                                uint64_t* __restrict__ keys,
                                                                uint32_t* __restrict__ vals) {
     const int64_t e = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
@@ -231,18 +231,27 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_build_relabel(int64_t nnz, int6
     }
     const int32_t t = tile_of_row[lo];
     const uint32_t pos = t >= 0 ? (uint32_t)posmap[(int64_t)t * n_contract + idx[e]] : (uint32_t)idx[e];
-    keys[e] = ((uint64_t)lo << 32) | pos;
+    keys[e] = ((uint64_t)lo << pbits) | pos;
     vals[e] = (uint32_t)e;
+}
+
+// FORM 1 words of every entry (what the host-side balancing needs besides the index)
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_build_words(int64_t nnz, const int2* __restrict__ val,
+                                                             uint8_t* __restrict__ words) {
+    const int64_t e = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    if (e >= nnz) return;
+    const int2 x = val[e];
+    words[e] = (uint8_t)min(vrx_chunks(x.x) + vrx_chunks((int64_t)x.y - x.x), 255);
 }
 
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_build_relabel_gather(int64_t nnz, const uint64_t* __restrict__ keys,
                                                                       const uint32_t* __restrict__ perm,
-                                                                      const int2* __restrict__ val,
+                                                                      const int2* __restrict__ val, int pbits,
                                                                       int32_t* __restrict__ idx2,
                                                                       int2* __restrict__ val2) {
     const int64_t q = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
     if (q >= nnz) return;
-    idx2[q] = (int32_t)(keys[q] & 0xffffffffu);
+    idx2[q] = (int32_t)(keys[q] & (((uint64_t)1 << pbits) - 1));
     val2[q] = val[perm[q]];
 }
 

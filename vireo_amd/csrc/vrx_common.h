@@ -105,7 +105,8 @@ struct TiledStream {
     // maximum over its 16 rows).  perm[tile][slab * slab_rows + p] = contracted row staged at slab-local
     // position p (unused positions name row 0); the stream's indices are positions.  Empty: slabs are consecutive rows.
     DevBuf<int32_t> perm;
-    bool balanced = false;
+    bool balanced = false, want_balance = false;
+    double balance_seconds = 0.0;
     DevBuf<int32_t> vptr;     // row -> its pieces [vptr[r], vptr[r+1]) (only when split)
     DevBuf<int32_t> split_rows;  // the rows with more than one piece (vrx_fold_split)
     int64_t n_split = 0;
@@ -141,6 +142,8 @@ struct vrx_problem {
     bool binom_done = false;
     double binom_sum = 0.0;
     std::vector<int32_t> n_vars;
+    bool want_balance = false;     // vrx_problem_create2 flag VRX_PROBLEM_BALANCED (TiledStream::perm)
+    double balance_seconds = 0.0;  // what the balanced slabs added to the build (both orientations)
 };
 
 // vrx_comm.hip broadcasts a model's variational state in place (vrx_comm_bcast_model): the four

@@ -276,6 +276,11 @@ struct DevRows {
     const int32_t* idx;
     const int2* val;
 };
+// the same rows on the host, where the caller still has them (the cell orientation IS the CSC input)
+struct HostCounts {
+    const int32_t* idx;
+    const int32_t *ad, *dp;
+};
 
 // Work list of an LDS-resident pass (TiledStream::items).  The (tile, slab) visits, tile-major,
 // are cut into n_wg contiguous runs of equal cost -- cost of a visit = the longest wave's trips in
@@ -430,13 +435,15 @@ static inline int words_of_count(int64_t v) {  // FORM 1 words of one count (pus
     return n;
 }
 
-static void balance_tile(const std::vector<int32_t>& rows, const int64_t* ptr, const int32_t* idx, const int2* val,
+// `words(e)` = FORM 1 words of entry e (host counts, or the bytes vrx_build_words left)
+template <class W>
+static void balance_tile(const std::vector<int32_t>& rows, const int64_t* ptr, const int32_t* idx, W&& words,
                          int64_t n_contract, int n_slab, int slab_rows, int32_t* posmap, int32_t* perm) {
     const int64_t NC = n_contract;
     std::vector<uint32_t> cptr((size_t)NC + 1, 0);
     for (int32_t r : rows)
         for (int64_t e = ptr[r]; e < ptr[r + 1]; ++e)
-            if (words_of_count(val[e].x) + words_of_count((int64_t)val[e].y - val[e].x) > 0) ++cptr[(size_t)idx[e] + 1];
+            if (words(e) > 0) ++cptr[(size_t)idx[e] + 1];
     for (int64_t c = 0; c < NC; ++c) cptr[(size_t)c + 1] += cptr[(size_t)c];
     const size_t ne = cptr[(size_t)NC];
     std::vector<uint16_t> erow(ne);
@@ -446,7 +453,7 @@ static void balance_tile(const std::vector<int32_t>& rows, const int64_t* ptr, c
         for (size_t i = 0; i < rows.size(); ++i) {
             const int32_t r = rows[i];
             for (int64_t e = ptr[r]; e < ptr[r + 1]; ++e) {
-                const int w = words_of_count(val[e].x) + words_of_count((int64_t)val[e].y - val[e].x);
+                const int w = words(e);
                 if (w == 0) continue;
                 const uint32_t at = cur[(size_t)idx[e]]++;
                 erow[at] = (uint16_t)i;
@@ -481,14 +488,28 @@ static void balance_tile(const std::vector<int32_t>& rows, const int64_t* ptr, c
             place(c, next_free);
             continue;
         }
-        std::fill(score.begin(), score.end(), 0);
+        // candidates: every slab while there are at most 256 of them; beyond (problems of 4x c3 and more:
+        // the search is columns x entries x slabs) a window of 64 consecutive slabs at a position hashed from
+        // the column -- every slab sits in many windows, the balance is a little coarser (1.24 instead of
+        // 1.18 executed slots per word at c3's shape), the cost linear in the problem again
+        int w0 = 0, wn = n_slab;
+        if (n_slab > 256) {
+            wn = 64;
+            w0 = (int)(((uint64_t)(uint32_t)c * 2654435761u) % (uint64_t)(n_slab - wn + 1));
+        }
+        std::fill(score.begin() + w0, score.begin() + w0 + wn, 0);
         for (uint32_t e = a; e < b; ++e) {
-            const int16_t* L = load.data() + (size_t)erow[e] * nsp;
-            for (int sl = 0; sl < nsp; ++sl) score[(size_t)sl] += L[sl];
+            const int16_t* L = load.data() + (size_t)erow[e] * nsp + w0;
+            int32_t* sc = score.data() + w0;
+            for (int sl = 0; sl < wn; ++sl) sc[sl] += L[sl];
         }
         int best = -1;
-        for (int sl = 0; sl < n_slab; ++sl)
+        for (int sl = w0; sl < w0 + wn; ++sl)
             if (cap[(size_t)sl] > 0 && (best < 0 || score[(size_t)sl] < score[(size_t)best])) best = sl;
+        if (best < 0) {  // the window is full: the first slab with room
+            while (cap[(size_t)next_free] == 0) ++next_free;
+            best = next_free;
+        }
         place(c, best);
         for (uint32_t e = a; e < b; ++e) load[(size_t)erow[e] * nsp + best] += ew[e];
     }
@@ -497,7 +518,7 @@ static void balance_tile(const std::vector<int32_t>& rows, const int64_t* ptr, c
 static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const int2* val,
                        int RW, int slab_rows, bool guard, int form, int mode, hipStream_t s,
                        int n_cu, const DevRows* dev = nullptr, int64_t virt_rows = -1,
-                       int64_t virt_contract = -1, int64_t virt_nnz = -1) {
+                       int64_t virt_contract = -1, int64_t virt_nnz = -1, const HostCounts* hc = nullptr) {
     constexpr int G = 64 / VRX_LDS_LPE, U = VRX_LDS_U;
     const int NR = RW / G;
     TiledStream& t = o.tiled;
@@ -646,12 +667,13 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
         DevBuf<int2> d_val2;
         t.balanced = false;
         t.perm.release();
-        if (form == 1 && !t.split && env_int("VIREO_BALANCE", 0) != 0 && t.n_slab > 1 &&
+        if (form == 1 && !t.split && t.want_balance && t.n_slab > 1 &&
             o_n_contract < ((int64_t)1 << 24) && o_n_rows < ((int64_t)1 << 31)) {
             const int64_t tile_pos = (int64_t)VRX_LDS_WAVES * RW, slots = (int64_t)t.n_slab * slab_rows;
             const bool timing = env_int("VIREO_BUILD_TIMING", 0) != 0;
             auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
             double tm0 = now();
+            const double tm_begin = tm0;
             auto lap = [&](const char* what) {
                 if (!timing) return;
                 (void)hipStreamSynchronize(s);
@@ -659,11 +681,22 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
                 fprintf(stderr, "[vrx build] balanced slabs (mode %d): %-28s %.3f s\n", mode, what, t1 - tm0);
                 tm0 = t1;
             };
-            std::vector<int32_t> h_idx((size_t)o_nnz);
-            std::vector<int2> h_val((size_t)o_nnz);
-            VRX_HIP(hipMemcpyAsync(h_idx.data(), dev->idx, (size_t)o_nnz * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-            VRX_HIP(hipMemcpyAsync(h_val.data(), dev->val, (size_t)o_nnz * sizeof(int2), hipMemcpyDeviceToHost, s));
-            VRX_HIP(hipStreamSynchronize(s));
+            // what the greedy reads: every entry's contracted index and its FORM 1 word count.  The cell
+            // orientation's rows are the caller's CSC arrays; otherwise the indices and one byte per entry
+            // (vrx_build_words) come back from the device
+            std::vector<int32_t> h_idx;
+            std::vector<uint8_t> h_words;
+            if (!hc) {
+                DevBuf<uint8_t> d_words;
+                VRX_HIP(d_words.alloc((size_t)o_nnz));
+                vrx_build_words<<<(unsigned)((o_nnz + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(o_nnz, dev->val, d_words.p);
+                VRX_HIP(hipGetLastError());
+                h_idx.resize((size_t)o_nnz);
+                h_words.resize((size_t)o_nnz);
+                VRX_HIP(hipMemcpyAsync(h_idx.data(), dev->idx, (size_t)o_nnz * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                VRX_HIP(hipMemcpyAsync(h_words.data(), d_words.p, (size_t)o_nnz, hipMemcpyDeviceToHost, s));
+                VRX_HIP(hipStreamSynchronize(s));
+            }
             lap("download rows");
             std::vector<int32_t> posmap((size_t)(t.n_tile * o_n_contract)), perm((size_t)(t.n_tile * slots));
             std::vector<int32_t> tile_of_row((size_t)o_n_rows, -1);
@@ -675,13 +708,20 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
                     rows.clear();
                     for (int64_t pos = tl * tile_pos; pos < (tl + 1) * tile_pos; ++pos)
                         if (rowmap[(size_t)pos] >= 0) rows.push_back(vrow_row[(size_t)rowmap[(size_t)pos]]);
-                    balance_tile(rows, ptr, h_idx.data(), h_val.data(), o_n_contract, t.n_slab, slab_rows,
-                                 posmap.data() + tl * o_n_contract, perm.data() + tl * slots);
+                    int32_t* pm = posmap.data() + tl * o_n_contract;
+                    int32_t* pr = perm.data() + tl * slots;
+                    if (hc)
+                        balance_tile(rows, ptr, hc->idx, [&](int64_t e) {
+                            return std::min(words_of_count(hc->ad[e]) + words_of_count((int64_t)hc->dp[e] - hc->ad[e]), 255);
+                        }, o_n_contract, t.n_slab, slab_rows, pm, pr);
+                    else
+                        balance_tile(rows, ptr, h_idx.data(), [&](int64_t e) { return (int)h_words[(size_t)e]; },
+                                     o_n_contract, t.n_slab, slab_rows, pm, pr);
                 }
             });
             lap("greedy (host threads)");
             std::vector<int32_t>().swap(h_idx);
-            std::vector<int2>().swap(h_val);
+            std::vector<uint8_t>().swap(h_words);
             VRX_HIP(d_tile_of_row.upload(tile_of_row.data(), tile_of_row.size(), s));
             VRX_HIP(d_posmap.upload(posmap.data(), posmap.size(), s));
             VRX_HIP(t.perm.upload(perm.data(), perm.size(), s));
@@ -692,24 +732,26 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
             VRX_HIP(v_in.alloc((size_t)o_nnz));
             VRX_HIP(v_out.alloc((size_t)o_nnz));
             const unsigned nbe = (unsigned)((o_nnz + VRX_BLOCK - 1) / VRX_BLOCK);
-            vrx_build_relabel<<<nbe, VRX_BLOCK, 0, s>>>(o_nnz, o_n_rows, o_n_contract, dev->ptr, dev->idx,
-                                                        d_tile_of_row.p, d_posmap.p, k_in.p, v_in.p);
-            VRX_HIP(hipGetLastError());
-            int rbits = 1;
+            int rbits = 1, pbits = 1;  // key = row << pbits | position: as few radix passes as the sizes need
             while (((int64_t)1 << rbits) < o_n_rows) ++rbits;
+            while (((int64_t)1 << pbits) < std::max<int64_t>(slots, o_n_contract)) ++pbits;
+            vrx_build_relabel<<<nbe, VRX_BLOCK, 0, s>>>(o_nnz, o_n_rows, o_n_contract, dev->ptr, dev->idx,
+                                                        d_tile_of_row.p, d_posmap.p, pbits, k_in.p, v_in.p);
+            VRX_HIP(hipGetLastError());
             size_t tmp_bytes = 0;
             VRX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k_in.p, k_out.p, v_in.p, v_out.p,
-                                                       (size_t)o_nnz, 0, 32 + rbits, s));
+                                                       (size_t)o_nnz, 0, pbits + rbits, s));
             DevBuf<char> tmp;
             VRX_HIP(tmp.alloc(tmp_bytes));
             VRX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, k_in.p, k_out.p, v_in.p, v_out.p,
-                                                       (size_t)o_nnz, 0, 32 + rbits, s));
+                                                       (size_t)o_nnz, 0, pbits + rbits, s));
             VRX_HIP(d_idx2.alloc((size_t)o_nnz));
             VRX_HIP(d_val2.alloc((size_t)o_nnz));
-            vrx_build_relabel_gather<<<nbe, VRX_BLOCK, 0, s>>>(o_nnz, k_out.p, v_out.p, dev->val, d_idx2.p, d_val2.p);
+            vrx_build_relabel_gather<<<nbe, VRX_BLOCK, 0, s>>>(o_nnz, k_out.p, v_out.p, dev->val, pbits, d_idx2.p, d_val2.p);
             VRX_HIP(hipGetLastError());
             VRX_HIP(hipStreamSynchronize(s));
             lap("upload + relabel + sort");
+            t.balance_seconds = now() - tm_begin;
             A.idx = d_idx2.p;
             A.val = d_val2.p;
             t.balanced = true;
@@ -1122,8 +1164,10 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
     if ((rc = set_orient(p->by_cell, n_cell, n_var, d_row.p, d_cval.p))) return rc;
     if ((rc = set_orient(p->by_var, n_var, n_cell, d_ridx.p, d_rval.p))) return rc;
     const DevRows cell_rows{d_colptr.p, d_row.p, d_cval.p}, var_rows{d_rptr.p, d_ridx.p, d_rval.p};
+    p->by_cell.tiled.want_balance = p->by_var.tiled.want_balance = p->want_balance;
+    const HostCounts cell_host{rowidx, ad, dp};
     rc = build_tiled(p->by_cell, colptr, nullptr, nullptr, rw_cell, slab_cell, guard, cell_form, 1, s,
-                     p->n_cu, &cell_rows);
+                     p->n_cu, &cell_rows, -1, -1, -1, &cell_host);
     if (rc) return rc;
     if (var_form == 3) {
         // the variant pass on virtual rows (vrx_build.h): derive them, then the AD/BD cell-pass
@@ -1181,6 +1225,14 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
 extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int64_t nnz,
                                   const int64_t* colptr, const int32_t* rowidx, const int32_t* ad,
                                   const int32_t* dp, vrx_problem** out) {
+    // (VIREO_BALANCE=1 in the environment: balanced slabs for every problem built through this entry)
+    return vrx_problem_create2(device, n_var, n_cell, nnz, colptr, rowidx, ad, dp,
+                               env_int("VIREO_BALANCE", 0) != 0 ? VRX_PROBLEM_BALANCED : 0, out);
+}
+
+extern "C" int vrx_problem_create2(int device, int64_t n_var, int64_t n_cell, int64_t nnz,
+                                   const int64_t* colptr, const int32_t* rowidx, const int32_t* ad,
+                                   const int32_t* dp, int32_t flags, vrx_problem** out) {
     VRX_REQUIRE(out, "vrx_problem_create: null output");
     *out = nullptr;
     VRX_REQUIRE(n_var > 0 && n_cell > 0 && nnz >= 0, "vrx_problem_create: bad shape");
@@ -1200,6 +1252,7 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
     p->n_var = n_var;
     p->n_cell = n_cell;
     p->nnz = nnz;
+    p->want_balance = (flags & VRX_PROBLEM_BALANCED) != 0;
     hipDeviceProp_t prop;
     VRX_HIP(hipGetDeviceProperties(&prop, device));
     p->n_cu = prop.multiProcessorCount;
@@ -1224,6 +1277,7 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
                                   lds0 != 1, &built);
             if (rc) return rc;
             if (built) {
+                p->balance_seconds = p->by_cell.tiled.balance_seconds + p->by_var.tiled.balance_seconds;
                 *out = p.release();
                 return VRX_OK;
             }
@@ -1472,6 +1526,15 @@ extern "C" int vrx_problem_digest(vrx_problem* p, uint64_t* out12) {
         if ((rc = fnv_of(o->tiled.rowmap, p->stream, out12 + k++))) return rc;
         out12[k++] = (uint64_t)o->n_seg;
     }
+    return VRX_OK;
+}
+
+extern "C" int vrx_problem_build_info(vrx_problem* p, double* info4) {
+    VRX_REQUIRE(p && info4, "vrx_problem_build_info: null argument");
+    info4[0] = p->by_var.tiled.ready && p->by_var.tiled.balanced ? 1.0 : 0.0;
+    info4[1] = p->by_cell.tiled.ready && p->by_cell.tiled.balanced ? 1.0 : 0.0;
+    info4[2] = p->balance_seconds;
+    info4[3] = p->by_var.tiled.ready && p->by_cell.tiled.ready && p->by_var.n_seg == 0 ? 1.0 : 0.0;  // built on the device
     return VRX_OK;
 }
 
@@ -2212,7 +2275,7 @@ static int launch_lds_one(const Orient& o, hipStream_t s, const double* X, int K
                                      t.wg_first.p, t.n_slab,
                                      t.slab_rows, t.n_contract, t.n_vrows,
                                      X + (size_t)c0 * (f1 ? 1 : XD), kb, K, dst + (size_t)c0 * NV, ctl, R,
-                                     t.balanced && kb == 16 && K == 16 ? t.perm.p : nullptr);
+                                     t.balanced ? t.perm.p : nullptr);
         VRX_HIP(hipGetLastError());
     }
     return VRX_OK;

@@ -585,9 +585,9 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
     // rows / columns they fill are never referenced by a word resp. never stored), so the walk
     // can leave the prefetch in flight while it waits for a chunk of its stream
     constexpr bool PRECISE = FORM != 0 && VRX_LDS_PRECISE;
-    // (element-wise: 2 loads per unit) + the bnd words of the next slab (+ flat AD/BD instances: the rows the
-    //  wave stages for the slab behind it, TiledStream::perm -- issued whether or not the stream is balanced)
-    constexpr bool GATHER = PADK == 0 && PRECISE;
+    // (element-wise: 2 loads per unit) + the bnd words of the next slab (+ AD/BD instances: the rows the wave
+    //  stages for the slab behind it, TiledStream::perm -- issued whether or not the stream is balanced)
+    constexpr bool GATHER = PRECISE;
     constexpr int NPF = (PADK == 1 ? 2 : 1) * PF + 1 + (GATHER ? 1 : 0);
     extern __shared__ __attribute__((aligned(16))) char vrx_smem[];
     const int lane = threadIdx.x & 63;
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
     auto slab_fetch = [&](int s, int rvec) {
         const int64_t row0 = (int64_t)s * slab_rows;
         const int64_t rows = min((int64_t)slab_rows, n_contract - row0);
-        if (GATHER && perm) {
+        if (!PADK && GATHER && perm) {
             // balanced slabs: a wave's load i covers the four slab-local rows 4 * wave + 64 i + 0..3; their
             // contracted rows sit in lanes 32 + 4 i + 0..3 of the vector rows_load fetched a slab ahead
             const vrx_d2* src = reinterpret_cast<const vrx_d2*>(X);
@@ -702,6 +702,15 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
                     const bool m0 = cc < K;
                     const int col = m0 ? (FORM == 1 ? (j0 >> 3) * ld + cc : cc) : 0;
                     const int pitch = FORM == 1 ? 2 * ld : ld;
+                    if (perm) {  // balanced slabs: the rows come through the tile's list (see the flat path)
+                        const int sel = (32 + ((tid_f & 63) >> 4)) << 2;
+#pragma unroll
+                        for (int i = 0; i < PF; ++i) {
+                            const int rowg = __builtin_amdgcn_ds_bpermute(sel + 16 * i, rvec);
+                            pf[i] = *reinterpret_cast<const vrx_d2*>(X + (uint32_t)(rowg * pitch + col));
+                            if (i & 1) __builtin_amdgcn_sched_barrier(0);
+                        }
+                    } else
 #pragma unroll
                     for (int i = 0; i < PF; ++i)
                         pf[i] = *reinterpret_cast<const vrx_d2*>(
@@ -722,12 +731,15 @@ __global__ __launch_bounds__(VRX_LDS_WAVES * 64)
                 const int cc = FORM == 1 ? 2 * (j0 & 7) : 2 * j0;
                 const int half = FORM == 1 ? (j0 >> 3) * ld : 0, pitch = FORM == 1 ? 2 * ld : ld;
                 const int c0 = half + (cc < K ? cc : 0), c1 = half + (cc + 1 < K ? cc + 1 : 0);
+                const int sel = (32 + ((tid_f & 63) >> 4)) << 2;
 #pragma unroll
                 for (int i = 0; i < PF; ++i) {
-                    const int at = min(r0v + i * rstep, rows32 - 1) * pitch;
+                    const int at = perm ? __builtin_amdgcn_ds_bpermute(sel + 16 * i, rvec) * pitch
+                                        : min(r0v + i * rstep, rows32 - 1) * pitch;
+                    const double* base = perm ? X : src;  // (the list names rows of the whole operand)
                     vrx_d2 v;
-                    v.x = src[at + c0];
-                    v.y = src[at + c1];
+                    v.x = base[at + c0];
+                    v.y = base[at + c1];
                     pf[i] = v;
                 }
             } else if (MODE == 1) {  // unit j0 = (w1, w2) of column j0

@@ -303,8 +303,10 @@ def vireo_wrap(AD, DP, GT_prior=None, n_donor=None, learn_GT=True, n_init=20,
     """Run vireo with multiple initialisations; returns the reference's result dict
     (keys: vireo_wrap.py:170-183)."""
     comm = LocalComm() if comm is None else comm
-    counts = device_counts(AD, DP)
     plan = _Plan(GT_prior, n_donor, learn_GT, n_init, n_extra_donor)
+    # every restart and the final fit run on ONE device problem (vireo_wrap.py:64-94): tell the builder how
+    # many iterations that is, so that it can spend a one-off effort that pays back over them
+    counts = device_counts(AD, DP, expected_iterations=-(-plan.n_init // comm.world) * max_iter_init + 200)
     if check_ambient:
         raise NotImplementedError("check_ambient (experimental in the reference, "
                                   "vireo.py:79-81) is out of scope of vireo_amd")
