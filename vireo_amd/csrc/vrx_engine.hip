@@ -281,6 +281,11 @@ struct HostCounts {
     const int32_t* idx;
     const int32_t *ad, *dp;
 };
+// ... or what the balancing needs of them, already brought back from the device by the caller
+struct HostWords {
+    const int32_t* idx;
+    const uint8_t* words;
+};
 
 // Work list of an LDS-resident pass (TiledStream::items).  The (tile, slab) visits, tile-major,
 // are cut into n_wg contiguous runs of equal cost -- cost of a visit = the longest wave's trips in
@@ -435,90 +440,16 @@ static inline int words_of_count(int64_t v) {  // FORM 1 words of one count (pus
     return n;
 }
 
-// `words(e)` = FORM 1 words of entry e (host counts, or the bytes vrx_build_words left)
-template <class W>
-static void balance_tile(const std::vector<int32_t>& rows, const int64_t* ptr, const int32_t* idx, W&& words,
-                         int64_t n_contract, int n_slab, int slab_rows, int32_t* posmap, int32_t* perm) {
-    const int64_t NC = n_contract;
-    std::vector<uint32_t> cptr((size_t)NC + 1, 0);
-    for (int32_t r : rows)
-        for (int64_t e = ptr[r]; e < ptr[r + 1]; ++e)
-            if (words(e) > 0) ++cptr[(size_t)idx[e] + 1];
-    for (int64_t c = 0; c < NC; ++c) cptr[(size_t)c + 1] += cptr[(size_t)c];
-    const size_t ne = cptr[(size_t)NC];
-    std::vector<uint16_t> erow(ne);
-    std::vector<uint8_t> ew(ne);
-    {
-        std::vector<uint32_t> cur(cptr.begin(), cptr.end() - 1);
-        for (size_t i = 0; i < rows.size(); ++i) {
-            const int32_t r = rows[i];
-            for (int64_t e = ptr[r]; e < ptr[r + 1]; ++e) {
-                const int w = words(e);
-                if (w == 0) continue;
-                const uint32_t at = cur[(size_t)idx[e]]++;
-                erow[at] = (uint16_t)i;
-                ew[at] = (uint8_t)std::min(w, 255);
-            }
-        }
-    }
-    // columns by degree, descending (counting sort, stable in the column index)
-    uint32_t maxdeg = 0;
-    for (int64_t c = 0; c < NC; ++c) maxdeg = std::max(maxdeg, cptr[(size_t)c + 1] - cptr[(size_t)c]);
-    std::vector<uint32_t> dstart((size_t)maxdeg + 2, 0);
-    for (int64_t c = 0; c < NC; ++c) ++dstart[(size_t)(maxdeg - (cptr[(size_t)c + 1] - cptr[(size_t)c])) + 1];
-    for (size_t d = 0; d <= maxdeg; ++d) dstart[d + 1] += dstart[d];
-    std::vector<int32_t> order((size_t)NC);
-    for (int64_t c = 0; c < NC; ++c) order[dstart[(size_t)(maxdeg - (cptr[(size_t)c + 1] - cptr[(size_t)c]))]++] = (int32_t)c;
-    const int nsp = (n_slab + 31) / 32 * 32;
-    std::vector<int16_t> load(rows.size() * (size_t)nsp, 0);
-    std::vector<int32_t> score((size_t)nsp), cap((size_t)n_slab, slab_rows), fill((size_t)n_slab, 0);
-    for (int64_t p = 0; p < (int64_t)n_slab * slab_rows; ++p) perm[p] = 0;  // (unused positions: any valid row)
-    auto place = [&](int32_t c, int sl) {
-        const int local = fill[(size_t)sl]++;
-        --cap[(size_t)sl];
-        posmap[c] = sl * slab_rows + local;
-        perm[(int64_t)sl * slab_rows + local] = c;
-    };
-    int next_free = 0;
-    for (int64_t k = 0; k < NC; ++k) {
-        const int32_t c = order[(size_t)k];
-        const uint32_t a = cptr[(size_t)c], b = cptr[(size_t)c + 1];
-        if (a == b) {  // no entry in this tile: any slab with room
-            while (cap[(size_t)next_free] == 0) ++next_free;
-            place(c, next_free);
-            continue;
-        }
-        // candidates: every slab while there are at most 256 of them; beyond (problems of 4x c3 and more:
-        // the search is columns x entries x slabs) a window of 64 consecutive slabs at a position hashed from
-        // the column -- every slab sits in many windows, the balance is a little coarser (1.24 instead of
-        // 1.18 executed slots per word at c3's shape), the cost linear in the problem again
-        int w0 = 0, wn = n_slab;
-        if (n_slab > 256) {
-            wn = 64;
-            w0 = (int)(((uint64_t)(uint32_t)c * 2654435761u) % (uint64_t)(n_slab - wn + 1));
-        }
-        std::fill(score.begin() + w0, score.begin() + w0 + wn, 0);
-        for (uint32_t e = a; e < b; ++e) {
-            const int16_t* L = load.data() + (size_t)erow[e] * nsp + w0;
-            int32_t* sc = score.data() + w0;
-            for (int sl = 0; sl < wn; ++sl) sc[sl] += L[sl];
-        }
-        int best = -1;
-        for (int sl = w0; sl < w0 + wn; ++sl)
-            if (cap[(size_t)sl] > 0 && (best < 0 || score[(size_t)sl] < score[(size_t)best])) best = sl;
-        if (best < 0) {  // the window is full: the first slab with room
-            while (cap[(size_t)next_free] == 0) ++next_free;
-            best = next_free;
-        }
-        place(c, best);
-        for (uint32_t e = a; e < b; ++e) load[(size_t)erow[e] * nsp + best] += ew[e];
-    }
-}
+// (the greedy itself: vrx_host.cpp, vrx_balance_tile -- host only, built with AVX2 clones of its inner loops)
+void vrx_balance_tile(const int32_t* rows, int64_t n_rows_tile, const int64_t* ptr, const int32_t* idx,
+                      const uint8_t* words, int64_t n_contract, int n_slab, int slab_rows, int32_t* posmap,
+                      int32_t* perm);
 
 static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const int2* val,
                        int RW, int slab_rows, bool guard, int form, int mode, hipStream_t s,
                        int n_cu, const DevRows* dev = nullptr, int64_t virt_rows = -1,
-                       int64_t virt_contract = -1, int64_t virt_nnz = -1, const HostCounts* hc = nullptr) {
+                       int64_t virt_contract = -1, int64_t virt_nnz = -1, const HostCounts* hc = nullptr,
+                       const HostWords* hw = nullptr) {
     constexpr int G = 64 / VRX_LDS_LPE, U = VRX_LDS_U;
     const int NR = RW / G;
     TiledStream& t = o.tiled;
@@ -686,7 +617,7 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
             // (vrx_build_words) come back from the device
             std::vector<int32_t> h_idx;
             std::vector<uint8_t> h_words;
-            if (!hc) {
+            if (!hc && !hw) {
                 DevBuf<uint8_t> d_words;
                 VRX_HIP(d_words.alloc((size_t)o_nnz));
                 vrx_build_words<<<(unsigned)((o_nnz + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(o_nnz, dev->val, d_words.p);
@@ -702,21 +633,26 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
             std::vector<int32_t> tile_of_row((size_t)o_n_rows, -1);
             for (int64_t pos = 0; pos < (int64_t)t.n_tile * tile_pos; ++pos)
                 if (rowmap[(size_t)pos] >= 0) tile_of_row[(size_t)vrow_row[(size_t)rowmap[(size_t)pos]]] = (int32_t)(pos / tile_pos);
-            parallel_chunks(t.n_tile, host_threads(), [&](int64_t t0, int64_t t1, int) {
+            if (hc) {  // the caller's counts: one byte per entry, on all host threads
+                h_words.resize((size_t)o_nnz);
+                parallel_chunks(o_nnz, host_threads(), [&](int64_t e0, int64_t e1, int) {
+                    for (int64_t e = e0; e < e1; ++e)
+                        h_words[(size_t)e] = (uint8_t)std::min(
+                            words_of_count(hc->ad[e]) + words_of_count((int64_t)hc->dp[e] - hc->ad[e]), 255);
+                });
+            }
+            const int32_t* g_idx = hc ? hc->idx : hw ? hw->idx : h_idx.data();
+            const uint8_t* g_words = hw ? hw->words : h_words.data();
+            // tiles in parallel, the most expensive first is not needed: they cost the same
+            std::atomic<int64_t> next_tile{0};
+            parallel_chunks(std::min<int64_t>(t.n_tile, host_threads()), host_threads(), [&](int64_t, int64_t, int) {
                 std::vector<int32_t> rows;
-                for (int64_t tl = t0; tl < t1; ++tl) {
+                for (int64_t tl = next_tile++; tl < t.n_tile; tl = next_tile++) {
                     rows.clear();
                     for (int64_t pos = tl * tile_pos; pos < (tl + 1) * tile_pos; ++pos)
                         if (rowmap[(size_t)pos] >= 0) rows.push_back(vrow_row[(size_t)rowmap[(size_t)pos]]);
-                    int32_t* pm = posmap.data() + tl * o_n_contract;
-                    int32_t* pr = perm.data() + tl * slots;
-                    if (hc)
-                        balance_tile(rows, ptr, hc->idx, [&](int64_t e) {
-                            return std::min(words_of_count(hc->ad[e]) + words_of_count((int64_t)hc->dp[e] - hc->ad[e]), 255);
-                        }, o_n_contract, t.n_slab, slab_rows, pm, pr);
-                    else
-                        balance_tile(rows, ptr, h_idx.data(), [&](int64_t e) { return (int)h_words[(size_t)e]; },
-                                     o_n_contract, t.n_slab, slab_rows, pm, pr);
+                    vrx_balance_tile(rows.data(), (int64_t)rows.size(), ptr, g_idx, g_words, o_n_contract,
+                                     t.n_slab, slab_rows, posmap.data() + tl * o_n_contract, perm.data() + tl * slots);
                 }
             });
             lap("greedy (host threads)");
@@ -1165,35 +1101,80 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
     if ((rc = set_orient(p->by_var, n_var, n_cell, d_ridx.p, d_rval.p))) return rc;
     const DevRows cell_rows{d_colptr.p, d_row.p, d_cval.p}, var_rows{d_rptr.p, d_ridx.p, d_rval.p};
     p->by_cell.tiled.want_balance = p->by_var.tiled.want_balance = p->want_balance;
-    const HostCounts cell_host{rowidx, ad, dp};
-    rc = build_tiled(p->by_cell, colptr, nullptr, nullptr, rw_cell, slab_cell, guard, cell_form, 1, s,
-                     p->n_cu, &cell_rows, -1, -1, -1, &cell_host);
-    if (rc) return rc;
+    // the variant pass on virtual rows (vrx_build.h): derived FIRST, so that -- balanced slabs -- their
+    // indices and word counts can travel to the host on a second stream while the host balances the cell
+    // orientation (the greedy of vrx_balance_tile reads both orientations' entries on the host)
+    DevBuf<int64_t> d_cnt, d_vptr2;
+    DevBuf<int32_t> d_vidx;
+    DevBuf<int2> d_vval;
+    std::vector<int64_t> vptr2;
+    int64_t vnnz = 0;
+    std::vector<int32_t> hv_idx;
+    std::vector<uint8_t> hv_words;
+    std::thread helper;
+    hipError_t helper_err = hipSuccess;
     if (var_form == 3) {
-        // the variant pass on virtual rows (vrx_build.h): derive them, then the AD/BD cell-pass
-        // stream (FORM 1) over 2 N rows x ceil(M / 2) double rows
-        DevBuf<int64_t> d_cnt, d_vptr2;
-        DevBuf<int32_t> d_vidx;
-        DevBuf<int2> d_vval;
         VRX_HIP(d_cnt.alloc((size_t)(2 * n_var)));
         const unsigned nbv = (unsigned)((n_var + VRX_BLOCK - 1) / VRX_BLOCK);
         vrx_virt_count<<<nbv, VRX_BLOCK, 0, s>>>(n_var, d_rptr.p, d_ridx.p, d_rval.p, d_cnt.p);
         VRX_HIP(hipGetLastError());
-        std::vector<int64_t> vptr2((size_t)(2 * n_var + 1), 0);
+        vptr2.assign((size_t)(2 * n_var + 1), 0);
         VRX_HIP(hipMemcpyAsync(vptr2.data() + 1, d_cnt.p, (size_t)(2 * n_var) * sizeof(int64_t),
                                hipMemcpyDeviceToHost, s));
         VRX_HIP(hipStreamSynchronize(s));
         for (int64_t r = 0; r < 2 * n_var; ++r) vptr2[(size_t)r + 1] += vptr2[(size_t)r];
-        const int64_t vnnz = vptr2[(size_t)(2 * n_var)];
+        vnnz = vptr2[(size_t)(2 * n_var)];
         VRX_HIP(d_vptr2.upload(vptr2.data(), vptr2.size(), s));
         VRX_HIP(d_vidx.alloc((size_t)std::max<int64_t>(vnnz, 1)));
         VRX_HIP(d_vval.alloc((size_t)std::max<int64_t>(vnnz, 1)));
         vrx_virt_fill<<<nbv, VRX_BLOCK, 0, s>>>(n_var, d_rptr.p, d_ridx.p, d_rval.p, d_vptr2.p, d_vidx.p,
                                                 d_vval.p);
         VRX_HIP(hipGetLastError());
+        if (p->want_balance && vnnz > 0) {
+            VRX_HIP(hipStreamSynchronize(s));
+            hv_idx.resize((size_t)vnnz);
+            hv_words.resize((size_t)vnnz);
+            const int dev_id = p->device;
+            helper = std::thread([&, dev_id] {
+                hipStream_t s2 = nullptr;
+                DevBuf<uint8_t> d_words;
+                auto ok = [&](hipError_t e) {
+                    if (e != hipSuccess && helper_err == hipSuccess) helper_err = e;
+                    return e == hipSuccess;
+                };
+                if (ok(hipSetDevice(dev_id)) && ok(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking)) &&
+                    ok(d_words.alloc((size_t)vnnz))) {
+                    vrx_build_words<<<(unsigned)((vnnz + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s2>>>(vnnz, d_vval.p, d_words.p);
+                    ok(hipGetLastError());
+                    ok(hipMemcpyAsync(hv_idx.data(), d_vidx.p, (size_t)vnnz * sizeof(int32_t), hipMemcpyDeviceToHost, s2));
+                    ok(hipMemcpyAsync(hv_words.data(), d_words.p, (size_t)vnnz, hipMemcpyDeviceToHost, s2));
+                    ok(hipStreamSynchronize(s2));
+                }
+                if (s2) (void)hipStreamDestroy(s2);
+            });
+        }
+    }
+    struct JoinGuard {  // (an early return must not leave the helper running on dying buffers)
+        std::thread& t;
+        ~JoinGuard() {
+            if (t.joinable()) t.join();
+        }
+    } join_guard{helper};
+    const HostCounts cell_host{rowidx, ad, dp};
+    rc = build_tiled(p->by_cell, colptr, nullptr, nullptr, rw_cell, slab_cell, guard, cell_form, 1, s,
+                     p->n_cu, &cell_rows, -1, -1, -1, &cell_host);
+    if (rc) return rc;
+    if (var_form == 3) {
+        if (helper.joinable()) helper.join();
+        if (helper_err != hipSuccess) {
+            vrx_set_error("balanced slabs: download of the variant rows failed: %s", hipGetErrorString(helper_err));
+            return VRX_ERR_HIP;
+        }
+        const HostWords virt_host{hv_idx.data(), hv_words.data()};
         const DevRows virt_rows{d_vptr2.p, d_vidx.p, d_vval.p};
         rc = build_tiled(p->by_var, vptr2.data(), nullptr, nullptr, VRX_LDS_RW_CELL, VRX_LDS_SLAB_BYTES / 256,
-                         guard, 1, 0, s, p->n_cu, &virt_rows, 2 * n_var, (n_cell + 1) / 2, vnnz);
+                         guard, 1, 0, s, p->n_cu, &virt_rows, 2 * n_var, (n_cell + 1) / 2, vnnz, nullptr,
+                         hv_idx.empty() ? nullptr : &virt_host);
         if (rc) return rc;
         VRX_HIP(hipStreamSynchronize(s));
     } else {

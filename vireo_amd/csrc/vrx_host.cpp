@@ -1068,3 +1068,124 @@ extern "C" int vrx_mtx_write(const char* path, int64_t n_rows, int64_t n_cols, i
         s.push_back('\n');
     });
 }
+
+
+// ------------------------------------------------------------------------------------
+// Balanced slabs (r6; TiledStream::perm, vrx_problem_create2 + VRX_PROBLEM_BALANCED): which contracted
+// rows share a slab of an LDS-resident pass, for ONE row tile.
+// The padding of a round is the maximum over its 16 rows of their words in ONE slab; which contracted
+// rows share a slab is free per tile.  Greedy: the contracted rows ("columns" of the tile's sub-matrix)
+// most-covered first, each to the slab -- among those with room -- where the sum of the present loads of
+// the tile rows it touches is smallest (ties: the lowest slab); columns without an entry in the tile fill
+// what is left.  Counted on the c3 matrix: 1.62 -> 1.17 executed slots per word.  Deterministic (the result
+// is part of the stream): the int16 and int32 score loops and their AVX2 clones add the same integers.
+// The reference has no counterpart (it multiplies SciPy's CSC / CSR as they are, vireo_model.py:167-196).
+// ------------------------------------------------------------------------------------
+#if defined(__x86_64__) && !defined(__SANITIZE_ADDRESS__) && !defined(__HIP_DEVICE_COMPILE__)  // (host code only)
+#define VRX_SIMD_CLONES __attribute__((target_clones("avx2", "default")))
+#else
+#define VRX_SIMD_CLONES
+#endif
+
+VRX_SIMD_CLONES static void score_rows_i16(const int16_t* load, int nsp, const uint16_t* erow, uint32_t n, int w0,
+                                           int wn, int16_t* sc) {
+    for (int sl = 0; sl < wn; ++sl) sc[sl] = 0;
+    for (uint32_t e = 0; e < n; ++e) {
+        const int16_t* L = load + (size_t)erow[e] * nsp + w0;
+        for (int sl = 0; sl < wn; ++sl) sc[sl] = (int16_t)(sc[sl] + L[sl]);
+    }
+}
+
+VRX_SIMD_CLONES static void score_rows_i32(const int16_t* load, int nsp, const uint16_t* erow, uint32_t n, int w0,
+                                           int wn, int32_t* sc) {
+    for (int sl = 0; sl < wn; ++sl) sc[sl] = 0;
+    for (uint32_t e = 0; e < n; ++e) {
+        const int16_t* L = load + (size_t)erow[e] * nsp + w0;
+        for (int sl = 0; sl < wn; ++sl) sc[sl] += L[sl];
+    }
+}
+
+// rows: the tile's rows (ids into ptr); idx / words: contracted index and FORM 1 word count of every entry;
+// posmap[c] <- slab * slab_rows + slab-local position of contracted row c; perm = its inverse (unused
+// positions name row 0: the pass stages some valid row there and no word refers to it)
+void vrx_balance_tile(const int32_t* rows, int64_t n_rows_tile, const int64_t* ptr, const int32_t* idx,
+                      const uint8_t* words, int64_t n_contract, int n_slab, int slab_rows, int32_t* posmap,
+                      int32_t* perm) {
+    const int64_t NC = n_contract;
+    std::vector<uint32_t> cptr((size_t)NC + 1, 0);
+    for (int64_t i = 0; i < n_rows_tile; ++i)
+        for (int64_t e = ptr[rows[i]]; e < ptr[rows[i] + 1]; ++e)
+            if (words[e] > 0) ++cptr[(size_t)idx[e] + 1];
+    for (int64_t c = 0; c < NC; ++c) cptr[(size_t)c + 1] += cptr[(size_t)c];
+    const size_t ne = cptr[(size_t)NC];
+    std::vector<uint16_t> erow(ne);
+    std::vector<uint8_t> ew(ne);
+    {
+        std::vector<uint32_t> cur(cptr.begin(), cptr.end() - 1);
+        for (int64_t i = 0; i < n_rows_tile; ++i)
+            for (int64_t e = ptr[rows[i]]; e < ptr[rows[i] + 1]; ++e) {
+                if (words[e] == 0) continue;
+                const uint32_t at = cur[(size_t)idx[e]]++;
+                erow[at] = (uint16_t)i;
+                ew[at] = words[e];
+            }
+    }
+    // columns by degree, descending (counting sort, stable in the column index)
+    uint32_t maxdeg = 0;
+    for (int64_t c = 0; c < NC; ++c) maxdeg = std::max(maxdeg, cptr[(size_t)c + 1] - cptr[(size_t)c]);
+    std::vector<uint32_t> dstart((size_t)maxdeg + 2, 0);
+    for (int64_t c = 0; c < NC; ++c) ++dstart[(size_t)(maxdeg - (cptr[(size_t)c + 1] - cptr[(size_t)c])) + 1];
+    for (size_t d = 0; d <= maxdeg; ++d) dstart[d + 1] += dstart[d];
+    std::vector<int32_t> order((size_t)NC);
+    for (int64_t c = 0; c < NC; ++c) order[dstart[(size_t)(maxdeg - (cptr[(size_t)c + 1] - cptr[(size_t)c]))]++] = (int32_t)c;
+    const int nsp = (n_slab + 31) / 32 * 32;
+    std::vector<int16_t> load((size_t)n_rows_tile * (size_t)nsp, 0), score16((size_t)nsp);
+    std::vector<int32_t> score((size_t)nsp), cap((size_t)n_slab, slab_rows), fill((size_t)n_slab, 0);
+    for (int64_t p = 0; p < (int64_t)n_slab * slab_rows; ++p) perm[p] = 0;
+    auto place = [&](int32_t c, int sl) {
+        const int local = fill[(size_t)sl]++;
+        --cap[(size_t)sl];
+        posmap[c] = sl * slab_rows + local;
+        perm[(int64_t)sl * slab_rows + local] = c;
+    };
+    int next_free = 0;
+    int32_t max_load = 0;  // the largest entry of `load` so far: decides whether 16-bit scores cannot overflow
+    for (int64_t k = 0; k < NC; ++k) {
+        const int32_t c = order[(size_t)k];
+        const uint32_t a = cptr[(size_t)c], b = cptr[(size_t)c + 1];
+        if (a == b) {  // no entry in this tile: any slab with room
+            while (cap[(size_t)next_free] == 0) ++next_free;
+            place(c, next_free);
+            continue;
+        }
+        // candidates: every slab while there are at most 256 of them; beyond (problems of 4x c3 and more:
+        // the search is columns x entries x slabs) a window of 64 consecutive slabs at a position hashed from
+        // the column -- every slab sits in many windows, the balance is a little coarser (1.24 instead of
+        // 1.18 executed slots per word at c3's shape), the cost linear in the problem again
+        int w0 = 0, wn = n_slab;
+        if (n_slab > 256) {
+            wn = 64;
+            w0 = (int)(((uint64_t)(uint32_t)c * 2654435761u) % (uint64_t)(n_slab - wn + 1));
+        }
+        int best = -1;
+        if ((int64_t)(b - a) * max_load < 32000) {
+            score_rows_i16(load.data(), nsp, erow.data() + a, b - a, w0, wn, score16.data());
+            for (int sl = 0; sl < wn; ++sl)
+                if (cap[(size_t)(w0 + sl)] > 0 && (best < 0 || score16[(size_t)sl] < score16[(size_t)(best - w0)])) best = w0 + sl;
+        } else {
+            score_rows_i32(load.data(), nsp, erow.data() + a, b - a, w0, wn, score.data());
+            for (int sl = 0; sl < wn; ++sl)
+                if (cap[(size_t)(w0 + sl)] > 0 && (best < 0 || score[(size_t)sl] < score[(size_t)(best - w0)])) best = w0 + sl;
+        }
+        if (best < 0) {  // the window is full: the first slab with room
+            while (cap[(size_t)next_free] == 0) ++next_free;
+            best = next_free;
+        }
+        place(c, best);
+        for (uint32_t e = a; e < b; ++e) {
+            int16_t& L = load[(size_t)erow[e] * nsp + best];
+            L = (int16_t)std::min<int32_t>(L + ew[e], 32000);
+            max_load = std::max<int32_t>(max_load, L);
+        }
+    }
+}
