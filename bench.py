@@ -214,25 +214,45 @@ def c3_skew_leg(device, K, uniform_ms, steps=100):
     rows = np.bincount(w["rowidx"], minlength=N)
     cols = np.diff(w["colptr"])
     max_count = int(w["dp"].max())
-    counts = DeviceCounts.from_merged(w["shape"], w["colptr"], w["rowidx"], w["ad"], w["dp"], device=device)
-    del w
     np.random.seed(1)
     host = Vireo(n_var=N, n_cell=M, n_donor=K)
-    dm = DeviceModel(counts, _lib.KIND_VIREO, K, n_gt=3)
-    dm.set_state(host.ID_prob, host.GT_prob, host.beta_mu, host.beta_sum)
-    dm.set_prior(host.ID_prior, host.GT_prior, host.theta_s1_prior, host.theta_s2_prior)
-    dm.run_iters(50, theta_from_iter=PROTOCOL["delay_fit_theta"])
-    t0 = time.perf_counter()
-    tr, _ = dm.run_iters(steps, theta_from_iter=0)
-    ms_it = (time.perf_counter() - t0) / steps * 1e3
-    if not np.all(np.isfinite(tr)):
-        raise RuntimeError("c3_skew leg: a non-finite ELBO in the timed iterations")
-    dm.profile(True)
-    dm.run_iters(steps, theta_from_iter=0)
-    pm, pn = dm.profile_read()
-    info = dm.info()
-    dm.close()
-    counts.close()
+
+    def measure(balance):
+        t_b = time.perf_counter()
+        counts = DeviceCounts.from_merged(w["shape"], w["colptr"], w["rowidx"], w["ad"], w["dp"], device=device,
+                                          balance=balance)
+        build_s = time.perf_counter() - t_b
+        binfo = counts.build_info()
+        dm = DeviceModel(counts, _lib.KIND_VIREO, K, n_gt=3)
+        dm.set_state(host.ID_prob, host.GT_prob, host.beta_mu, host.beta_sum)
+        dm.set_prior(host.ID_prior, host.GT_prior, host.theta_s1_prior, host.theta_s2_prior)
+        dm.run_iters(50, theta_from_iter=PROTOCOL["delay_fit_theta"])
+        t0 = time.perf_counter()
+        tr, _ = dm.run_iters(steps, theta_from_iter=0)
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        if not np.all(np.isfinite(tr)):
+            raise RuntimeError("c3_skew leg: a non-finite ELBO in the timed iterations")
+        dm.profile(True)
+        dm.run_iters(steps, theta_from_iter=0)
+        pm_, pn_ = dm.profile_read()
+        info_ = dm.info()
+        dm.close()
+        counts.close()
+        return ms, pm_, pn_, info_, binfo, build_s, np.asarray(tr)
+
+    # the default build first (rows cut into pieces, contiguous slabs), then the headline's stream choice
+    d_ms, d_pm, d_pn, d_info, _, d_build_s, d_tr = measure(False)
+    balanced = os.environ.get("VIREO_BALANCE", "1") != "0"
+    if balanced:
+        ms_it, pm, pn, info, binfo, build_s, tr = measure(True)
+    else:
+        ms_it, pm, pn, info, binfo, build_s, tr = d_ms, d_pm, d_pn, d_info, None, d_build_s, d_tr
+    del w
+    default_build = dict(ms_per_iteration=d_ms, pad_variant=d_info["pad_variant"], pad_cell=d_info["pad_cell"],
+                         passes_ms={"variant_pass": d_pm[0] / max(d_pn[0], 1), "cell_pass": d_pm[1] / max(d_pn[1], 1),
+                                    "dense_kernels": d_pm[2] / steps},
+                         build_s=round(d_build_s, 3),
+                         elbo_rel_diff_to_balanced=float(np.max(np.abs(tr - d_tr) / np.abs(d_tr))))
     B = algorithmic_bytes(N, M, K, 3, nnz)
     return dict(workload="c3 shape, log-normal coverage / depth (sigma %.1f / %.1f): nnz=%d, entries per "
                          "variant %d..%d (median %d), per cell %d..%d (median %d), largest count %d; "
@@ -247,7 +267,10 @@ def c3_skew_leg(device, K, uniform_ms, steps=100):
                 pad_variant=info["pad_variant"], pad_cell=info["pad_cell"],
                 extra_pieces_variant=info["extra_pieces_variant"], extra_pieces_cell=info["extra_pieces_cell"],
                 imbalance_variant=info["imbalance_variant"], imbalance_cell=info["imbalance_cell"],
-                lds_passes=bool(info["lds_variant"] and info["lds_cell"]), kernel_info=info)
+                lds_passes=bool(info["lds_variant"] and info["lds_cell"]), kernel_info=info,
+                stream="balanced slabs, the pieces of long rows as the unit" if balanced and binfo and binfo["balanced_cell"]
+                else "default build",
+                build_info=binfo, build_s=round(build_s, 3), default_build=default_build)
 
 
 FLAG_PATHS = ("ase", "fixedGT", "priorGT", "fixsum")

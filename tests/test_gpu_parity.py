@@ -1244,3 +1244,65 @@ def test_balanced_slabs_small_problem_vs_oracle_and_default_build(va, monkeypatc
     close(dbl, dbl_ref)
     close(sing, sing_ref)
     close(llr, llr_ref, atol=1e-9)
+
+
+def test_balanced_slabs_with_rows_cut_into_pieces(va, monkeypatch):
+    """Balanced slabs on a heavy-tailed problem: long rows are cut into pieces (the default rule), the pieces
+    of one row may sit in different row tiles, and each piece is relabelled by ITS tile's permutation
+    (vrx_build_pieces: the pieces become rows of their own before the relabel).  Both streams split rows and
+    are balanced, a whole fit is within 1e-5 of the oracle with identical iteration count and assignments,
+    within summation-order distance of the default build, and deterministic."""
+    from vireo_amd.counts import DeviceCounts
+    from vireo_amd.engine import DeviceModel
+    from vireo_amd import _lib
+    monkeypatch.setenv("VIREO_LDS", "1")
+    monkeypatch.setenv("VIREO_BUILD", "device")
+    rng = np.random.default_rng(11)
+    N, M, K = 2600, 2300, 6
+    cov_v = np.exp(rng.normal(0.0, 1.2, N))[:, None]
+    cov_c = np.exp(rng.normal(0.0, 1.0, M))[None, :]
+    p = np.minimum(0.9, 0.025 * cov_v * cov_c / (cov_v.mean() * cov_c.mean()))
+    dp = (rng.random((N, M)) < p) * (1 + rng.poisson(1.5, (N, M)))
+    z = rng.integers(0, K, M)
+    gt = rng.integers(0, 3, (N, K))
+    ad = rng.binomial(dp, np.array([0.01, 0.5, 0.99])[gt][:, z])
+    AD, DP = csc_matrix(ad), csc_matrix(dp)
+    cb, cd = DeviceCounts(AD, DP, balance=True), DeviceCounts(AD, DP, balance=False)
+    ib = cb.build_info()
+    assert ib["balanced_variant"] and ib["balanced_cell"] and ib["device_built"]
+    kb, kd = DeviceModel(cb, _lib.KIND_VIREO, K).info(), DeviceModel(cd, _lib.KIND_VIREO, K).info()
+    assert kb["lds_variant"] and kb["lds_cell"]
+    assert kb["extra_pieces_variant"] > 0 and kb["extra_pieces_cell"] > 0, kb
+    assert kb["pad_cell"] < kd["pad_cell"] and kb["pad_variant"] < kd["pad_variant"]
+    print("rows cut into pieces: +%d / +%d; stream slots per non-zero: balanced %.3f / %.3f, default %.3f / %.3f"
+          % (kb["extra_pieces_variant"], kb["extra_pieces_cell"], kb["pad_variant"], kb["pad_cell"],
+             kd["pad_variant"], kd["pad_cell"]))
+    assert DeviceCounts(AD, DP, balance=True).digest() == cb.digest()
+    monkeypatch.setenv("VIREO_BALANCE_SPLIT", "0")          # the knob that keeps such streams on the default build
+    assert not DeviceCounts(AD, DP, balance=True).build_info()["balanced_cell"]
+    monkeypatch.delenv("VIREO_BALANCE_SPLIT")
+
+    def fit(counts, **kw):
+        np.random.seed(4)
+        m = va.Vireo(n_var=N, n_cell=M, n_donor=K, **kw)
+        m.fit(counts, None, min_iter=5, max_iter=25, delay_fit_theta=2, verbose=False)
+        return m
+
+    for kw in (dict(), dict(ASE_mode=True)):
+        a, a2, d = fit(cb, **kw), fit(cb, **kw), fit(cd, **kw)
+        for name in ("ELBO_", "ID_prob", "GT_prob", "beta_mu", "beta_sum"):
+            assert np.array_equal(getattr(a, name), getattr(a2, name)), name
+        np.random.seed(4)
+        ref = O.vireo_new(M, N, K, **kw)
+        O.vireo_fit(ref, AD, DP, min_iter=5, max_iter=25, delay_fit_theta=2)
+        assert len(a.ELBO_) == len(ref.ELBO_) == len(d.ELBO_)
+        close(a.ELBO_, ref.ELBO_)
+        close(a.ID_prob, ref.ID_prob)
+        close(a.GT_prob, ref.GT_prob)
+        close(a.beta_mu, ref.beta_mu)
+        close(a.beta_sum, ref.beta_sum)
+        sure = np.sort(ref.ID_prob, axis=1)[:, -1] - np.sort(ref.ID_prob, axis=1)[:, -2] > 1e-6   # (cells without
+        assert sure.sum() > 0.9 * M                                    # reads keep the flat prior: a tie)
+        assert np.array_equal(a.ID_prob.argmax(1)[sure], ref.ID_prob.argmax(1)[sure])
+        np.testing.assert_allclose(a.ELBO_, d.ELBO_, rtol=1e-10)
+        np.testing.assert_allclose(a.ID_prob, d.ID_prob, rtol=1e-7, atol=1e-290)

@@ -235,6 +235,34 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_build_relabel(int64_t nnz, int6
     vals[e] = (uint32_t)e;
 }
 
+// Rows that were cut into pieces, as rows of their own: entry k of a row with P pieces belongs to piece
+// k % P and is that piece's entry k / P (`pptr` = the pieces' row pointer, from the host).  Balanced slabs
+// relabel the entries of a piece by the permutation of the piece's TILE, and the pieces of one row may sit
+// in different tiles.
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_build_pieces(int64_t nnz, int64_t n_rows,
+                                                              const int64_t* __restrict__ ptr,
+                                                              const int32_t* __restrict__ vptr,
+                                                              const int64_t* __restrict__ pptr,
+                                                              const int32_t* __restrict__ idx,
+                                                              const int2* __restrict__ val,
+                                                              int32_t* __restrict__ idx_p, int2* __restrict__ val_p) {
+    const int64_t e = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    if (e >= nnz) return;
+    int64_t lo = 0, hi = n_rows;  // the last row with ptr[row] <= e
+    while (lo < hi) {
+        const int64_t mid = (lo + hi + 1) >> 1;
+        if (ptr[mid] <= e)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const int64_t k = e - ptr[lo];
+    const int32_t v0 = vptr[lo], P = vptr[lo + 1] - v0;
+    const int64_t at = pptr[v0 + (int32_t)(k % P)] + k / P;
+    idx_p[at] = idx[e];
+    val_p[at] = val[e];
+}
+
 // FORM 1 words of every entry (what the host-side balancing needs besides the index)
 __global__ __launch_bounds__(VRX_BLOCK) void vrx_build_words(int64_t nnz, const int2* __restrict__ val,
                                                              uint8_t* __restrict__ words) {

@@ -598,8 +598,11 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
         DevBuf<int2> d_val2;
         t.balanced = false;
         t.perm.release();
-        if (form == 1 && !t.split && t.want_balance && t.n_slab > 1 &&
-            o_n_contract < ((int64_t)1 << 24) && o_n_rows < ((int64_t)1 << 31)) {
+        DevBuf<int64_t> d_pptr;       // (split rows: the pieces as rows of their own, see vrx_build_pieces)
+        DevBuf<int32_t> d_pidx, d_iota;
+        DevBuf<int2> d_pval;
+        if (form == 1 && t.want_balance && t.n_slab > 1 && o_n_contract < ((int64_t)1 << 24) &&
+            n_vrows < ((int64_t)1 << 31) && (!t.split || env_int("VIREO_BALANCE_SPLIT", 1) != 0)) {
             const int64_t tile_pos = (int64_t)VRX_LDS_WAVES * RW, slots = (int64_t)t.n_slab * slab_rows;
             const bool timing = env_int("VIREO_BUILD_TIMING", 0) != 0;
             auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -617,22 +620,54 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
             // (vrx_build_words) come back from the device
             std::vector<int32_t> h_idx;
             std::vector<uint8_t> h_words;
+            // Rows cut into pieces (heavy-tailed data): the unit of everything below is the PIECE -- its
+            // entries are copied out as a row of their own (entry k of the row -> piece k % P), so that
+            // every unit belongs to exactly one tile and is relabelled by that tile's permutation
+            const bool pieces = t.split;
+            std::vector<int64_t> pptr;
+            const int64_t* u_ptr = ptr;         // row pointer of the units (host) ...
+            const int64_t* du_ptr = dev->ptr;   // ... and on the device, with their entries
+            const int32_t* du_idx = dev->idx;
+            const int2* du_val = dev->val;
+            const int64_t n_unit_rows = pieces ? n_vrows : o_n_rows;
+            if (pieces) {
+                pptr.assign((size_t)n_vrows + 1, 0);
+                for (int64_t r = 0; r < o_n_rows; ++r) {
+                    const int64_t L = ptr[r + 1] - ptr[r];
+                    const int32_t v0 = vptr[(size_t)r], P = vptr[(size_t)r + 1] - v0;
+                    for (int32_t q = 0; q < P; ++q) pptr[(size_t)(v0 + q) + 1] = (L - q + P - 1) / P;
+                }
+                for (int64_t v = 0; v < n_vrows; ++v) pptr[(size_t)v + 1] += pptr[(size_t)v];
+                VRX_HIP(d_pptr.upload(pptr.data(), pptr.size(), s));
+                VRX_HIP(d_pidx.alloc((size_t)o_nnz));
+                VRX_HIP(d_pval.alloc((size_t)o_nnz));
+                vrx_build_pieces<<<(unsigned)((o_nnz + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
+                    o_nnz, o_n_rows, dev->ptr, d_vptr.p, d_pptr.p, dev->idx, dev->val, d_pidx.p, d_pval.p);
+                VRX_HIP(hipGetLastError());
+                u_ptr = pptr.data();
+                du_ptr = d_pptr.p;
+                du_idx = d_pidx.p;
+                du_val = d_pval.p;
+                hc = nullptr;  // (the caller's arrays are the whole rows)
+                hw = nullptr;
+            }
             if (!hc && !hw) {
                 DevBuf<uint8_t> d_words;
                 VRX_HIP(d_words.alloc((size_t)o_nnz));
-                vrx_build_words<<<(unsigned)((o_nnz + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(o_nnz, dev->val, d_words.p);
+                vrx_build_words<<<(unsigned)((o_nnz + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(o_nnz, du_val, d_words.p);
                 VRX_HIP(hipGetLastError());
                 h_idx.resize((size_t)o_nnz);
                 h_words.resize((size_t)o_nnz);
-                VRX_HIP(hipMemcpyAsync(h_idx.data(), dev->idx, (size_t)o_nnz * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                VRX_HIP(hipMemcpyAsync(h_idx.data(), du_idx, (size_t)o_nnz * sizeof(int32_t), hipMemcpyDeviceToHost, s));
                 VRX_HIP(hipMemcpyAsync(h_words.data(), d_words.p, (size_t)o_nnz, hipMemcpyDeviceToHost, s));
                 VRX_HIP(hipStreamSynchronize(s));
             }
             lap("download rows");
             std::vector<int32_t> posmap((size_t)(t.n_tile * o_n_contract)), perm((size_t)(t.n_tile * slots));
-            std::vector<int32_t> tile_of_row((size_t)o_n_rows, -1);
+            std::vector<int32_t> tile_of_row((size_t)n_unit_rows, -1);
+            auto unit_of = [&](int32_t v) { return pieces ? v : vrow_row[(size_t)v]; };
             for (int64_t pos = 0; pos < (int64_t)t.n_tile * tile_pos; ++pos)
-                if (rowmap[(size_t)pos] >= 0) tile_of_row[(size_t)vrow_row[(size_t)rowmap[(size_t)pos]]] = (int32_t)(pos / tile_pos);
+                if (rowmap[(size_t)pos] >= 0) tile_of_row[(size_t)unit_of(rowmap[(size_t)pos])] = (int32_t)(pos / tile_pos);
             if (hc) {  // the caller's counts: one byte per entry, on all host threads
                 h_words.resize((size_t)o_nnz);
                 parallel_chunks(o_nnz, host_threads(), [&](int64_t e0, int64_t e1, int) {
@@ -650,8 +685,8 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
                 for (int64_t tl = next_tile++; tl < t.n_tile; tl = next_tile++) {
                     rows.clear();
                     for (int64_t pos = tl * tile_pos; pos < (tl + 1) * tile_pos; ++pos)
-                        if (rowmap[(size_t)pos] >= 0) rows.push_back(vrow_row[(size_t)rowmap[(size_t)pos]]);
-                    vrx_balance_tile(rows.data(), (int64_t)rows.size(), ptr, g_idx, g_words, o_n_contract,
+                        if (rowmap[(size_t)pos] >= 0) rows.push_back(unit_of(rowmap[(size_t)pos]));
+                    vrx_balance_tile(rows.data(), (int64_t)rows.size(), u_ptr, g_idx, g_words, o_n_contract,
                                      t.n_slab, slab_rows, posmap.data() + tl * o_n_contract, perm.data() + tl * slots);
                 }
             });
@@ -669,9 +704,9 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
             VRX_HIP(v_out.alloc((size_t)o_nnz));
             const unsigned nbe = (unsigned)((o_nnz + VRX_BLOCK - 1) / VRX_BLOCK);
             int rbits = 1, pbits = 1;  // key = row << pbits | position: as few radix passes as the sizes need
-            while (((int64_t)1 << rbits) < o_n_rows) ++rbits;
+            while (((int64_t)1 << rbits) < n_unit_rows) ++rbits;
             while (((int64_t)1 << pbits) < std::max<int64_t>(slots, o_n_contract)) ++pbits;
-            vrx_build_relabel<<<nbe, VRX_BLOCK, 0, s>>>(o_nnz, o_n_rows, o_n_contract, dev->ptr, dev->idx,
+            vrx_build_relabel<<<nbe, VRX_BLOCK, 0, s>>>(o_nnz, n_unit_rows, o_n_contract, du_ptr, du_idx,
                                                         d_tile_of_row.p, d_posmap.p, pbits, k_in.p, v_in.p);
             VRX_HIP(hipGetLastError());
             size_t tmp_bytes = 0;
@@ -683,9 +718,20 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
                                                        (size_t)o_nnz, 0, pbits + rbits, s));
             VRX_HIP(d_idx2.alloc((size_t)o_nnz));
             VRX_HIP(d_val2.alloc((size_t)o_nnz));
-            vrx_build_relabel_gather<<<nbe, VRX_BLOCK, 0, s>>>(o_nnz, k_out.p, v_out.p, dev->val, pbits, d_idx2.p, d_val2.p);
+            vrx_build_relabel_gather<<<nbe, VRX_BLOCK, 0, s>>>(o_nnz, k_out.p, v_out.p, du_val, pbits, d_idx2.p, d_val2.p);
             VRX_HIP(hipGetLastError());
+            if (pieces) {  // the stream's rows are the pieces now: one piece per "row", nothing left to cut
+                std::vector<int32_t> iota((size_t)n_vrows + 1);
+                for (int64_t v = 0; v <= n_vrows; ++v) iota[(size_t)v] = (int32_t)v;
+                VRX_HIP(d_iota.upload(iota.data(), iota.size(), s));
+                VRX_HIP(hipStreamSynchronize(s));
+                A.ptr = d_pptr.p;
+                A.vptr = d_iota.p;
+                A.vrow_row = d_iota.p;
+            }
             VRX_HIP(hipStreamSynchronize(s));
+            d_pidx.release();
+            d_pval.release();
             lap("upload + relabel + sort");
             t.balance_seconds = now() - tm_begin;
             A.idx = d_idx2.p;
