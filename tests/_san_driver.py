@@ -122,10 +122,58 @@ def mtx_fuzz(L, tmp):
     print("mtx fuzz: %d parsed like scipy, %d rejected with a status" % (n_ok, n_err))
 
 
+def balance_tiles(lib_path):
+    """vrx_balance_tile (the per-tile greedy of the balanced-slab build; a C++ symbol of the host unit, called
+    by the device builder only): random tiles through both record widths (<= 2048 rows and counts of < 32
+    words, else 32-bit records), the 16- and 32-bit score paths, the hashed window (> 256 slabs), empty
+    columns, rows outside the tile.  posmap / perm must be inverse of each other, no slab over its capacity,
+    and the row-slab loads flatter than contiguous slabs."""
+    import subprocess
+    import numpy as np
+    names = [l.split()[-1] for l in subprocess.run(["nm", "-D", lib_path], capture_output=True, text=True,
+                                                   check=True).stdout.splitlines() if "vrx_balance_tile" in l]
+    assert len(names) == 1, names
+    fn = getattr(C.CDLL(lib_path), names[0])
+    fn.restype = None
+    vp = C.c_void_p
+    fn.argtypes = [vp, C.c_int64, vp, vp, vp, C.c_int64, C.c_int, C.c_int, vp, vp]
+    rng = np.random.default_rng(9)
+    n_cases = 0
+    for (n_all, n_tile, NC, S, dens, wmax) in ((300, 200, 700, 64, 0.05, 3), (2500, 2300, 900, 64, 0.02, 3),
+                                               (150, 150, 600, 32, 0.2, 60), (64, 48, 9000, 32, 0.05, 2),
+                                               (40, 40, 100, 512, 0.3, 2), (500, 400, 1000, 16, 0.9, 200)):
+        mask = rng.random((n_all, NC)) < dens
+        mask[:, rng.integers(0, NC, NC // 10)] = False                    # columns without an entry
+        ptr = np.zeros(n_all + 1, np.int64)
+        np.cumsum(mask.sum(1), out=ptr[1:])
+        idx = np.nonzero(mask)[1].astype(np.int32)
+        words = rng.integers(0, wmax + 1, idx.size).astype(np.uint8)      # (0: an entry without words)
+        rows = np.sort(rng.choice(n_all, n_tile, replace=False)).astype(np.int32)
+        n_slab = -(-NC // S)
+        posmap = np.full(NC, -1, np.int32)
+        perm = np.full(n_slab * S, -1, np.int32)
+        fn(rows.ctypes.data, n_tile, ptr.ctypes.data, idx.ctypes.data, words.ctypes.data, NC, n_slab, S,
+           posmap.ctypes.data, perm.ctypes.data)
+        assert np.array_equal(np.sort(posmap), np.unique(posmap)) and posmap.min() >= 0 and posmap.max() < n_slab * S
+        assert np.array_equal(perm[posmap], np.arange(NC))
+        assert np.bincount(posmap // S, minlength=n_slab).max() <= S
+
+        def spread(slab_of):
+            load = np.zeros((n_tile, n_slab))
+            for i, r in enumerate(rows):
+                e = slice(ptr[r], ptr[r + 1])
+                np.add.at(load[i], slab_of[idx[e]], words[e])
+            return load.std()
+        assert spread(posmap // S) <= spread(np.arange(NC) // S) + 1e-9
+        n_cases += 1
+    print("balance tiles: %d cases" % n_cases)
+
+
 def main(lib_path, tmp):
     L, bound = bind(lib_path)
     assert "vrx_mtx_read" in bound and "vrx_model_fit" not in bound
     mtx_fuzz(L, tmp)
+    balance_tiles(lib_path)
     import pytest
     keep = ("merge_counts or generator_jump or legacy_stream_continues or fast_generator or "
             "float32_sum or native_text_writers or donor_genotype_codes")

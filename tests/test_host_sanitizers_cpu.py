@@ -44,4 +44,4 @@ def test_host_translation_unit_under_asan_ubsan(tmp_path):
     report = p.stdout[-3000:] + "\n" + p.stderr[-6000:]
     assert "AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, report
     assert p.returncode == 0, report
-    assert "mtx fuzz:" in p.stdout
+    assert "mtx fuzz:" in p.stdout and "balance tiles: 6 cases" in p.stdout

@@ -1087,48 +1087,78 @@ extern "C" int vrx_mtx_write(const char* path, int64_t n_rows, int64_t n_cols, i
 #define VRX_SIMD_CLONES
 #endif
 
-VRX_SIMD_CLONES static void score_rows_i16(const int16_t* load, int nsp, const uint16_t* erow, uint32_t n, int w0,
-                                           int wn, int16_t* sc) {
-    for (int sl = 0; sl < wn; ++sl) sc[sl] = 0;
+// score[sl] = sum over the column's rows of load[row][w0 + sl], then the first slab with room and the smallest
+// score (-1: none has room).  The sums are formed a block of slabs at a time with the block in registers
+// (the rows of `load` are read once per block: the matrix is L2-resident, the accumulators never leave the
+// registers); `full` holds all-ones for a slab without room, OR-ed in before the minimum.
+// An entry of a column is one record: row inside the tile in the low RB bits, its word count above.
+template <class ACC, int B, class E, int RB>
+static inline __attribute__((always_inline)) void score_block(const int16_t* load, int nsp, const E* ent,
+                                                              uint32_t n, int at, ACC* sc) {
+    ACC acc[B];
+    for (int k = 0; k < B; ++k) acc[k] = 0;
     for (uint32_t e = 0; e < n; ++e) {
-        const int16_t* L = load + (size_t)erow[e] * nsp + w0;
-        for (int sl = 0; sl < wn; ++sl) sc[sl] = (int16_t)(sc[sl] + L[sl]);
+        const int16_t* L = load + (size_t)(ent[e] & ((1u << RB) - 1)) * nsp + at;
+        for (int k = 0; k < B; ++k) acc[k] = (ACC)(acc[k] + L[k]);
     }
+    for (int k = 0; k < B; ++k) sc[k] = acc[k];
 }
 
-VRX_SIMD_CLONES static void score_rows_i32(const int16_t* load, int nsp, const uint16_t* erow, uint32_t n, int w0,
-                                           int wn, int32_t* sc) {
-    for (int sl = 0; sl < wn; ++sl) sc[sl] = 0;
-    for (uint32_t e = 0; e < n; ++e) {
-        const int16_t* L = load + (size_t)erow[e] * nsp + w0;
-        for (int sl = 0; sl < wn; ++sl) sc[sl] += L[sl];
+template <class ACC, class E, int RB>
+static inline __attribute__((always_inline)) int best_slab(const int16_t* load, int nsp, const E* ent,
+                                                           uint32_t n, int w0, int wn, const ACC* full, ACC* sc) {
+    int sl = 0;  // (wn is a multiple of 32: nsp is, and a window is 64)
+    for (; sl + 128 <= wn; sl += 128) score_block<ACC, 128, E, RB>(load, nsp, ent, n, w0 + sl, sc + sl);
+    for (; sl + 64 <= wn; sl += 64) score_block<ACC, 64, E, RB>(load, nsp, ent, n, w0 + sl, sc + sl);
+    for (; sl + 32 <= wn; sl += 32) score_block<ACC, 32, E, RB>(load, nsp, ent, n, w0 + sl, sc + sl);
+    for (; sl < wn; ++sl) {
+        ACC a = 0;
+        for (uint32_t e = 0; e < n; ++e) a = (ACC)(a + load[(size_t)(ent[e] & ((1u << RB) - 1)) * nsp + w0 + sl]);
+        sc[sl] = a;
     }
+    const ACC none = (ACC)(sizeof(ACC) == 2 ? 0x7fff : 0x7fffffff);
+    ACC m = none;
+    for (int k = 0; k < wn; ++k) {
+        sc[k] = (ACC)(sc[k] | full[w0 + k]);
+        m = sc[k] < m ? sc[k] : m;
+    }
+    if (m == none) return -1;
+    for (int k = 0; k < wn; ++k)
+        if (sc[k] == m) return w0 + k;
+    return -1;
 }
 
-// rows: the tile's rows (ids into ptr); idx / words: contracted index and FORM 1 word count of every entry;
-// posmap[c] <- slab * slab_rows + slab-local position of contracted row c; perm = its inverse (unused
-// positions name row 0: the pass stages some valid row there and no word refers to it)
-void vrx_balance_tile(const int32_t* rows, int64_t n_rows_tile, const int64_t* ptr, const int32_t* idx,
-                      const uint8_t* words, int64_t n_contract, int n_slab, int slab_rows, int32_t* posmap,
-                      int32_t* perm) {
+#define VRX_BEST_SLAB(NAME, ACC, E, RB)                                                                        \
+    VRX_SIMD_CLONES static int NAME(const int16_t* load, int nsp, const E* ent, uint32_t n, int w0, int wn,        \
+                                    const ACC* full, ACC* sc) {                                                    \
+        return best_slab<ACC, E, RB>(load, nsp, ent, n, w0, wn, full, sc);                                         \
+    }
+VRX_BEST_SLAB(best_slab_i16_e16, int16_t, uint16_t, 11)
+VRX_BEST_SLAB(best_slab_i32_e16, int32_t, uint16_t, 11)
+VRX_BEST_SLAB(best_slab_i16_e32, int16_t, uint32_t, 16)
+VRX_BEST_SLAB(best_slab_i32_e32, int32_t, uint32_t, 16)
+#undef VRX_BEST_SLAB
+static int best_slab_of(const int16_t* load, int nsp, const uint16_t* ent, uint32_t n, int w0, int wn,
+                        const int16_t* full, int16_t* sc) { return best_slab_i16_e16(load, nsp, ent, n, w0, wn, full, sc); }
+static int best_slab_of(const int16_t* load, int nsp, const uint16_t* ent, uint32_t n, int w0, int wn,
+                        const int32_t* full, int32_t* sc) { return best_slab_i32_e16(load, nsp, ent, n, w0, wn, full, sc); }
+static int best_slab_of(const int16_t* load, int nsp, const uint32_t* ent, uint32_t n, int w0, int wn,
+                        const int16_t* full, int16_t* sc) { return best_slab_i16_e32(load, nsp, ent, n, w0, wn, full, sc); }
+static int best_slab_of(const int16_t* load, int nsp, const uint32_t* ent, uint32_t n, int w0, int wn,
+                        const int32_t* full, int32_t* sc) { return best_slab_i32_e32(load, nsp, ent, n, w0, wn, full, sc); }
+
+template <class E, int RB>
+static void balance_tile(const int32_t* rows, int64_t n_rows_tile, const int64_t* ptr, const int32_t* idx,
+                         const uint8_t* words, int64_t n_contract, int n_slab, int slab_rows, int32_t* posmap,
+                         int32_t* perm, std::vector<uint32_t>& cptr) {
     const int64_t NC = n_contract;
-    std::vector<uint32_t> cptr((size_t)NC + 1, 0);
-    for (int64_t i = 0; i < n_rows_tile; ++i)
-        for (int64_t e = ptr[rows[i]]; e < ptr[rows[i] + 1]; ++e)
-            if (words[e] > 0) ++cptr[(size_t)idx[e] + 1];
-    for (int64_t c = 0; c < NC; ++c) cptr[(size_t)c + 1] += cptr[(size_t)c];
     const size_t ne = cptr[(size_t)NC];
-    std::vector<uint16_t> erow(ne);
-    std::vector<uint8_t> ew(ne);
+    std::vector<E> ent(ne);  // the tile's entries, column by column
     {
         std::vector<uint32_t> cur(cptr.begin(), cptr.end() - 1);
         for (int64_t i = 0; i < n_rows_tile; ++i)
-            for (int64_t e = ptr[rows[i]]; e < ptr[rows[i] + 1]; ++e) {
-                if (words[e] == 0) continue;
-                const uint32_t at = cur[(size_t)idx[e]]++;
-                erow[at] = (uint16_t)i;
-                ew[at] = words[e];
-            }
+            for (int64_t e = ptr[rows[i]]; e < ptr[rows[i] + 1]; ++e)
+                if (words[e] != 0) ent[cur[(size_t)idx[e]]++] = (E)((uint32_t)i | (uint32_t)words[e] << RB);
     }
     // columns by degree, descending (counting sort, stable in the column index)
     uint32_t maxdeg = 0;
@@ -1139,12 +1169,19 @@ void vrx_balance_tile(const int32_t* rows, int64_t n_rows_tile, const int64_t* p
     std::vector<int32_t> order((size_t)NC);
     for (int64_t c = 0; c < NC; ++c) order[dstart[(size_t)(maxdeg - (cptr[(size_t)c + 1] - cptr[(size_t)c]))]++] = (int32_t)c;
     const int nsp = (n_slab + 31) / 32 * 32;
-    std::vector<int16_t> load((size_t)n_rows_tile * (size_t)nsp, 0), score16((size_t)nsp);
-    std::vector<int32_t> score((size_t)nsp), cap((size_t)n_slab, slab_rows), fill((size_t)n_slab, 0);
+    std::vector<int16_t> load((size_t)n_rows_tile * (size_t)nsp, 0), score16((size_t)nsp), full16((size_t)nsp, 0);
+    std::vector<int32_t> score((size_t)nsp), full32((size_t)nsp, 0), cap((size_t)n_slab, slab_rows), fill((size_t)n_slab, 0);
+    for (int sl = n_slab; sl < nsp; ++sl) {  // (the padding slabs of the last block never have room)
+        full16[(size_t)sl] = 0x7fff;
+        full32[(size_t)sl] = 0x7fffffff;
+    }
     for (int64_t p = 0; p < (int64_t)n_slab * slab_rows; ++p) perm[p] = 0;
     auto place = [&](int32_t c, int sl) {
         const int local = fill[(size_t)sl]++;
-        --cap[(size_t)sl];
+        if (--cap[(size_t)sl] == 0) {
+            full16[(size_t)sl] = 0x7fff;
+            full32[(size_t)sl] = 0x7fffffff;
+        }
         posmap[c] = sl * slab_rows + local;
         perm[(int64_t)sl * slab_rows + local] = c;
     };
@@ -1162,30 +1199,43 @@ void vrx_balance_tile(const int32_t* rows, int64_t n_rows_tile, const int64_t* p
         // the search is columns x entries x slabs) a window of 64 consecutive slabs at a position hashed from
         // the column -- every slab sits in many windows, the balance is a little coarser (1.24 instead of
         // 1.18 executed slots per word at c3's shape), the cost linear in the problem again
-        int w0 = 0, wn = n_slab;
+        int w0 = 0, wn = nsp;
         if (n_slab > 256) {
             wn = 64;
             w0 = (int)(((uint64_t)(uint32_t)c * 2654435761u) % (uint64_t)(n_slab - wn + 1));
         }
-        int best = -1;
-        if ((int64_t)(b - a) * max_load < 32000) {
-            score_rows_i16(load.data(), nsp, erow.data() + a, b - a, w0, wn, score16.data());
-            for (int sl = 0; sl < wn; ++sl)
-                if (cap[(size_t)(w0 + sl)] > 0 && (best < 0 || score16[(size_t)sl] < score16[(size_t)(best - w0)])) best = w0 + sl;
-        } else {
-            score_rows_i32(load.data(), nsp, erow.data() + a, b - a, w0, wn, score.data());
-            for (int sl = 0; sl < wn; ++sl)
-                if (cap[(size_t)(w0 + sl)] > 0 && (best < 0 || score[(size_t)sl] < score[(size_t)(best - w0)])) best = w0 + sl;
-        }
+        int best = (int64_t)(b - a) * max_load < 32000
+                       ? best_slab_of(load.data(), nsp, ent.data() + a, b - a, w0, wn, full16.data(), score16.data())
+                       : best_slab_of(load.data(), nsp, ent.data() + a, b - a, w0, wn, full32.data(), score.data());
         if (best < 0) {  // the window is full: the first slab with room
             while (cap[(size_t)next_free] == 0) ++next_free;
             best = next_free;
         }
         place(c, best);
         for (uint32_t e = a; e < b; ++e) {
-            int16_t& L = load[(size_t)erow[e] * nsp + best];
-            L = (int16_t)std::min<int32_t>(L + ew[e], 32000);
+            int16_t& L = load[(size_t)(ent[e] & ((1u << RB) - 1)) * nsp + best];
+            L = (int16_t)std::min<int32_t>(L + (int32_t)(ent[e] >> RB), 32000);
             max_load = std::max<int32_t>(max_load, L);
         }
     }
+}
+
+// rows: the tile's rows (ids into ptr); idx / words: contracted index and FORM 1 word count of every entry;
+// posmap[c] <- slab * slab_rows + slab-local position of contracted row c; perm = its inverse (unused
+// positions name row 0: the pass stages some valid row there and no word refers to it)
+void vrx_balance_tile(const int32_t* rows, int64_t n_rows_tile, const int64_t* ptr, const int32_t* idx,
+                      const uint8_t* words, int64_t n_contract, int n_slab, int slab_rows, int32_t* posmap,
+                      int32_t* perm) {
+    std::vector<uint32_t> cptr((size_t)n_contract + 1, 0);
+    uint8_t wmax = 0;
+    for (int64_t i = 0; i < n_rows_tile; ++i)
+        for (int64_t e = ptr[rows[i]]; e < ptr[rows[i] + 1]; ++e) {
+            cptr[(size_t)idx[e] + 1] += words[e] != 0;
+            wmax = std::max(wmax, words[e]);
+        }
+    for (int64_t c = 0; c < n_contract; ++c) cptr[(size_t)c + 1] += cptr[(size_t)c];
+    if (n_rows_tile <= 2048 && wmax < 32)  // (a 96-row tile and counts below 2^30: always)
+        balance_tile<uint16_t, 11>(rows, n_rows_tile, ptr, idx, words, n_contract, n_slab, slab_rows, posmap, perm, cptr);
+    else
+        balance_tile<uint32_t, 16>(rows, n_rows_tile, ptr, idx, words, n_contract, n_slab, slab_rows, posmap, perm, cptr);
 }
