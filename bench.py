@@ -88,6 +88,11 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def stream_choice():
+    """the headline problem's build: balanced slabs unless VIREO_BALANCE=0 (a traffic record names its own)"""
+    return "balanced slabs" if os.environ.get("VIREO_BALANCE", "1") != "0" else "default build"
+
+
 def cpu_protocol_leg(w, K, seed):
     """the whole timing protocol on the oracle (1 core), from the same initial state"""
     from oracle import vireo_oracle as O
@@ -850,10 +855,16 @@ def main():
         if kname and os.path.exists(tpath):
             doc = json.load(open(tpath))
             rec = doc.get("kernels", {}).get(kname)
-            if rec and doc.get("kernel_source_hash") == kernel_source_hash():
+            same_stream = args.config != "c3" or doc.get("stream") == stream_choice()
+            if rec and doc.get("kernel_source_hash") == kernel_source_hash() and same_stream:
                 traffic = rec["traffic_bytes"]
                 traffic_src = ("profiles/traffic_%s.json (rocprofv3 --pmc FETCH_SIZE x2 + "
-                               "WRITE_SIZE, kernel sources %s)" % (args.config, kernel_source_hash()))
+                               "WRITE_SIZE, kernel sources %s%s)"
+                               % (args.config, kernel_source_hash(),
+                                  ", " + doc["stream"] if doc.get("stream") else ""))
+            elif rec and not same_stream:
+                traffic_src = ("profiles/traffic_%s.json was collected on the other stream build (%s): "
+                               "not quoted" % (args.config, doc.get("stream")))
             elif rec:
                 traffic_src = ("profiles/traffic_%s.json was collected on other kernel sources "
                                "(%s, now %s): not quoted" % (args.config, doc.get("kernel_source_hash"),

@@ -57,7 +57,7 @@ for k, c in vals.items():
     kernels[k] = dict(FETCH_SIZE_KiB=fetch, WRITE_SIZE_KiB=write, launches=len(c["FETCH_SIZE"]),
                       traffic_bytes=int(2 * fetch * 1024 + write * 1024))
 doc = dict(_comment=__doc__.split("\n\n")[1].replace("\n", " "), config=config,
-           kernel_source_hash=bench.kernel_source_hash(), kernels=kernels)
-path = os.path.join(ROOT, "profiles", "traffic_%s.json" % config)
+           kernel_source_hash=bench.kernel_source_hash(), stream=bench.stream_choice(), kernels=kernels)
+path = os.environ.get("VIREO_TRAFFIC_OUT") or os.path.join(ROOT, "profiles", "traffic_%s.json" % config)
 json.dump(doc, open(path, "w"), indent=1)
 print(json.dumps(doc, indent=1))

@@ -31,6 +31,8 @@ mkdir -p /tmp/pmc_sq_all && cp -r /tmp/pmc_sq_1 /tmp/pmc_sq_2 /tmp/pmc_sq_all/ 2
 python $REPO/scratch/pmc_summary.py /tmp/pmc_sq_all > $OUT/${TAG}_c3_pmc_sq.txt
 cd $REPO && timeout 900 python scratch/collect_traffic.py c3 > $OUT/${TAG}_traffic_c3.log 2>&1
 cp profiles/traffic_c3.json $OUT/traffic_c3.json
+# the default build's stream beside it (contiguous slabs; not the record bench.py quotes)
+cd $REPO && VIREO_BALANCE=0 VIREO_TRAFFIC_OUT=$OUT/traffic_c3_default_build.json timeout 900 python scratch/collect_traffic.py c3 > $OUT/${TAG}_traffic_c3_default_build.log 2>&1
 cd $REPO && timeout 900 python scratch/collect_traffic.py c5 > $OUT/${TAG}_traffic_c5.log 2>&1
 cp profiles/traffic_c5.json $OUT/traffic_c5.json
 ls -la $OUT
