@@ -125,7 +125,7 @@ def mtx_fuzz(L, tmp):
 def balance_tiles(lib_path):
     """vrx_balance_tile (the per-tile greedy of the balanced-slab build; a C++ symbol of the host unit, called
     by the device builder only): random tiles through both record widths (<= 2048 rows and counts of < 32
-    words, else 32-bit records), the 16- and 32-bit score paths, the hashed window (> 256 slabs), empty
+    words, else 32-bit records), the 16- and 32-bit score paths, the aligned blocks of 64 slabs (>= 128 slabs), empty
     columns, rows outside the tile.  posmap / perm must be inverse of each other, no slab over its capacity,
     and the row-slab loads flatter than contiguous slabs."""
     import subprocess

@@ -801,13 +801,13 @@ def test_rccl_init_watchdog_ends_a_rank_that_hangs(tmp_path):
 
 def test_balance_policy_order_of_precedence(monkeypatch):
     """Balanced slabs are a build option: the caller's word first, then VIREO_BALANCE, then the
-    announced number of iterations against VIREO_BALANCE_MIN_ITERS (default 4000)."""
+    announced number of iterations against VIREO_BALANCE_MIN_ITERS (default 2500)."""
     from vireo_amd.counts import balance_policy
     monkeypatch.delenv("VIREO_BALANCE", raising=False)
     monkeypatch.delenv("VIREO_BALANCE_MIN_ITERS", raising=False)
     assert balance_policy() is False
     assert balance_policy(expected_iterations=1200) is False       # vireo's defaults: 50 x 20 + 200
-    assert balance_policy(expected_iterations=4000) is True
+    assert balance_policy(expected_iterations=2500) is True
     assert balance_policy(balance=False, expected_iterations=10 ** 6) is False
     assert balance_policy(balance=True) is True
     monkeypatch.setenv("VIREO_BALANCE_MIN_ITERS", "1000")

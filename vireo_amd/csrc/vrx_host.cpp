@@ -1107,10 +1107,11 @@ static inline __attribute__((always_inline)) void score_block(const int16_t* loa
 template <class ACC, class E, int RB>
 static inline __attribute__((always_inline)) int best_slab(const int16_t* load, int nsp, const E* ent,
                                                            uint32_t n, int w0, int wn, const ACC* full, ACC* sc) {
-    int sl = 0;  // (wn is a multiple of 32: nsp is, and a window is 64)
+    int sl = 0;
     for (; sl + 128 <= wn; sl += 128) score_block<ACC, 128, E, RB>(load, nsp, ent, n, w0 + sl, sc + sl);
     for (; sl + 64 <= wn; sl += 64) score_block<ACC, 64, E, RB>(load, nsp, ent, n, w0 + sl, sc + sl);
     for (; sl + 32 <= wn; sl += 32) score_block<ACC, 32, E, RB>(load, nsp, ent, n, w0 + sl, sc + sl);
+    for (; sl + 8 <= wn; sl += 8) score_block<ACC, 8, E, RB>(load, nsp, ent, n, w0 + sl, sc + sl);
     for (; sl < wn; ++sl) {
         ACC a = 0;
         for (uint32_t e = 0; e < n; ++e) a = (ACC)(a + load[(size_t)(ent[e] & ((1u << RB) - 1)) * nsp + w0 + sl]);
@@ -1169,6 +1170,7 @@ static void balance_tile(const int32_t* rows, int64_t n_rows_tile, const int64_t
     std::vector<int32_t> order((size_t)NC);
     for (int64_t c = 0; c < NC; ++c) order[dstart[(size_t)(maxdeg - (cptr[(size_t)c + 1] - cptr[(size_t)c]))]++] = (int32_t)c;
     const int nsp = (n_slab + 31) / 32 * 32;
+    static const int block = getenv("VIREO_BALANCE_BLOCK") ? atoi(getenv("VIREO_BALANCE_BLOCK")) : 64;
     std::vector<int16_t> load((size_t)n_rows_tile * (size_t)nsp, 0), score16((size_t)nsp), full16((size_t)nsp, 0);
     std::vector<int32_t> score((size_t)nsp), full32((size_t)nsp, 0), cap((size_t)n_slab, slab_rows), fill((size_t)n_slab, 0);
     for (int sl = n_slab; sl < nsp; ++sl) {  // (the padding slabs of the last block never have room)
@@ -1195,14 +1197,17 @@ static void balance_tile(const int32_t* rows, int64_t n_rows_tile, const int64_t
             place(c, next_free);
             continue;
         }
-        // candidates: every slab while there are at most 256 of them; beyond (problems of 4x c3 and more:
-        // the search is columns x entries x slabs) a window of 64 consecutive slabs at a position hashed from
-        // the column -- every slab sits in many windows, the balance is a little coarser (1.24 instead of
-        // 1.18 executed slots per word at c3's shape), the cost linear in the problem again
+        // candidates: the slabs of the column's own aligned block of 64 slabs (the last block takes the
+        // remainder, up to 127).  Measured at c3 (196 slabs in the cell orientation): the whole range gives
+        // 1.185 executed slots per word, blocks of 64 give 1.225 -- and the same pass time, because the
+        // workgroups of a launch then stage their slabs out of the same 8-MB stretch of the operand at the
+        // same time (blocks of 32 / 16 / 8: 1.26 / 1.30 / 1.35, passes 1-5 % slower); the search is linear
+        // in the problem at any size.  VIREO_BALANCE_BLOCK=n: blocks of n slabs, <= 0: the whole range.
         int w0 = 0, wn = nsp;
-        if (n_slab > 256) {
-            wn = 64;
-            w0 = (int)(((uint64_t)(uint32_t)c * 2654435761u) % (uint64_t)(n_slab - wn + 1));
+        if (block > 0 && n_slab >= 2 * block) {
+            const int nb = n_slab / block, bi = std::min((int)(c / slab_rows) / block, nb - 1);
+            w0 = bi * block;
+            wn = bi == nb - 1 ? nsp - w0 : block;
         }
         int best = (int64_t)(b - a) * max_load < 32000
                        ? best_slab_of(load.data(), nsp, ent.data() + a, b - a, w0, wn, full16.data(), score16.data())
