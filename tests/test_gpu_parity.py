@@ -1210,6 +1210,9 @@ def test_balanced_slabs_small_problem_vs_oracle_and_default_build(va, monkeypatc
     print("stream slots per non-zero: balanced %.3f / %.3f, default %.3f / %.3f (variant / cell)"
           % (kb["pad_variant"], kb["pad_cell"], kd["pad_variant"], kd["pad_cell"]))
     assert build(True).digest() == cb.digest()
+    monkeypatch.setenv("VIREO_BALANCE_EARLY", "0")         # the cell orientation's greedy inside build_tiled
+    assert build(True).digest() == cb.digest()             # instead of beside the upload: the same stream
+    monkeypatch.delenv("VIREO_BALANCE_EARLY")
 
     def fit(counts, **kw):
         np.random.seed(4)

@@ -71,6 +71,13 @@ static int host_threads() {
     return n;
 }
 
+// the per-tile greedy of the balanced-slab build is compute in a core's own L2: it takes more threads
+static int balance_threads() {
+    const char* v = getenv("VIREO_HOST_THREADS");
+    if (v && *v) return host_threads();
+    return (int)std::min(128u, std::max(1u, std::thread::hardware_concurrency()));
+}
+
 // uninitialised host array (a std::vector would zero hundreds of MB on one thread first)
 template <class T>
 struct RawArray {
@@ -445,30 +452,50 @@ void vrx_balance_tile(const int32_t* rows, int64_t n_rows_tile, const int64_t* p
                       const uint8_t* words, int64_t n_contract, int n_slab, int slab_rows, int32_t* posmap,
                       int32_t* perm);
 
-static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const int2* val,
-                       int RW, int slab_rows, bool guard, int form, int mode, hipStream_t s,
-                       int n_cu, const DevRows* dev = nullptr, int64_t virt_rows = -1,
-                       int64_t virt_contract = -1, int64_t virt_nnz = -1, const HostCounts* hc = nullptr,
-                       const HostWords* hw = nullptr) {
-    constexpr int G = 64 / VRX_LDS_LPE, U = VRX_LDS_U;
-    const int NR = RW / G;
-    TiledStream& t = o.tiled;
-    // (virt_rows >= 0: ptr / idx / val are the VIRTUAL rows of the variant pass, vrx_build.h)
-    t.virt = virt_rows >= 0;
-    const int64_t o_n_rows = t.virt ? virt_rows : o.n_rows;
-    const int64_t o_n_contract = t.virt ? virt_contract : o.n_contract;
-    const int64_t o_nnz = t.virt ? virt_nnz : o.nnz;
-    t.n_contract = o_n_contract;
-    t.form = form;
-    t.rw = RW;
-    t.slab_rows = slab_rows;
-    t.n_slab = (int)((o_n_contract + slab_rows - 1) / slab_rows);
+// The host half of a tiled stream that needs nothing but the row pointer: the pieces long rows are cut
+// into, the tile / slab geometry, and which piece sits at which tile position.  A function of its own so
+// that device_build can run it -- and the balanced-slab greedy behind it -- on a helper thread while the
+// counts are still being uploaded and transposed.
+struct TileLayout {
+    // what it was computed for
+    const int64_t* ptr = nullptr;
+    int64_t n_rows = -1, n_contract = -1, nnz = -1;
+    int RW = 0, slab_rows_in = 0, form = -1, n_cu = -1;
+    // the layout
+    std::vector<int32_t> vptr, vrow_row, split_rows, rowmap;
+    int64_t n_vrows = 0;
+    bool split = false;
+    int n_tile = 0, n_slab = 0, slab_rows = 0;
+    // balanced slabs, when the greedy already ran (cell orientation, from the caller's arrays)
+    bool greedy_done = false;
+    std::vector<int32_t> posmap, perm, tile_of_row;
+    double greedy_seconds = 0.0;
+    bool matches(const int64_t* p, int64_t nr, int64_t nc, int64_t nz, int rw, int sr, int f, int cu) const {
+        return ptr == p && n_rows == nr && n_contract == nc && nnz == nz && RW == rw && slab_rows_in == sr &&
+               form == f && n_cu == cu;
+    }
+};
+
+static int tile_layout(TileLayout& L, const int64_t* ptr, int64_t o_n_rows, int64_t o_n_contract, int64_t o_nnz,
+                       int RW, int slab_rows, int form, int n_cu) {
+    constexpr int G = 64 / VRX_LDS_LPE;
+    L.ptr = ptr;
+    L.n_rows = o_n_rows;
+    L.n_contract = o_n_contract;
+    L.nnz = o_nnz;
+    L.RW = RW;
+    L.slab_rows_in = slab_rows;
+    L.form = form;
+    L.n_cu = n_cu;
+    L.slab_rows = slab_rows;
+    L.n_slab = (int)((o_n_contract + slab_rows - 1) / slab_rows);
     // ---- pieces ------------------------------------------------------------------------
     const double mean = (double)o_nnz / (double)std::max<int64_t>(o_n_rows, 1);
     const int64_t cap = std::max<int64_t>(
         64, (int64_t)(mean * (double)env_int("VIREO_LDS_SPLIT_X10", 20) / 10.0 + 0.5));
     const bool reorder = env_int("VIREO_LDS_SORT", 1) != 0;
-    std::vector<int32_t> vptr((size_t)o_n_rows + 1, 0);
+    std::vector<int32_t>& vptr = L.vptr;
+    vptr.assign((size_t)o_n_rows + 1, 0);
     for (int64_t r = 0; r < o_n_rows; ++r) {
         const int64_t len = ptr[r + 1] - ptr[r];
         const int64_t P = reorder ? std::max<int64_t>(1, (len + cap - 1) / cap) : 1;
@@ -479,17 +506,18 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
         vptr[(size_t)r + 1] = vptr[(size_t)r] + (int32_t)P;
     }
     const int64_t n_vrows = vptr[(size_t)o_n_rows];
-    t.n_vrows = n_vrows;
-    t.split = n_vrows != o_n_rows;
-    std::vector<int32_t> split_rows;  // rows cut into several pieces: folded by vrx_fold_split
+    L.n_vrows = n_vrows;
+    L.split = n_vrows != o_n_rows;
+    std::vector<int32_t>& split_rows = L.split_rows;  // rows cut into several pieces: folded by vrx_fold_split
+    split_rows.clear();
     for (int64_t r = 0; r < o_n_rows; ++r)
         if (vptr[(size_t)r + 1] - vptr[(size_t)r] > 1) split_rows.push_back((int32_t)r);
-    t.n_split = (int64_t)split_rows.size();
-    std::vector<int32_t> vrow_row((size_t)n_vrows);
+    std::vector<int32_t>& vrow_row = L.vrow_row;
+    vrow_row.assign((size_t)n_vrows, 0);
     for (int64_t r = 0; r < o_n_rows; ++r)
         for (int32_t v = vptr[(size_t)r]; v < vptr[(size_t)r + 1]; ++v) vrow_row[(size_t)v] = (int32_t)r;
     const int64_t tile_rows = VRX_LDS_WAVES * (int64_t)RW;
-    t.n_tile = (int)((n_vrows + tile_rows - 1) / tile_rows);
+    L.n_tile = (int)((n_vrows + tile_rows - 1) / tile_rows);
     // Coarse shapes (clone mode: a few hundred variants, 10^5 cells): the (tile, slab) visits
     // are what the work list deals to the CUs, and a visit is not divisible.
     //  * fewer visits than CUs: shorter slabs, until every CU has one (c5 variant pass: ONE tile
@@ -499,28 +527,24 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
     //    (c5 cell pass: 196 full tiles of 1024 cells -> 256 tiles of 782).
     if (n_cu > 0 && env_int("VIREO_LDS_FILL_CUS", 1) != 0) {
         auto spread_tiles = [&]() {  // (tiles must keep >= 4 rows per wave on average)
-            const int64_t visits = (int64_t)t.n_tile * t.n_slab, rounds = (visits + n_cu - 1) / n_cu;
-            const int64_t nt = rounds * n_cu / t.n_slab;
-            if (nt > t.n_tile && nt * VRX_LDS_WAVES * G <= std::max<int64_t>(n_vrows, 1) * 4) t.n_tile = (int)nt;
+            const int64_t visits = (int64_t)L.n_tile * L.n_slab, rounds = (visits + n_cu - 1) / n_cu;
+            const int64_t nt = rounds * n_cu / L.n_slab;
+            if (nt > L.n_tile && nt * VRX_LDS_WAVES * G <= std::max<int64_t>(n_vrows, 1) * 4) L.n_tile = (int)nt;
         };
-        if (t.n_slab <= 2) spread_tiles();
-        if ((int64_t)t.n_tile * t.n_slab < n_cu) {
-            const int64_t want = (n_cu + t.n_tile - 1) / t.n_tile;
+        if (L.n_slab <= 2) spread_tiles();
+        if ((int64_t)L.n_tile * L.n_slab < n_cu) {
+            const int64_t want = (n_cu + L.n_tile - 1) / L.n_tile;
             const int64_t sr = std::min<int64_t>(slab_rows, std::max<int64_t>(64, ((o_n_contract + want - 1) / want + 15) / 16 * 16));
             slab_rows = (int)sr;
-            t.slab_rows = slab_rows;
-            t.n_slab = (int)((o_n_contract + slab_rows - 1) / slab_rows);
-            if ((int64_t)t.n_tile * t.n_slab < n_cu) spread_tiles();
+            L.slab_rows = slab_rows;
+            L.n_slab = (int)((o_n_contract + slab_rows - 1) / slab_rows);
+            if ((int64_t)L.n_tile * L.n_slab < n_cu) spread_tiles();
         }
     }
-    const int64_t n_wave = (int64_t)t.n_tile * VRX_LDS_WAVES;
-    const int PH = form == 2 ? 2 : 1;  // phases of a round (form 2: AD entries, then BD entries)
-    const int64_t per_wave = (int64_t)t.n_slab * NR * PH + 1;
-    std::vector<int64_t> wave_start((size_t)n_wave), wave_len((size_t)n_wave, 0);
-    std::vector<int32_t> bnd((size_t)(n_wave * per_wave));
-    std::atomic<bool> too_long{false};
+    const int64_t n_wave = (int64_t)L.n_tile * VRX_LDS_WAVES;
     // ---- tile position -> piece (-1 = padding position) ---------------------------------
-    std::vector<int32_t> rowmap((size_t)(n_wave * RW), -1);
+    std::vector<int32_t>& rowmap = L.rowmap;
+    rowmap.assign((size_t)(n_wave * RW), -1);
     {
         std::vector<int32_t> order((size_t)n_vrows);
         for (int64_t v = 0; v < n_vrows; ++v) order[(size_t)v] = (int32_t)v;
@@ -540,6 +564,99 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
                 rowmap[(size_t)(w * RW + j * G + g)] = order[(size_t)(u * G + g)];
         }
     }
+    L.slab_rows = slab_rows;
+    return VRX_OK;
+}
+
+// The greedy of every tile (vrx_balance_tile), tiles in parallel: the tile of every unit (row, or piece where
+// rows are cut), posmap / perm per tile.  `unit_ptr`, `idx`, `words`: the units' entries on the host.
+static void greedy_tiles(const TileLayout& L, bool pieces, const int64_t* unit_ptr, const int32_t* idx,
+                         const uint8_t* words, int64_t n_unit_rows, std::vector<int32_t>& posmap,
+                         std::vector<int32_t>& perm, std::vector<int32_t>& tile_of_row) {
+    const int64_t tile_pos = (int64_t)VRX_LDS_WAVES * L.RW, slots = (int64_t)L.n_slab * L.slab_rows;
+    const int64_t n_contract = L.n_contract;
+    posmap.resize((size_t)(L.n_tile * n_contract));
+    perm.resize((size_t)(L.n_tile * slots));
+    tile_of_row.assign((size_t)n_unit_rows, -1);
+    auto unit_of = [&](int32_t v) { return pieces ? v : L.vrow_row[(size_t)v]; };
+    for (int64_t pos = 0; pos < (int64_t)L.n_tile * tile_pos; ++pos)
+        if (L.rowmap[(size_t)pos] >= 0) tile_of_row[(size_t)unit_of(L.rowmap[(size_t)pos])] = (int32_t)(pos / tile_pos);
+    std::atomic<int64_t> next_tile{0};  // (tiles cost about the same: first come, first served)
+    parallel_chunks(std::min<int64_t>(L.n_tile, balance_threads()), balance_threads(), [&](int64_t, int64_t, int) {
+        std::vector<int32_t> rows;
+        for (int64_t tl = next_tile++; tl < L.n_tile; tl = next_tile++) {
+            rows.clear();
+            for (int64_t pos = tl * tile_pos; pos < (tl + 1) * tile_pos; ++pos)
+                if (L.rowmap[(size_t)pos] >= 0) rows.push_back(unit_of(L.rowmap[(size_t)pos]));
+            vrx_balance_tile(rows.data(), (int64_t)rows.size(), unit_ptr, idx, words, n_contract, L.n_slab,
+                             L.slab_rows, posmap.data() + tl * n_contract, perm.data() + tl * slots);
+        }
+    });
+}
+
+// one byte per entry: the FORM 1 words of the caller's (ad, dp), on all host threads; false if an index is
+// outside [0, n_contract) (the caller's arrays may not have been validated yet)
+static bool host_words(const HostCounts& hc, int64_t nnz, int64_t n_contract, std::vector<uint8_t>& words) {
+    words.resize((size_t)nnz);
+    std::atomic<bool> bad{false};
+    parallel_chunks(nnz, host_threads(), [&](int64_t e0, int64_t e1, int) {
+        bool b = false;
+        for (int64_t e = e0; e < e1; ++e) {
+            b |= hc.idx[e] < 0 || hc.idx[e] >= n_contract;
+            words[(size_t)e] = (uint8_t)std::min(words_of_count(hc.ad[e]) + words_of_count((int64_t)hc.dp[e] - hc.ad[e]), 255);
+        }
+        if (b) bad = true;
+    });
+    return !bad;
+}
+
+// may this layout be balanced on the host from the caller's arrays alone?  (the same conditions build_tiled
+// applies; pieces need the device's copy of the rows)
+static bool host_balance_applies(const TileLayout& L) {
+    return L.form == 1 && L.n_slab > 1 && L.n_contract < ((int64_t)1 << 24) && L.n_vrows < ((int64_t)1 << 31) && !L.split;
+}
+
+static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const int2* val,
+                       int RW, int slab_rows, bool guard, int form, int mode, hipStream_t s,
+                       int n_cu, const DevRows* dev = nullptr, int64_t virt_rows = -1,
+                       int64_t virt_contract = -1, int64_t virt_nnz = -1, const HostCounts* hc = nullptr,
+                       const HostWords* hw = nullptr, TileLayout* pre = nullptr) {
+    constexpr int G = 64 / VRX_LDS_LPE, U = VRX_LDS_U;
+    const int NR = RW / G;
+    TiledStream& t = o.tiled;
+    // (virt_rows >= 0: ptr / idx / val are the VIRTUAL rows of the variant pass, vrx_build.h)
+    t.virt = virt_rows >= 0;
+    const int64_t o_n_rows = t.virt ? virt_rows : o.n_rows;
+    const int64_t o_n_contract = t.virt ? virt_contract : o.n_contract;
+    const int64_t o_nnz = t.virt ? virt_nnz : o.nnz;
+    t.n_contract = o_n_contract;
+    t.form = form;
+    t.rw = RW;
+    t.slab_rows = slab_rows;
+    t.n_slab = (int)((o_n_contract + slab_rows - 1) / slab_rows);
+    // ---- pieces, tile / slab geometry, tile position -> piece (tile_layout) ---------------------
+    TileLayout own_layout;
+    const bool have_pre = pre && pre->matches(ptr, o_n_rows, o_n_contract, o_nnz, RW, slab_rows, form, n_cu);
+    TileLayout& L = have_pre ? *pre : own_layout;
+    if (!have_pre) {
+        const int rc_layout = tile_layout(L, ptr, o_n_rows, o_n_contract, o_nnz, RW, slab_rows, form, n_cu);
+        if (rc_layout) return rc_layout;
+    }
+    std::vector<int32_t>&vptr = L.vptr, &vrow_row = L.vrow_row, &split_rows = L.split_rows, &rowmap = L.rowmap;
+    const int64_t n_vrows = L.n_vrows;
+    t.n_vrows = n_vrows;
+    t.split = L.split;
+    t.n_split = (int64_t)split_rows.size();
+    t.n_tile = L.n_tile;
+    slab_rows = L.slab_rows;
+    t.slab_rows = slab_rows;
+    t.n_slab = L.n_slab;
+    const int64_t n_wave = (int64_t)t.n_tile * VRX_LDS_WAVES;
+    const int PH = form == 2 ? 2 : 1;  // phases of a round (form 2: AD entries, then BD entries)
+    const int64_t per_wave = (int64_t)t.n_slab * NR * PH + 1;
+    std::vector<int64_t> wave_start((size_t)n_wave), wave_len((size_t)n_wave, 0);
+    std::vector<int32_t> bnd((size_t)(n_wave * per_wave));
+    std::atomic<bool> too_long{false};
     // One wave's stream: walks its RW pieces slab by slab, records the (slab, round) offsets
     // and appends the words to the wave's own buffer.  Waves are independent.
     const bool parity_order = env_int("VIREO_LDS_PARITY", 1) != 0;
@@ -651,7 +768,7 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
                 hc = nullptr;  // (the caller's arrays are the whole rows)
                 hw = nullptr;
             }
-            if (!hc && !hw) {
+            if (!hc && !hw && !(have_pre && L.greedy_done && !pieces)) {
                 DevBuf<uint8_t> d_words;
                 VRX_HIP(d_words.alloc((size_t)o_nnz));
                 vrx_build_words<<<(unsigned)((o_nnz + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(o_nnz, du_val, d_words.p);
@@ -663,33 +780,18 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
                 VRX_HIP(hipStreamSynchronize(s));
             }
             lap("download rows");
-            std::vector<int32_t> posmap((size_t)(t.n_tile * o_n_contract)), perm((size_t)(t.n_tile * slots));
-            std::vector<int32_t> tile_of_row((size_t)n_unit_rows, -1);
-            auto unit_of = [&](int32_t v) { return pieces ? v : vrow_row[(size_t)v]; };
-            for (int64_t pos = 0; pos < (int64_t)t.n_tile * tile_pos; ++pos)
-                if (rowmap[(size_t)pos] >= 0) tile_of_row[(size_t)unit_of(rowmap[(size_t)pos])] = (int32_t)(pos / tile_pos);
-            if (hc) {  // the caller's counts: one byte per entry, on all host threads
-                h_words.resize((size_t)o_nnz);
-                parallel_chunks(o_nnz, host_threads(), [&](int64_t e0, int64_t e1, int) {
-                    for (int64_t e = e0; e < e1; ++e)
-                        h_words[(size_t)e] = (uint8_t)std::min(
-                            words_of_count(hc->ad[e]) + words_of_count((int64_t)hc->dp[e] - hc->ad[e]), 255);
-                });
+            std::vector<int32_t> posmap_own, perm_own, tile_of_row_own;
+            const bool pre_done = have_pre && L.greedy_done && !pieces;  // device_build's helper thread already did it
+            if (!pre_done) {
+                if (hc) (void)host_words(*hc, o_nnz, o_n_contract, h_words);  // (validated by now)
+                const int32_t* g_idx = hc ? hc->idx : hw ? hw->idx : h_idx.data();
+                const uint8_t* g_words = hw ? hw->words : h_words.data();
+                greedy_tiles(L, pieces, u_ptr, g_idx, g_words, n_unit_rows, posmap_own, perm_own, tile_of_row_own);
             }
-            const int32_t* g_idx = hc ? hc->idx : hw ? hw->idx : h_idx.data();
-            const uint8_t* g_words = hw ? hw->words : h_words.data();
-            // tiles in parallel, the most expensive first is not needed: they cost the same
-            std::atomic<int64_t> next_tile{0};
-            parallel_chunks(std::min<int64_t>(t.n_tile, host_threads()), host_threads(), [&](int64_t, int64_t, int) {
-                std::vector<int32_t> rows;
-                for (int64_t tl = next_tile++; tl < t.n_tile; tl = next_tile++) {
-                    rows.clear();
-                    for (int64_t pos = tl * tile_pos; pos < (tl + 1) * tile_pos; ++pos)
-                        if (rowmap[(size_t)pos] >= 0) rows.push_back(unit_of(rowmap[(size_t)pos]));
-                    vrx_balance_tile(rows.data(), (int64_t)rows.size(), u_ptr, g_idx, g_words, o_n_contract,
-                                     t.n_slab, slab_rows, posmap.data() + tl * o_n_contract, perm.data() + tl * slots);
-                }
-            });
+            std::vector<int32_t>&posmap = pre_done ? L.posmap : posmap_own, &perm = pre_done ? L.perm : perm_own,
+                                &tile_of_row = pre_done ? L.tile_of_row : tile_of_row_own;
+            if (pre_done && timing)
+                fprintf(stderr, "[vrx build] balanced slabs (mode %d): greedy ran beside the upload     %.3f s (hidden)\n", mode, L.greedy_seconds);
             lap("greedy (host threads)");
             std::vector<int32_t>().swap(h_idx);
             std::vector<uint8_t>().swap(h_words);
@@ -1039,6 +1141,46 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
             vrx_set_error("vrx_problem_create: colptr not monotone at column %lld", (long long)c);
             return VRX_ERR_ARG;
         }
+    const bool timing = env_int("VIREO_BUILD_TIMING", 0) != 0;
+    auto wall = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double lap_t = wall();
+    auto lap = [&](const char* what) {  // (VIREO_BUILD_TIMING=1: where a device build spends its wall clock)
+        if (!timing) return;
+        (void)hipStreamSynchronize(s);
+        const double t1 = wall();
+        fprintf(stderr, "[vrx build] device_build: %-36s %.3f s\n", what, t1 - lap_t);
+        lap_t = t1;
+    };
+    struct JoinGuard {  // (an early return must not leave a helper thread running on dying buffers)
+        std::thread& t;
+        ~JoinGuard() {
+            if (t.joinable()) t.join();
+        }
+    };
+    // Balanced slabs: the cell orientation's layout and greedy need nothing but the caller's arrays -- they
+    // run on a helper thread (and its own pool of host threads) from here on, beside the upload, the
+    // validation and the transposition on the device.  Used by build_tiled if the layout it asks for is
+    // this one (a count >= 2048 can still change the stream form below; then it is simply recomputed).
+    TileLayout cell_layout;
+    std::thread early;
+    if (p->want_balance && forms.cell == 1 && env_int("VIREO_BALANCE_EARLY", 1) != 0) {
+        const int rw0 = rw_cell, form0 = forms.cell;
+        early = std::thread([&, rw0, form0] {
+            const auto t0 = std::chrono::steady_clock::now();
+            TileLayout& L = cell_layout;
+            if (tile_layout(L, colptr, n_cell, n_var, nnz, rw0, slab_cell, form0, p->n_cu) != VRX_OK) {
+                L.ptr = nullptr;  // (matches nothing: build_tiled computes -- and reports -- by itself)
+                return;
+            }
+            if (!host_balance_applies(L)) return;
+            std::vector<uint8_t> words;
+            if (!host_words(HostCounts{rowidx, ad, dp}, nnz, n_var, words)) return;  // (the validation will say why)
+            greedy_tiles(L, false, colptr, rowidx, words.data(), n_cell, L.posmap, L.perm, L.tile_of_row);
+            L.greedy_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            L.greedy_done = true;
+        });
+    }
+    JoinGuard early_guard{early};
     DevBuf<int64_t> d_colptr, d_rptr;
     DevBuf<int32_t> d_row, d_ad, d_dp, d_ecol, d_nvars, d_status, d_ridx;
     DevBuf<int2> d_cval, d_rval;
@@ -1080,6 +1222,7 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
     const int var_form = forms.var, cell_form = forms.cell;
     // (pair words hold 11-bit counts; a forced pair form leaves such data to the host builder)
     if ((var_form < 2 || cell_form != 1) && max_count >= 2048) return VRX_OK;
+    lap("upload + validate");
     // ---- transposition: stable sort of (variant, entry) ---------------------------------------
     VRX_HIP(keys_in.alloc((size_t)nnz));
     VRX_HIP(keys_out.alloc((size_t)nnz));
@@ -1147,6 +1290,7 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
     if ((rc = set_orient(p->by_var, n_var, n_cell, d_ridx.p, d_rval.p))) return rc;
     const DevRows cell_rows{d_colptr.p, d_row.p, d_cval.p}, var_rows{d_rptr.p, d_ridx.p, d_rval.p};
     p->by_cell.tiled.want_balance = p->by_var.tiled.want_balance = p->want_balance;
+    lap("transposition");
     // the variant pass on virtual rows (vrx_build.h): derived FIRST, so that -- balanced slabs -- their
     // indices and word counts can travel to the host on a second stream while the host balances the cell
     // orientation (the greedy of vrx_balance_tile reads both orientations' entries on the host)
@@ -1200,18 +1344,18 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
             });
         }
     }
-    struct JoinGuard {  // (an early return must not leave the helper running on dying buffers)
-        std::thread& t;
-        ~JoinGuard() {
-            if (t.joinable()) t.join();
-        }
-    } join_guard{helper};
+    JoinGuard join_guard{helper};
     const HostCounts cell_host{rowidx, ad, dp};
+    lap("virtual rows");
+    if (early.joinable()) early.join();
+    lap("wait for the early cell greedy");
     rc = build_tiled(p->by_cell, colptr, nullptr, nullptr, rw_cell, slab_cell, guard, cell_form, 1, s,
-                     p->n_cu, &cell_rows, -1, -1, -1, &cell_host);
+                     p->n_cu, &cell_rows, -1, -1, -1, &cell_host, nullptr, &cell_layout);
     if (rc) return rc;
     if (var_form == 3) {
+        lap("cell stream");
         if (helper.joinable()) helper.join();
+        lap("wait for the variant rows' download");
         if (helper_err != hipSuccess) {
             vrx_set_error("balanced slabs: download of the variant rows failed: %s", hipGetErrorString(helper_err));
             return VRX_ERR_HIP;
@@ -1245,6 +1389,7 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
         }
         return VRX_OK;
     }
+    lap("variant stream");
     *built = true;
     return VRX_OK;
 }
