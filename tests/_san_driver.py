@@ -125,7 +125,7 @@ def mtx_fuzz(L, tmp):
 def balance_tiles(lib_path):
     """vrx_balance_tile (the per-tile greedy of the balanced-slab build; a C++ symbol of the host unit, called
     by the device builder only): random tiles through both record widths (<= 2048 rows and counts of < 32
-    words, else 32-bit records), the 16- and 32-bit score paths, the aligned blocks of 64 slabs (>= 128 slabs), empty
+    words, else 32-bit records), the 16- and 32-bit score paths, blocks of at most 64 slabs and the whole range, empty
     columns, rows outside the tile.  posmap / perm must be inverse of each other, no slab over its capacity,
     and the row-slab loads flatter than contiguous slabs."""
     import subprocess
@@ -136,7 +136,7 @@ def balance_tiles(lib_path):
     fn = getattr(C.CDLL(lib_path), names[0])
     fn.restype = None
     vp = C.c_void_p
-    fn.argtypes = [vp, C.c_int64, vp, vp, vp, C.c_int64, C.c_int, C.c_int, vp, vp]
+    fn.argtypes = [vp, C.c_int64, vp, vp, vp, C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp]
     rng = np.random.default_rng(9)
     n_cases = 0
     for (n_all, n_tile, NC, S, dens, wmax) in ((300, 200, 700, 64, 0.05, 3), (2500, 2300, 900, 64, 0.02, 3),
@@ -153,7 +153,7 @@ def balance_tiles(lib_path):
         posmap = np.full(NC, -1, np.int32)
         perm = np.full(n_slab * S, -1, np.int32)
         fn(rows.ctypes.data, n_tile, ptr.ctypes.data, idx.ctypes.data, words.ctypes.data, NC, n_slab, S,
-           posmap.ctypes.data, perm.ctypes.data)
+           64 if n_cases % 2 == 0 else 0, posmap.ctypes.data, perm.ctypes.data)
         assert np.array_equal(np.sort(posmap), np.unique(posmap)) and posmap.min() >= 0 and posmap.max() < n_slab * S
         assert np.array_equal(perm[posmap], np.arange(NC))
         assert np.bincount(posmap // S, minlength=n_slab).max() <= S

@@ -21,6 +21,7 @@
 #pragma once
 
 #include <hipcub/hipcub.hpp>
+#include "vrx_balance.h"
 
 #include "vrx_common.h"
 #include "vrx_kernels.h"
@@ -281,6 +282,279 @@ __global__ __launch_bounds__(VRX_BLOCK) void vrx_build_relabel_gather(int64_t nn
     if (q >= nnz) return;
     idx2[q] = (int32_t)(keys[q] & (((uint64_t)1 << pbits) - 1));
     val2[q] = val[perm[q]];
+}
+
+// ---- balanced slabs: the per-tile greedy on the device (rule: vrx_balance.h; specification: the host's
+// vrx_balance_tile, against which VIREO_BALANCE_CHECK=1 compares it bit for bit) ----------------------
+// (1) one key per entry: tile << cbits | contracted index; value = position of its unit (row or piece) inside
+//     the tile | words << 16.  Entries without words, or of a unit in no tile, sort behind everything
+//     (tile index n_tile).
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_bal_keys(int64_t nnz, int64_t n_units,
+                                                          const int64_t* __restrict__ ptr,
+                                                          const int32_t* __restrict__ idx,
+                                                          const int2* __restrict__ val,
+                                                          const int32_t* __restrict__ tpos_of_unit, int tile_pos,
+                                                          int n_tile, int cbits, uint64_t* __restrict__ keys,
+                                                          uint32_t* __restrict__ vals) {
+    const int64_t e = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    if (e >= nnz) return;
+    int64_t lo = 0, hi = n_units;  // the last unit with ptr[unit] <= e
+    while (lo < hi) {
+        const int64_t mid = (lo + hi + 1) >> 1;
+        if (ptr[mid] <= e)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const int2 x = val[e];
+    const int w = min(vrx_chunks(x.x) + vrx_chunks((int64_t)x.y - x.x), 255);
+    const int32_t tp = tpos_of_unit[lo];
+    if (tp < 0 || w == 0) {
+        keys[e] = (uint64_t)n_tile << cbits;  // (the tile behind the last one)
+        vals[e] = 0;
+        return;
+    }
+    keys[e] = ((uint64_t)(tp / tile_pos) << cbits) | (uint32_t)idx[e];
+    vals[e] = (uint32_t)(tp % tile_pos) | (uint32_t)w << 16;
+}
+
+// (2) first sorted entry of every (tile, column); cptr[n_tile * n_contract] = the entries that count
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_bal_cptr(int64_t n_cols_all, int64_t n_contract, int64_t nnz,
+                                                          const uint64_t* __restrict__ keys, int cbits,
+                                                          uint32_t* __restrict__ cptr) {
+    const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    if (i > n_cols_all) return;
+    const uint64_t key = ((uint64_t)(i / n_contract) << cbits) | (uint64_t)(i % n_contract);
+    int64_t lo = 0, hi = nnz;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    cptr[i] = (uint32_t)lo;
+}
+
+// (3) processing order: (tile, block) | 4095 - degree | column, sorted ascending = degree descending, then column
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_bal_order_keys(int64_t n_cols_all, int64_t n_contract,
+                                                                const uint32_t* __restrict__ cptr, int slab_rows,
+                                                                int bs, int nb, int cbits,
+                                                                uint64_t* __restrict__ okeys, int32_t* too_deep) {
+    const int64_t i = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    if (i >= n_cols_all) return;
+    const int64_t t = i / n_contract, c = i % n_contract;
+    const uint32_t deg = cptr[i + 1] - cptr[i];
+    if (deg > 4095u) *too_deep = 1;
+    const uint64_t g = (uint64_t)t * (uint64_t)nb + (uint64_t)((c / slab_rows) / bs);
+    okeys[i] = (g << (12 + cbits)) | ((uint64_t)(4095u - min(deg, 4095u)) << cbits) | (uint64_t)c;
+}
+
+// (4) first column (in processing order) of every (tile, block); seg[n_groups] = all columns
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_bal_groups(int64_t n_groups, int64_t n_cols_all,
+                                                            const uint64_t* __restrict__ okeys, int shift,
+                                                            int64_t* __restrict__ seg) {
+    const int64_t g = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    if (g > n_groups) return;
+    const uint64_t key = (uint64_t)g << shift;
+    int64_t lo = 0, hi = n_cols_all;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (okeys[mid] < key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    seg[g] = lo;
+}
+
+// (5) degrees in processing order (scanned into stream offsets by the host's hipCUB call), (6) the entries
+// copied into that order: the greedy reads ONE sequential stream, no dependent address in its loop
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_bal_degrees(int64_t n_cols_all, const uint64_t* __restrict__ okeys,
+                                                             int cbits, uint32_t* __restrict__ deg) {
+    const int64_t k = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    if (k < n_cols_all) deg[k] = 4095u - (uint32_t)((okeys[k] >> cbits) & 4095u);
+}
+
+__global__ __launch_bounds__(VRX_BLOCK) void vrx_bal_stream(int64_t n_cols_all, int64_t n_contract,
+                                                            const uint64_t* __restrict__ okeys, int cbits, int nb,
+                                                            const uint32_t* __restrict__ cptr,
+                                                            const uint32_t* __restrict__ vals,
+                                                            const uint32_t* __restrict__ ostart,
+                                                            uint32_t* __restrict__ ovals) {
+    const int64_t k = (int64_t)blockIdx.x * VRX_BLOCK + threadIdx.x;
+    if (k >= n_cols_all) return;
+    const uint64_t ok = okeys[k];
+    const int64_t t = (int64_t)(ok >> (12 + cbits)) / nb, c = (int64_t)(ok & (((uint64_t)1 << cbits) - 1));
+    const uint32_t a = cptr[t * n_contract + c], b = cptr[t * n_contract + c + 1];
+    uint32_t o = ostart[k];
+    for (uint32_t e = a; e < b; ++e) ovals[o++] = vals[e];
+}
+
+// minimum over the wave: DPP inside the rows of 16 lanes (pairs, quads, half-row mirror, row mirror: a
+// minimum does not care which way the lanes are folded), the four row results by readlane
+__device__ __forceinline__ int vrx_wave_min(int v) {
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));  // row_half_mirror
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));  // row_mirror
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+// (7) the greedy: one wave per (tile, block), lane = slab of the block, the block's load matrix
+// [tile position][64 slabs] of bytes in LDS.  The group's entries arrive through a ring of two 1024-entry
+// batches in LDS: the next batch waits in 16 registers per lane (loaded a batch -- some thirty columns --
+// ahead, so its latency is never waited for) and is written behind the ring when the columns reach it.  A
+// column of <= 64 entries is one LDS read (lane i = entry i); the score of a slab is the sum of the loads of
+// the column's rows in it (every lane reads its own byte of each row, 16 reads in flight), the winner a
+// wave-wide minimum of score << 6 | lane among the lanes with room; the column's words are added
+// lane-parallel (saturating).
+constexpr int VRX_BAL_BATCH = 1024;
+
+// One wave per workgroup: the LDS executes a wave's instructions in order, so a write is seen by every later
+// read of any lane without a barrier; what is needed is only that the COMPILER keeps the order.  (A
+// __syncthreads() here also waits for the column's global stores and the batch on its way: ~1 us per column.)
+__device__ __forceinline__ void vrx_bal_lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(64) void vrx_balance_greedy(const uint64_t* __restrict__ okeys,
+                                                         const int64_t* __restrict__ seg,
+                                                         const uint32_t* __restrict__ ostart,
+                                                         const uint32_t* __restrict__ ovals, int64_t n_stream,
+                                                         int64_t n_contract, int cbits, int n_slab, int slab_rows,
+                                                         int bs, int nb, int tile_pos, int32_t* __restrict__ posmap,
+                                                         int32_t* __restrict__ perm, int32_t* __restrict__ fail) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t vrx_bal_lds[];
+    uint32_t* ring = reinterpret_cast<uint32_t*>(vrx_bal_lds);        // [2 * VRX_BAL_BATCH] entries
+    uint8_t* load = vrx_bal_lds + 2 * VRX_BAL_BATCH * sizeof(uint32_t);  // [tile_pos + 1][64], the last row zero
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const int64_t t = g / nb;
+    const int w0 = (g % nb) * bs, wn = min(bs, n_slab - w0);
+    for (int i = lane; i < (tile_pos + 1) * 16; i += 64) reinterpret_cast<uint32_t*>(load)[i] = 0u;
+    __syncthreads();
+    const int64_t k0 = seg[g], k1 = seg[g + 1];
+    if (k0 >= k1) return;
+    const int64_t slots = (int64_t)n_slab * slab_rows;
+    const uint64_t cmask = ((uint64_t)1 << cbits) - 1;
+    int cap = lane < wn ? slab_rows : 0, fill = 0;
+    const int64_t q0 = ostart[k0];
+    const int64_t q_end = k1 < seg[(int64_t)gridDim.x] ? (int64_t)ostart[k1] : n_stream;
+    int64_t q = q0;            // the next column's first entry
+    int64_t resident = q0;     // entries [.., resident) are in the ring (at (entry - q0) mod 2 batches)
+    uint32_t nxt[16];          // batch [resident, resident + VRX_BAL_BATCH), on its way
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int64_t e = resident + i * 64 + lane;
+        nxt[i] = e < q_end ? ovals[e] : 0u;
+    }
+    for (int64_t kb = k0; kb < k1; kb += 64) {
+        const uint64_t okl = kb + lane < k1 ? okeys[kb + lane] : 0;
+        uint32_t okl_lo = (uint32_t)okl, okl_hi = (uint32_t)(okl >> 32);
+        // (the wait for this load belongs HERE: left to the compiler it becomes an `s_waitcnt vmcnt(0)` at the
+        //  head of the column loop, which then waits for the previous column's two stores every time: ~1 us)
+        asm volatile("" : "+v"(okl_lo), "+v"(okl_hi));
+        const int nk = (int)min((int64_t)64, k1 - kb);
+        for (int j = 0; j < nk; ++j) {
+            const uint32_t ok_lo = __builtin_amdgcn_readlane(okl_lo, j), ok_hi = __builtin_amdgcn_readlane(okl_hi, j);
+            const uint64_t ok = (uint64_t)ok_hi << 32 | ok_lo;
+            const int64_t c = (int64_t)(ok & cmask);
+            const int deg = 4095 - (int)((ok >> cbits) & 4095u);
+            int best = -1;
+            uint32_t mine = 0;
+            if (deg > 0 && deg <= 64) {
+                while (q + 64 > resident && resident < q_end) {  // the waiting batch goes behind the ring
+                    const uint32_t at = (uint32_t)((resident - q0) & (2 * VRX_BAL_BATCH - 1));
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) ring[at + i * 64 + lane] = nxt[i];
+                    resident += VRX_BAL_BATCH;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int64_t e = resident + i * 64 + lane;
+                        nxt[i] = e < q_end ? ovals[e] : 0u;
+                    }
+                    vrx_bal_lds_order();
+                }
+                mine = lane < deg ? ring[(uint32_t)((q - q0 + lane) & (2 * VRX_BAL_BATCH - 1))] : (uint32_t)tile_pos;
+                // Scores, four entries a step: the 16 lanes of row r of the wave take entry 4 * step + r, each
+                // lane one dword = four slabs of that entry's load row, summed in 16-bit fields (a single wave
+                // issues one instruction every few clocks: the instruction count per column IS the run time;
+                // one byte read per entry and slab cost four times as many).
+                const uint32_t maddr = (mine & 0xffffu) << 6;  // byte address of the entry's load row
+                const uint32_t from = (uint32_t)(lane >> 4) << 2, quad = (uint32_t)(lane & 15) << 2;
+                uint32_t even = 0, odd = 0;  // slabs (4q, 4q + 2) and (4q + 1, 4q + 3) of quad q = lane & 15
+                for (int e0 = 0; e0 < deg; e0 += 16) {
+                    uint32_t x[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t row = __builtin_amdgcn_ds_bpermute((int)(from + (uint32_t)(e0 + 4 * i) * 4u), (int)maddr);
+                        x[i] = *reinterpret_cast<const uint32_t*>(load + row + quad);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        even += x[i] & 0x00ff00ffu;
+                        odd += (x[i] >> 8) & 0x00ff00ffu;
+                    }
+                }
+                // the four rows of the wave added up (every lane then holds its quad's totals), and lane = slab
+                // picks its field out of the lane that holds its quad
+                even += (uint32_t)__shfl_xor((int)even, 16, 64);
+                odd += (uint32_t)__shfl_xor((int)odd, 16, 64);
+                even += (uint32_t)__shfl_xor((int)even, 32, 64);
+                odd += (uint32_t)__shfl_xor((int)odd, 32, 64);
+                const uint32_t ev = (uint32_t)__builtin_amdgcn_ds_bpermute((lane >> 2) << 2, (int)even);
+                const uint32_t od = (uint32_t)__builtin_amdgcn_ds_bpermute((lane >> 2) << 2, (int)odd);
+                const uint32_t both = (lane & 1) ? od : ev;
+                const int score = (int)((lane & 2) ? both >> 16 : both & 0xffffu);
+                const int key = vrx_wave_min(cap > 0 ? (score << 6 | lane) : 0x7fffffff);
+                best = key == 0x7fffffff ? -1 : (key & 63);
+            } else if (deg > 64) {  // a long column: straight from memory, 64 entries at a time
+                int score = 0;
+                for (int64_t e0 = q; e0 < q + deg; e0 += 64) {
+                    const int n = (int)min((int64_t)64, q + deg - e0);
+                    const uint32_t v = lane < n ? ovals[e0 + lane] : 0u;
+                    for (int i = 0; i < n; ++i) score += load[(__builtin_amdgcn_readlane(v, i) & 0xffffu) * 64u + lane];
+                }
+                const int key = vrx_wave_min(cap > 0 ? (score << 6 | lane) : 0x7fffffff);
+                best = key == 0x7fffffff ? -1 : (key & 63);
+            }
+            if (best < 0) {  // no entry in this tile (they come last): the first slab of the block with room
+                const unsigned long long room = __ballot(cap > 0);
+                if (room == 0ull) {
+                    if (lane == 0) *fail = 1;
+                    return;
+                }
+                best = __ffsll((long long)room) - 1;
+            }
+            const int f = __builtin_amdgcn_readlane(fill, best);
+            if (lane == best) {
+                --cap;
+                ++fill;
+            }
+            if (lane == 0) {
+                const int64_t pos = (int64_t)(w0 + best) * slab_rows + f;
+                posmap[t * n_contract + c] = (int32_t)pos;
+                perm[t * slots + pos] = (int32_t)c;
+            }
+            if (deg > 0 && deg <= 64) {
+                if (lane < deg) {
+                    uint8_t& L = load[(mine & 0xffffu) * 64u + (uint32_t)best];
+                    L = (uint8_t)min((int)L + (int)(mine >> 16), VRX_BAL_LOAD_MAX);
+                }
+            } else if (deg > 64) {
+                for (int64_t e = q + lane; e < q + deg; e += 64) {
+                    const uint32_t v = ovals[e];
+                    uint8_t& L = load[(v & 0xffffu) * 64u + (uint32_t)best];
+                    L = (uint8_t)min((int)L + (int)(v >> 16), VRX_BAL_LOAD_MAX);
+                }
+            }
+            q += deg;
+            vrx_bal_lds_order();  // this column's LDS updates before the next column's reads
+        }
+    }
 }
 
 // ---- tiled streams: segment of every (wave, slab, tile position), round lengths ------------------

@@ -449,8 +449,8 @@ static inline int words_of_count(int64_t v) {  // FORM 1 words of one count (pus
 
 // (the greedy itself: vrx_host.cpp, vrx_balance_tile -- host only, built with AVX2 clones of its inner loops)
 void vrx_balance_tile(const int32_t* rows, int64_t n_rows_tile, const int64_t* ptr, const int32_t* idx,
-                      const uint8_t* words, int64_t n_contract, int n_slab, int slab_rows, int32_t* posmap,
-                      int32_t* perm);
+                      const uint8_t* words, int64_t n_contract, int n_slab, int slab_rows, int max_block,
+                      int32_t* posmap, int32_t* perm);
 
 // The host half of a tiled stream that needs nothing but the row pointer: the pieces long rows are cut
 // into, the tile / slab geometry, and which piece sits at which tile position.  A function of its own so
@@ -575,6 +575,7 @@ static void greedy_tiles(const TileLayout& L, bool pieces, const int64_t* unit_p
                          std::vector<int32_t>& perm, std::vector<int32_t>& tile_of_row) {
     const int64_t tile_pos = (int64_t)VRX_LDS_WAVES * L.RW, slots = (int64_t)L.n_slab * L.slab_rows;
     const int64_t n_contract = L.n_contract;
+    const int max_block = env_int("VIREO_BALANCE_BLOCK", 64);
     posmap.resize((size_t)(L.n_tile * n_contract));
     perm.resize((size_t)(L.n_tile * slots));
     tile_of_row.assign((size_t)n_unit_rows, -1);
@@ -589,7 +590,7 @@ static void greedy_tiles(const TileLayout& L, bool pieces, const int64_t* unit_p
             for (int64_t pos = tl * tile_pos; pos < (tl + 1) * tile_pos; ++pos)
                 if (L.rowmap[(size_t)pos] >= 0) rows.push_back(unit_of(L.rowmap[(size_t)pos]));
             vrx_balance_tile(rows.data(), (int64_t)rows.size(), unit_ptr, idx, words, n_contract, L.n_slab,
-                             L.slab_rows, posmap.data() + tl * n_contract, perm.data() + tl * slots);
+                             L.slab_rows, max_block, posmap.data() + tl * n_contract, perm.data() + tl * slots);
         }
     });
 }
@@ -768,36 +769,152 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
                 hc = nullptr;  // (the caller's arrays are the whole rows)
                 hw = nullptr;
             }
-            if (!hc && !hw && !(have_pre && L.greedy_done && !pieces)) {
-                DevBuf<uint8_t> d_words;
-                VRX_HIP(d_words.alloc((size_t)o_nnz));
-                vrx_build_words<<<(unsigned)((o_nnz + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(o_nnz, du_val, d_words.p);
-                VRX_HIP(hipGetLastError());
-                h_idx.resize((size_t)o_nnz);
-                h_words.resize((size_t)o_nnz);
-                VRX_HIP(hipMemcpyAsync(h_idx.data(), du_idx, (size_t)o_nnz * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-                VRX_HIP(hipMemcpyAsync(h_words.data(), d_words.p, (size_t)o_nnz, hipMemcpyDeviceToHost, s));
-                VRX_HIP(hipStreamSynchronize(s));
-            }
-            lap("download rows");
-            std::vector<int32_t> posmap_own, perm_own, tile_of_row_own;
             const bool pre_done = have_pre && L.greedy_done && !pieces;  // device_build's helper thread already did it
-            if (!pre_done) {
-                if (hc) (void)host_words(*hc, o_nnz, o_n_contract, h_words);  // (validated by now)
-                const int32_t* g_idx = hc ? hc->idx : hw ? hw->idx : h_idx.data();
-                const uint8_t* g_words = hw ? hw->words : h_words.data();
-                greedy_tiles(L, pieces, u_ptr, g_idx, g_words, n_unit_rows, posmap_own, perm_own, tile_of_row_own);
+            // the tile position of every unit (what both routes of the greedy start from)
+            std::vector<int32_t> tile_of_row_own((size_t)n_unit_rows, -1), tpos((size_t)n_unit_rows, -1);
+            for (int64_t pos = 0; pos < (int64_t)t.n_tile * tile_pos; ++pos)
+                if (rowmap[(size_t)pos] >= 0) {
+                    const int32_t u = pieces ? rowmap[(size_t)pos] : vrow_row[(size_t)rowmap[(size_t)pos]];
+                    tile_of_row_own[(size_t)u] = (int32_t)(pos / tile_pos);
+                    tpos[(size_t)u] = (int32_t)pos;
+                }
+            VRX_HIP(d_tile_of_row.upload(tile_of_row_own.data(), tile_of_row_own.size(), s));
+            // ---- the greedy on the device (vrx_build.h, vrx_balance_greedy): no entry leaves the GPU ----------
+            const int max_block = env_int("VIREO_BALANCE_BLOCK", 64);
+            const VrxBalBlocks blocks = vrx_bal_blocks(t.n_slab, max_block);
+            const bool check = env_int("VIREO_BALANCE_CHECK", 0) != 0;
+            const char* gm = getenv("VIREO_BALANCE_GREEDY");
+            const int64_t n_cols_all = (int64_t)t.n_tile * o_n_contract, n_groups = (int64_t)t.n_tile * blocks.nb;
+            bool dev_greedy = !(gm && !strcmp(gm, "host")) && !pre_done && blocks.bs <= 64 &&
+                              (tile_pos + 1) * 64 + 2 * VRX_BAL_BATCH * 4 <= 160 * 1024 && tile_pos <= 4095 && n_cols_all < (int64_t)INT32_MAX &&
+                              n_groups < ((int64_t)1 << 20) && (int64_t)t.n_tile * tile_pos < (int64_t)INT32_MAX;
+            if (dev_greedy) {
+                DevBuf<int32_t> d_tpos, d_flags;
+                DevBuf<uint64_t> bk_in, bk_out, ok_in, ok_out;
+                DevBuf<uint32_t> bv_in, bv_out, d_cptr, d_deg, d_ostart, d_ovals;
+                DevBuf<int64_t> d_seg;
+                DevBuf<char> tmp;
+                int cbits = 1, tbits = 1, gbits = 1;
+                while (((int64_t)1 << cbits) < o_n_contract) ++cbits;
+                while (((int64_t)1 << tbits) < (int64_t)t.n_tile + 1) ++tbits;
+                while (((int64_t)1 << gbits) < n_groups) ++gbits;
+                const unsigned nbe = (unsigned)((o_nnz + VRX_BLOCK - 1) / VRX_BLOCK);
+                const unsigned nbc = (unsigned)((n_cols_all + 1 + VRX_BLOCK - 1) / VRX_BLOCK);
+                VRX_HIP(d_tpos.upload(tpos.data(), tpos.size(), s));
+                const int32_t zero2[2] = {0, 0};
+                VRX_HIP(d_flags.upload(zero2, 2, s));
+                VRX_HIP(bk_in.alloc((size_t)o_nnz));
+                VRX_HIP(bk_out.alloc((size_t)o_nnz));
+                VRX_HIP(bv_in.alloc((size_t)o_nnz));
+                VRX_HIP(bv_out.alloc((size_t)o_nnz));
+                vrx_bal_keys<<<nbe, VRX_BLOCK, 0, s>>>(o_nnz, n_unit_rows, du_ptr, du_idx, du_val, d_tpos.p, (int)tile_pos,
+                                                       t.n_tile, cbits, bk_in.p, bv_in.p);
+                VRX_HIP(hipGetLastError());
+                size_t tmp_bytes = 0, tmp2 = 0, tmp3 = 0;
+                VRX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, bk_in.p, bk_out.p, bv_in.p, bv_out.p,
+                                                           (size_t)o_nnz, 0, cbits + tbits, s));
+                VRX_HIP(ok_in.alloc((size_t)n_cols_all));
+                VRX_HIP(ok_out.alloc((size_t)n_cols_all));
+                VRX_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp2, ok_in.p, ok_out.p, (size_t)n_cols_all, 0,
+                                                          cbits + 12 + gbits, s));
+                VRX_HIP(d_deg.alloc((size_t)n_cols_all));
+                VRX_HIP(d_ostart.alloc((size_t)n_cols_all));
+                VRX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp3, d_deg.p, d_ostart.p, (size_t)n_cols_all, s));
+                VRX_HIP(tmp.alloc(std::max(tmp_bytes, std::max(tmp2, tmp3))));
+                VRX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, bk_in.p, bk_out.p, bv_in.p, bv_out.p,
+                                                           (size_t)o_nnz, 0, cbits + tbits, s));
+                VRX_HIP(d_cptr.alloc((size_t)n_cols_all + 1));
+                vrx_bal_cptr<<<nbc, VRX_BLOCK, 0, s>>>(n_cols_all, o_n_contract, o_nnz, bk_out.p, cbits, d_cptr.p);
+                VRX_HIP(hipGetLastError());
+                vrx_bal_order_keys<<<nbc, VRX_BLOCK, 0, s>>>(n_cols_all, o_n_contract, d_cptr.p, slab_rows, blocks.bs,
+                                                             blocks.nb, cbits, ok_in.p, d_flags.p);
+                VRX_HIP(hipGetLastError());
+                VRX_HIP(hipcub::DeviceRadixSort::SortKeys(tmp.p, tmp2, ok_in.p, ok_out.p, (size_t)n_cols_all, 0,
+                                                          cbits + 12 + gbits, s));
+                VRX_HIP(d_seg.alloc((size_t)n_groups + 1));
+                vrx_bal_groups<<<(unsigned)((n_groups + 1 + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(
+                    n_groups, n_cols_all, ok_out.p, 12 + cbits, d_seg.p);
+                VRX_HIP(hipGetLastError());
+                vrx_bal_degrees<<<nbc, VRX_BLOCK, 0, s>>>(n_cols_all, ok_out.p, cbits, d_deg.p);
+                VRX_HIP(hipGetLastError());
+                VRX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp3, d_deg.p, d_ostart.p, (size_t)n_cols_all, s));
+                uint32_t n_stream = 0;  // the entries that count = first entry of the column behind the last one
+                VRX_HIP(hipMemcpyAsync(&n_stream, d_cptr.p + n_cols_all, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                bk_in.release();
+                bv_in.release();
+                VRX_HIP(d_ovals.alloc((size_t)o_nnz));
+                vrx_bal_stream<<<nbc, VRX_BLOCK, 0, s>>>(n_cols_all, o_n_contract, ok_out.p, cbits, blocks.nb, d_cptr.p,
+                                                         bv_out.p, d_ostart.p, d_ovals.p);
+                VRX_HIP(hipGetLastError());
+                VRX_HIP(d_posmap.alloc((size_t)n_cols_all));
+                VRX_HIP(t.perm.alloc((size_t)(t.n_tile * slots)));
+                VRX_HIP(hipMemsetAsync(t.perm.p, 0, (size_t)(t.n_tile * slots) * sizeof(int32_t), s));
+                VRX_HIP(hipStreamSynchronize(s));  // (n_stream)
+                const size_t lds = (size_t)(tile_pos + 1) * 64 + 2 * VRX_BAL_BATCH * sizeof(uint32_t);
+                VRX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vrx_balance_greedy),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                vrx_balance_greedy<<<(unsigned)n_groups, 64, lds, s>>>(ok_out.p, d_seg.p, d_ostart.p, d_ovals.p,
+                                                                      (int64_t)n_stream, o_n_contract, cbits, t.n_slab,
+                                                                      slab_rows, blocks.bs, blocks.nb, (int)tile_pos,
+                                                                      d_posmap.p, t.perm.p, d_flags.p + 1);
+                VRX_HIP(hipGetLastError());
+                int32_t flags[2] = {0, 0};
+                VRX_HIP(hipMemcpyAsync(flags, d_flags.p, sizeof flags, hipMemcpyDeviceToHost, s));
+                VRX_HIP(hipStreamSynchronize(s));
+                lap("greedy on the device");
+                if (flags[0] || flags[1]) {  // a column deeper than 4095 tile rows / a block without room: cannot be
+                    dev_greedy = false;
+                    if (timing) fprintf(stderr, "[vrx build] balanced slabs: device greedy declined (%d, %d)\n", flags[0], flags[1]);
+                }
             }
-            std::vector<int32_t>&posmap = pre_done ? L.posmap : posmap_own, &perm = pre_done ? L.perm : perm_own,
-                                &tile_of_row = pre_done ? L.tile_of_row : tile_of_row_own;
-            if (pre_done && timing)
-                fprintf(stderr, "[vrx build] balanced slabs (mode %d): greedy ran beside the upload     %.3f s (hidden)\n", mode, L.greedy_seconds);
-            lap("greedy (host threads)");
-            std::vector<int32_t>().swap(h_idx);
-            std::vector<uint8_t>().swap(h_words);
-            VRX_HIP(d_tile_of_row.upload(tile_of_row.data(), tile_of_row.size(), s));
-            VRX_HIP(d_posmap.upload(posmap.data(), posmap.size(), s));
-            VRX_HIP(t.perm.upload(perm.data(), perm.size(), s));
+            std::vector<int32_t> posmap_own, perm_own, tor_unused;
+            if (!dev_greedy || check) {  // ---- the greedy on host threads (the specification) -----------------
+                if (!hc && !hw && !pre_done) {
+                    DevBuf<uint8_t> d_words;
+                    VRX_HIP(d_words.alloc((size_t)o_nnz));
+                    vrx_build_words<<<(unsigned)((o_nnz + VRX_BLOCK - 1) / VRX_BLOCK), VRX_BLOCK, 0, s>>>(o_nnz, du_val, d_words.p);
+                    VRX_HIP(hipGetLastError());
+                    h_idx.resize((size_t)o_nnz);
+                    h_words.resize((size_t)o_nnz);
+                    VRX_HIP(hipMemcpyAsync(h_idx.data(), du_idx, (size_t)o_nnz * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                    VRX_HIP(hipMemcpyAsync(h_words.data(), d_words.p, (size_t)o_nnz, hipMemcpyDeviceToHost, s));
+                    VRX_HIP(hipStreamSynchronize(s));
+                }
+                lap("download rows");
+                if (!pre_done) {
+                    if (hc) (void)host_words(*hc, o_nnz, o_n_contract, h_words);  // (validated by now)
+                    const int32_t* g_idx = hc ? hc->idx : hw ? hw->idx : h_idx.data();
+                    const uint8_t* g_words = hw ? hw->words : h_words.data();
+                    greedy_tiles(L, pieces, u_ptr, g_idx, g_words, n_unit_rows, posmap_own, perm_own, tor_unused);
+                }
+                std::vector<int32_t>&posmap = pre_done ? L.posmap : posmap_own, &perm = pre_done ? L.perm : perm_own;
+                if (pre_done && timing)
+                    fprintf(stderr, "[vrx build] balanced slabs (mode %d): greedy ran beside the upload     %.3f s (hidden)\n", mode, L.greedy_seconds);
+                lap("greedy (host threads)");
+                std::vector<int32_t>().swap(h_idx);
+                std::vector<uint8_t>().swap(h_words);
+                if (dev_greedy) {  // VIREO_BALANCE_CHECK=1: the device's result against the specification, bit for bit
+                    std::vector<int32_t> dp((size_t)n_cols_all), dq((size_t)(t.n_tile * slots));
+                    VRX_HIP(hipMemcpyAsync(dp.data(), d_posmap.p, dp.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                    VRX_HIP(hipMemcpyAsync(dq.data(), t.perm.p, dq.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                    VRX_HIP(hipStreamSynchronize(s));
+                    for (int64_t i = 0; i < n_cols_all; ++i)
+                        if (dp[(size_t)i] != posmap[(size_t)i]) {
+                            vrx_set_error("balanced slabs: the device greedy differs from the host's at tile %lld, contracted "
+                                          "row %lld (%d against %d)", (long long)(i / o_n_contract),
+                                          (long long)(i % o_n_contract), dp[(size_t)i], posmap[(size_t)i]);
+                            return VRX_ERR_UNSUPPORTED;
+                        }
+                    if (dq != perm) {
+                        vrx_set_error("balanced slabs: the device greedy's slab lists differ from the host's");
+                        return VRX_ERR_UNSUPPORTED;
+                    }
+                    if (timing) fprintf(stderr, "[vrx build] balanced slabs (mode %d): device greedy == host greedy (%lld columns)\n", mode, (long long)n_cols_all);
+                } else {
+                    VRX_HIP(d_posmap.upload(posmap.data(), posmap.size(), s));
+                    VRX_HIP(t.perm.upload(perm.data(), perm.size(), s));
+                }
+            }
             DevBuf<uint64_t> k_in, k_out;
             DevBuf<uint32_t> v_in, v_out;
             VRX_HIP(k_in.alloc((size_t)o_nnz));
@@ -1163,7 +1280,10 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
     // this one (a count >= 2048 can still change the stream form below; then it is simply recomputed).
     TileLayout cell_layout;
     std::thread early;
-    if (p->want_balance && forms.cell == 1 && env_int("VIREO_BALANCE_EARLY", 1) != 0) {
+    // (only where the greedy runs on host threads, VIREO_BALANCE_GREEDY=host: by default it runs on the device)
+    const char* greedy_mode = getenv("VIREO_BALANCE_GREEDY");
+    const bool host_greedy = greedy_mode && !strcmp(greedy_mode, "host");
+    if (p->want_balance && host_greedy && forms.cell == 1 && env_int("VIREO_BALANCE_EARLY", 1) != 0) {
         const int rw0 = rw_cell, form0 = forms.cell;
         early = std::thread([&, rw0, form0] {
             const auto t0 = std::chrono::steady_clock::now();
@@ -1320,7 +1440,7 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
         vrx_virt_fill<<<nbv, VRX_BLOCK, 0, s>>>(n_var, d_rptr.p, d_ridx.p, d_rval.p, d_vptr2.p, d_vidx.p,
                                                 d_vval.p);
         VRX_HIP(hipGetLastError());
-        if (p->want_balance && vnnz > 0) {
+        if (p->want_balance && host_greedy && vnnz > 0) {
             VRX_HIP(hipStreamSynchronize(s));
             hv_idx.resize((size_t)vnnz);
             hv_words.resize((size_t)vnnz);

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../../include/vireo_hip.h"
+#include "vrx_balance.h"
 
 // ------------------------------------------------------------------------------------
 // errors: a thread-local message behind every non-zero status (include/vireo_hip.h)
@@ -1150,8 +1151,8 @@ static int best_slab_of(const int16_t* load, int nsp, const uint32_t* ent, uint3
 
 template <class E, int RB>
 static void balance_tile(const int32_t* rows, int64_t n_rows_tile, const int64_t* ptr, const int32_t* idx,
-                         const uint8_t* words, int64_t n_contract, int n_slab, int slab_rows, int32_t* posmap,
-                         int32_t* perm, std::vector<uint32_t>& cptr) {
+                         const uint8_t* words, int64_t n_contract, int n_slab, int slab_rows, int max_block,
+                         int32_t* posmap, int32_t* perm, std::vector<uint32_t>& cptr) {
     const int64_t NC = n_contract;
     const size_t ne = cptr[(size_t)NC];
     std::vector<E> ent(ne);  // the tile's entries, column by column
@@ -1170,10 +1171,10 @@ static void balance_tile(const int32_t* rows, int64_t n_rows_tile, const int64_t
     std::vector<int32_t> order((size_t)NC);
     for (int64_t c = 0; c < NC; ++c) order[dstart[(size_t)(maxdeg - (cptr[(size_t)c + 1] - cptr[(size_t)c]))]++] = (int32_t)c;
     const int nsp = (n_slab + 31) / 32 * 32;
-    static const int block = getenv("VIREO_BALANCE_BLOCK") ? atoi(getenv("VIREO_BALANCE_BLOCK")) : 64;
+    const VrxBalBlocks blocks = vrx_bal_blocks(n_slab, max_block);
     std::vector<int16_t> load((size_t)n_rows_tile * (size_t)nsp, 0), score16((size_t)nsp), full16((size_t)nsp, 0);
     std::vector<int32_t> score((size_t)nsp), full32((size_t)nsp, 0), cap((size_t)n_slab, slab_rows), fill((size_t)n_slab, 0);
-    for (int sl = n_slab; sl < nsp; ++sl) {  // (the padding slabs of the last block never have room)
+    for (int sl = n_slab; sl < nsp; ++sl) {  // (padding slabs never have room)
         full16[(size_t)sl] = 0x7fff;
         full32[(size_t)sl] = 0x7fffffff;
     }
@@ -1187,50 +1188,40 @@ static void balance_tile(const int32_t* rows, int64_t n_rows_tile, const int64_t
         posmap[c] = sl * slab_rows + local;
         perm[(int64_t)sl * slab_rows + local] = c;
     };
-    int next_free = 0;
+    std::vector<int> next_free((size_t)blocks.nb);  // per block: the first slab that may still have room
+    for (int bi = 0; bi < blocks.nb; ++bi) next_free[(size_t)bi] = bi * blocks.bs;
     int32_t max_load = 0;  // the largest entry of `load` so far: decides whether 16-bit scores cannot overflow
     for (int64_t k = 0; k < NC; ++k) {
         const int32_t c = order[(size_t)k];
         const uint32_t a = cptr[(size_t)c], b = cptr[(size_t)c + 1];
-        if (a == b) {  // no entry in this tile: any slab with room
-            while (cap[(size_t)next_free] == 0) ++next_free;
-            place(c, next_free);
-            continue;
-        }
-        // candidates: the slabs of the column's own aligned block of 64 slabs (the last block takes the
-        // remainder, up to 127).  Measured at c3 (196 slabs in the cell orientation): the whole range gives
-        // 1.185 executed slots per word, blocks of 64 give 1.225 -- and the same pass time, because the
-        // workgroups of a launch then stage their slabs out of the same 8-MB stretch of the operand at the
-        // same time (blocks of 32 / 16 / 8: 1.26 / 1.30 / 1.35, passes 1-5 % slower); the search is linear
-        // in the problem at any size.  VIREO_BALANCE_BLOCK=n: blocks of n slabs, <= 0: the whole range.
-        int w0 = 0, wn = nsp;
-        if (block > 0 && n_slab >= 2 * block) {
-            const int nb = n_slab / block, bi = std::min((int)(c / slab_rows) / block, nb - 1);
-            w0 = bi * block;
-            wn = bi == nb - 1 ? nsp - w0 : block;
-        }
-        int best = (int64_t)(b - a) * max_load < 32000
+        const int bi = (int)(c / slab_rows) / blocks.bs, w0 = bi * blocks.bs, wn = std::min(blocks.bs, n_slab - w0);
+        int best = -1;
+        if (a != b)
+            best = (int64_t)(b - a) * max_load < 32000
                        ? best_slab_of(load.data(), nsp, ent.data() + a, b - a, w0, wn, full16.data(), score16.data())
                        : best_slab_of(load.data(), nsp, ent.data() + a, b - a, w0, wn, full32.data(), score.data());
-        if (best < 0) {  // the window is full: the first slab with room
-            while (cap[(size_t)next_free] == 0) ++next_free;
-            best = next_free;
+        if (best < 0) {  // no entry in this tile (they come last): the first slab of the block with room
+            int& nf = next_free[(size_t)bi];
+            while (nf < w0 + wn && cap[(size_t)nf] == 0) ++nf;
+            best = nf;  // (a block holds at least as many positions as columns: there is one)
         }
         place(c, best);
         for (uint32_t e = a; e < b; ++e) {
             int16_t& L = load[(size_t)(ent[e] & ((1u << RB) - 1)) * nsp + best];
-            L = (int16_t)std::min<int32_t>(L + (int32_t)(ent[e] >> RB), 32000);
+            L = (int16_t)std::min<int32_t>(L + (int32_t)(ent[e] >> RB), VRX_BAL_LOAD_MAX);
             max_load = std::max<int32_t>(max_load, L);
         }
     }
 }
 
+// The per-tile greedy of the balanced-slab build, host version = the specification (vrx_balance.h).
 // rows: the tile's rows (ids into ptr); idx / words: contracted index and FORM 1 word count of every entry;
+// max_block: the largest block of slabs a contracted row may move in (<= 0: all of them);
 // posmap[c] <- slab * slab_rows + slab-local position of contracted row c; perm = its inverse (unused
 // positions name row 0: the pass stages some valid row there and no word refers to it)
 void vrx_balance_tile(const int32_t* rows, int64_t n_rows_tile, const int64_t* ptr, const int32_t* idx,
-                      const uint8_t* words, int64_t n_contract, int n_slab, int slab_rows, int32_t* posmap,
-                      int32_t* perm) {
+                      const uint8_t* words, int64_t n_contract, int n_slab, int slab_rows, int max_block,
+                      int32_t* posmap, int32_t* perm) {
     std::vector<uint32_t> cptr((size_t)n_contract + 1, 0);
     uint8_t wmax = 0;
     for (int64_t i = 0; i < n_rows_tile; ++i)
@@ -1240,7 +1231,7 @@ void vrx_balance_tile(const int32_t* rows, int64_t n_rows_tile, const int64_t* p
         }
     for (int64_t c = 0; c < n_contract; ++c) cptr[(size_t)c + 1] += cptr[(size_t)c];
     if (n_rows_tile <= 2048 && wmax < 32)  // (a 96-row tile and counts below 2^30: always)
-        balance_tile<uint16_t, 11>(rows, n_rows_tile, ptr, idx, words, n_contract, n_slab, slab_rows, posmap, perm, cptr);
+        balance_tile<uint16_t, 11>(rows, n_rows_tile, ptr, idx, words, n_contract, n_slab, slab_rows, max_block, posmap, perm, cptr);
     else
-        balance_tile<uint32_t, 16>(rows, n_rows_tile, ptr, idx, words, n_contract, n_slab, slab_rows, posmap, perm, cptr);
+        balance_tile<uint32_t, 16>(rows, n_rows_tile, ptr, idx, words, n_contract, n_slab, slab_rows, max_block, posmap, perm, cptr);
 }
