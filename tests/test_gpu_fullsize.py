@@ -184,7 +184,7 @@ def test_config3_flag_paths(va, flag):
     assert np.array_equal(m.ID_prob.argmax(1), st.ID_prob.argmax(1))
 
 
-def test_config3_balanced_slabs(va):
+def test_config3_balanced_slabs(va, monkeypatch):
     """The headline configuration on BALANCED SLABS (what bench.py's headline runs on): both streams
     balanced, a quarter fewer stream slots, the whole protocol bitwise repeatable, within summation-order
     distance of the default build's (same iteration count, same assignments), planted donors recovered, and
@@ -196,7 +196,13 @@ def test_config3_balanced_slabs(va):
     from tests.subset_parity import one_iteration_subset_check
     N, M, K, dens = synth.CONFIGS["c3"]
     w = synth.donor_workload(N, M, K, dens, seed=0)
+    # (the first build also runs the host's greedy -- the specification -- and fails unless the device's agrees
+    #  with it bit for bit: 3.3 M (tile, contracted row) assignments per orientation)
+    monkeypatch.setenv("VIREO_BALANCE_CHECK", "1")
     cb = DeviceCounts.from_merged(w["shape"], w["colptr"], w["rowidx"], w["ad"], w["dp"], balance=True)
+    monkeypatch.delenv("VIREO_BALANCE_CHECK")
+    assert DeviceCounts.from_merged(w["shape"], w["colptr"], w["rowidx"], w["ad"], w["dp"], balance=True).digest() \
+        == cb.digest()
     cd = DeviceCounts.from_merged(w["shape"], w["colptr"], w["rowidx"], w["ad"], w["dp"], balance=False)
     ib = cb.build_info()
     assert ib["balanced_variant"] and ib["balanced_cell"] and ib["device_built"]

@@ -1193,7 +1193,8 @@ def test_balanced_slabs_small_problem_vs_oracle_and_default_build(va, monkeypatc
     from vireo_amd import _lib
     monkeypatch.setenv("VIREO_LDS", "1")
     monkeypatch.setenv("VIREO_BUILD", "device")
-    monkeypatch.setenv("VIREO_LDS_SPLIT_X10", "60")        # (no row pieces: a stream that splits rows is not balanced)
+    monkeypatch.setenv("VIREO_LDS_SPLIT_X10", "60")        # (no row pieces here: the next test has them)
+    monkeypatch.setenv("VIREO_BALANCE_CHECK", "1")         # device greedy == host greedy, or the build fails
     AD, DP = O.synth_donor(2600, 2300, 6, 0.03, seed=3)          # 6 slabs of variants, 3 of double rows of cells
     N, M = AD.shape
 
@@ -1210,9 +1211,18 @@ def test_balanced_slabs_small_problem_vs_oracle_and_default_build(va, monkeypatc
     print("stream slots per non-zero: balanced %.3f / %.3f, default %.3f / %.3f (variant / cell)"
           % (kb["pad_variant"], kb["pad_cell"], kd["pad_variant"], kd["pad_cell"]))
     assert build(True).digest() == cb.digest()
-    monkeypatch.setenv("VIREO_BALANCE_EARLY", "0")         # the cell orientation's greedy inside build_tiled
-    assert build(True).digest() == cb.digest()             # instead of beside the upload: the same stream
+    # the same stream by every route: the greedy on host threads (the specification; by default it runs on the
+    # device, and VIREO_BALANCE_CHECK=1 -- set above -- makes every build compare the two bit for bit), with
+    # the cell orientation's share beside the upload or inside build_tiled, the orientations one after the other
+    monkeypatch.setenv("VIREO_BALANCE_GREEDY", "host")
+    assert build(True).digest() == cb.digest()
+    monkeypatch.setenv("VIREO_BALANCE_EARLY", "0")
+    assert build(True).digest() == cb.digest()
     monkeypatch.delenv("VIREO_BALANCE_EARLY")
+    monkeypatch.delenv("VIREO_BALANCE_GREEDY")
+    monkeypatch.setenv("VIREO_BUILD_CONCURRENT", "0")
+    assert build(True).digest() == cb.digest()
+    monkeypatch.delenv("VIREO_BUILD_CONCURRENT")
 
     def fit(counts, **kw):
         np.random.seed(4)
@@ -1260,6 +1270,7 @@ def test_balanced_slabs_with_rows_cut_into_pieces(va, monkeypatch):
     from vireo_amd import _lib
     monkeypatch.setenv("VIREO_LDS", "1")
     monkeypatch.setenv("VIREO_BUILD", "device")
+    monkeypatch.setenv("VIREO_BALANCE_CHECK", "1")         # device greedy == host greedy, or the build fails
     rng = np.random.default_rng(11)
     N, M, K = 2600, 2300, 6
     cov_v = np.exp(rng.normal(0.0, 1.2, N))[:, None]

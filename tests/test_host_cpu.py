@@ -801,17 +801,17 @@ def test_rccl_init_watchdog_ends_a_rank_that_hangs(tmp_path):
 
 def test_balance_policy_order_of_precedence(monkeypatch):
     """Balanced slabs are a build option: the caller's word first, then VIREO_BALANCE, then the
-    announced number of iterations against VIREO_BALANCE_MIN_ITERS (default 2500)."""
+    announced number of iterations against VIREO_BALANCE_MIN_ITERS (default 1200)."""
     from vireo_amd.counts import balance_policy
     monkeypatch.delenv("VIREO_BALANCE", raising=False)
     monkeypatch.delenv("VIREO_BALANCE_MIN_ITERS", raising=False)
     assert balance_policy() is False
-    assert balance_policy(expected_iterations=1200) is False       # vireo's defaults: 50 x 20 + 200
-    assert balance_policy(expected_iterations=2500) is True
+    assert balance_policy(expected_iterations=840) is False        # bench.py's c4 job: 32 x 20 + 200
+    assert balance_policy(expected_iterations=1200) is True        # vireo's defaults: 50 x 20 + 200
     assert balance_policy(balance=False, expected_iterations=10 ** 6) is False
     assert balance_policy(balance=True) is True
-    monkeypatch.setenv("VIREO_BALANCE_MIN_ITERS", "1000")
-    assert balance_policy(expected_iterations=1200) is True
+    monkeypatch.setenv("VIREO_BALANCE_MIN_ITERS", "500")
+    assert balance_policy(expected_iterations=840) is True
     monkeypatch.setenv("VIREO_BALANCE", "0")
     assert balance_policy(expected_iterations=10 ** 6) is False
     assert balance_policy(balance=True) is True                     # the caller outranks the environment

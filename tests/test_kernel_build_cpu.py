@@ -112,3 +112,27 @@ def test_slab_prefetch_is_a_fixed_number_of_loads(isa):
         #  of the element-wise instances leave behind always jumps -- EXEC is full -- and skips no load)
         assert not any("saveexec" in l or "s_cbranch_execz" in l for l in between[loads[0]:loads[-1] + 1]), name
         assert any("s_waitcnt vmcnt(%d)" % (n_pf + n_rec) in l for l in body), name
+
+
+def test_balance_greedy_column_loop_waits_for_no_memory(isa):
+    """vrx_balance_greedy (the balanced-slab greedy, one wave per (tile, block)): a strictly sequential kernel
+    whose run time is its dependent-latency chain per column -- no scratch, no barrier in the loop (a
+    __syncthreads() per column also waits for that column's two global stores), and no `s_waitcnt
+    vmcnt` at the head of the column loop (the wait for the batch of order keys sits in front of the loop:
+    left to the compiler it lands inside and waits for the previous column's stores every time)."""
+    asm, report = isa
+    block = [b for b in re.split(r"remark: [^\n]*Function Name: ", report)[1:] if b.startswith("_Z18vrx_balance_greedy")]
+    assert len(block) == 1
+    get = lambda key: int(re.search(key + r": (\d+)", block[0]).group(1))      # noqa: E731
+    assert get("VGPRs Spill") == 0 and get("SGPRs Spill") == 0 and get(r"ScratchSize \[bytes/lane\]") == 0
+    name = block[0].split()[0]
+    body = asm[asm.index("\n" + name + ":"):]
+    body = body[:body.index("s_endpgm")].split("\n")
+    assert sum(1 for l in body if re.match(r"\s*s_barrier", l)) <= 1      # (one wave: the compiler may drop it)
+    # the column loop = the depth-2 loop; its header block runs to the next label
+    heads = [i for i, l in enumerate(body) if "Loop Header: Depth=2" in l]
+    assert len(heads) == 1, heads
+    nxt = next(i for i in range(heads[0] + 1, len(body)) if re.match(r"\.LBB\d+_\d+:", body[i]))
+    head = body[heads[0]:nxt]
+    assert not any("s_waitcnt vmcnt" in l for l in head), [l for l in head if "waitcnt" in l]
+    assert any("ds_bpermute_b32" in l for l in body) and any("row_mirror" in l for l in body)

@@ -90,10 +90,10 @@ def merge_counts(AD, DP):
 def balance_policy(balance=None, expected_iterations=None):
     """Should the problem be built with *balanced slabs* (``vrx_problem_create2``, VRX_PROBLEM_BALANCED)?
 
-    They shorten the sparse passes by 10-17 % at c3 and cost a one-off ~0.13 s at 1e8 entries (break-even at c3: ~1 800
+    They shorten the sparse passes by 10-17 % at c3 and cost a one-off ~0.06 s at 1e8 entries (break-even at c3: ~800
     iterations on the same problem).  ``balance`` True / False decides; None: the
     environment (VIREO_BALANCE=1 / 0), else on when the caller expects at least VIREO_BALANCE_MIN_ITERS
-    iterations (default 2500; ``vireo_wrap`` announces n_init x max_iter_init + 200).  The library applies the
+    iterations (default 1200; ``vireo_wrap`` announces n_init x max_iter_init + 200).  The library applies the
     flag only where it can (LDS-resident passes on AD/BD words, no split rows); ``DeviceCounts.build_info``
     says what was built."""
     import os
@@ -102,7 +102,7 @@ def balance_policy(balance=None, expected_iterations=None):
     env = os.environ.get("VIREO_BALANCE")
     if env in ("0", "1"):
         return env == "1"
-    need = int(os.environ.get("VIREO_BALANCE_MIN_ITERS", "2500"))
+    need = int(os.environ.get("VIREO_BALANCE_MIN_ITERS", "1200"))
     return expected_iterations is not None and expected_iterations >= need
 
 

@@ -1465,33 +1465,70 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
         }
     }
     JoinGuard join_guard{helper};
-    const HostCounts cell_host{rowidx, ad, dp};
     lap("virtual rows");
+    // The two orientations' streams are independent from here on: the variant orientation is built by a second
+    // host thread on a stream of its own while this one builds the cell orientation (their host halves --
+    // layout, work list -- and their device halves -- the greedy of balanced slabs is a latency-bound kernel on
+    // half the CUs -- overlap).  Not for problems whose two sets of transient buffers would not fit together.
+    auto build_var = [&](hipStream_t sv) -> int {
+        int rcv;
+        if (var_form == 3) {
+            if (helper.joinable()) helper.join();
+            if (helper_err != hipSuccess) {
+                vrx_set_error("balanced slabs: download of the variant rows failed: %s", hipGetErrorString(helper_err));
+                return VRX_ERR_HIP;
+            }
+            const HostWords virt_host{hv_idx.data(), hv_words.data()};
+            const DevRows virt_rows{d_vptr2.p, d_vidx.p, d_vval.p};
+            rcv = build_tiled(p->by_var, vptr2.data(), nullptr, nullptr, VRX_LDS_RW_CELL, VRX_LDS_SLAB_BYTES / 256,
+                              guard, 1, 0, sv, p->n_cu, &virt_rows, 2 * n_var, (n_cell + 1) / 2, vnnz, nullptr,
+                              hv_idx.empty() ? nullptr : &virt_host);
+        } else {
+            rcv = build_tiled(p->by_var, rptr.data(), nullptr, nullptr, VRX_LDS_RW_VARIANT, slab_var, guard,
+                              var_form == 2 ? 2 : 0, 0, sv, p->n_cu, &var_rows);
+        }
+        if (rcv) return rcv;
+        return hipStreamSynchronize(sv) == hipSuccess ? VRX_OK : VRX_ERR_HIP;
+    };
+    VRX_HIP(hipStreamSynchronize(s));  // (the rows both builds read are complete)
+    const bool concurrent = env_int("VIREO_BUILD_CONCURRENT", 1) != 0 &&
+                            nnz < (int64_t)env_int("VIREO_BUILD_CONCURRENT_MAX_MNNZ", 1000) * 1000000;
+    std::thread var_thread;
+    int rc_var = VRX_OK;
+    std::string err_var;
+    hipStream_t s2 = nullptr;
+    if (concurrent) {
+        VRX_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        const int dev_id = p->device;
+        var_thread = std::thread([&, dev_id] {
+            if (hipSetDevice(dev_id) != hipSuccess) {
+                rc_var = VRX_ERR_HIP;
+                err_var = "hipSetDevice failed on the variant orientation's build thread";
+                return;
+            }
+            rc_var = build_var(s2);
+            if (rc_var) err_var = vrx_last_error();
+        });
+    }
+    JoinGuard var_guard{var_thread};
+    const HostCounts cell_host{rowidx, ad, dp};
     if (early.joinable()) early.join();
-    lap("wait for the early cell greedy");
     rc = build_tiled(p->by_cell, colptr, nullptr, nullptr, rw_cell, slab_cell, guard, cell_form, 1, s,
                      p->n_cu, &cell_rows, -1, -1, -1, &cell_host, nullptr, &cell_layout);
-    if (rc) return rc;
-    if (var_form == 3) {
-        lap("cell stream");
-        if (helper.joinable()) helper.join();
-        lap("wait for the variant rows' download");
-        if (helper_err != hipSuccess) {
-            vrx_set_error("balanced slabs: download of the variant rows failed: %s", hipGetErrorString(helper_err));
-            return VRX_ERR_HIP;
-        }
-        const HostWords virt_host{hv_idx.data(), hv_words.data()};
-        const DevRows virt_rows{d_vptr2.p, d_vidx.p, d_vval.p};
-        rc = build_tiled(p->by_var, vptr2.data(), nullptr, nullptr, VRX_LDS_RW_CELL, VRX_LDS_SLAB_BYTES / 256,
-                         guard, 1, 0, s, p->n_cu, &virt_rows, 2 * n_var, (n_cell + 1) / 2, vnnz, nullptr,
-                         hv_idx.empty() ? nullptr : &virt_host);
-        if (rc) return rc;
-        VRX_HIP(hipStreamSynchronize(s));
-    } else {
-        rc = build_tiled(p->by_var, rptr.data(), nullptr, nullptr, VRX_LDS_RW_VARIANT, slab_var, guard,
-                         var_form == 2 ? 2 : 0, 0, s, p->n_cu, &var_rows);
-        if (rc) return rc;
+    lap("cell stream");
+    if (concurrent) {
+        var_thread.join();
+        (void)hipStreamDestroy(s2);
+        lap("wait for the variant stream (built beside it)");
     }
+    if (rc) return rc;
+    if (!concurrent) {
+        rc_var = build_var(s);
+        lap("variant stream");
+    } else if (rc_var) {
+        vrx_set_error("%s", err_var.c_str());
+    }
+    if (rc_var) return rc_var;
     VRX_HIP(hipStreamSynchronize(s));
     if (!p->by_cell.tiled.ready || !p->by_var.tiled.ready) {  // rejected by the padding guard
         for (Orient* o : {&p->by_cell, &p->by_var}) {
@@ -1509,7 +1546,6 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
         }
         return VRX_OK;
     }
-    lap("variant stream");
     *built = true;
     return VRX_OK;
 }
