@@ -808,6 +808,9 @@ def test_balance_policy_order_of_precedence(monkeypatch):
     assert balance_policy() is False
     assert balance_policy(expected_iterations=840) is False        # bench.py's c4 job: 32 x 20 + 200
     assert balance_policy(expected_iterations=1200) is True        # vireo's defaults: 50 x 20 + 200
+    assert balance_policy(expected_iterations=1200, nnz=10 ** 8) is True
+    assert balance_policy(expected_iterations=1200, nnz=16 * 10 ** 8) is False      # 16x c3: from 6 000 on
+    assert balance_policy(expected_iterations=6000, nnz=16 * 10 ** 8) is True
     assert balance_policy(balance=False, expected_iterations=10 ** 6) is False
     assert balance_policy(balance=True) is True
     monkeypatch.setenv("VIREO_BALANCE_MIN_ITERS", "500")

@@ -87,15 +87,16 @@ def merge_counts(AD, DP):
     return ((n_var, n_cell), colptr, rowidx, ad, dp)
 
 
-def balance_policy(balance=None, expected_iterations=None):
+def balance_policy(balance=None, expected_iterations=None, nnz=None):
     """Should the problem be built with *balanced slabs* (``vrx_problem_create2``, VRX_PROBLEM_BALANCED)?
 
-    They shorten the sparse passes by 10-17 % at c3 and cost a one-off ~0.06 s at 1e8 entries (break-even at c3: ~800
-    iterations on the same problem).  ``balance`` True / False decides; None: the
-    environment (VIREO_BALANCE=1 / 0), else on when the caller expects at least VIREO_BALANCE_MIN_ITERS
-    iterations (default 1200; ``vireo_wrap`` announces n_init x max_iter_init + 200).  The library applies the
-    flag only where it can (LDS-resident passes on AD/BD words, no split rows); ``DeviceCounts.build_info``
-    says what was built."""
+    They shorten the sparse passes by 15-17 % at c3 and cost a one-off ~0.065 s at 1e8 entries (break-even at
+    c3: ~800 iterations on the same problem).  ``balance`` True / False decides; None: the environment
+    (VIREO_BALANCE=1 / 0), else on when the caller expects at least VIREO_BALANCE_MIN_ITERS iterations (default
+    1200; ``vireo_wrap`` announces n_init x max_iter_init + 200) -- five times as many from 5e8 entries on,
+    where the build's transient buffers (tens of GB allocated and freed) cost more than in proportion: 16x c3
+    builds in 12.9 instead of 4.8 s and breaks even at ~5 000 iterations.  The library applies the flag only
+    where it can (LDS-resident passes on AD/BD words); ``DeviceCounts.build_info`` says what was built."""
     import os
     if balance is not None:
         return bool(balance)
@@ -103,6 +104,8 @@ def balance_policy(balance=None, expected_iterations=None):
     if env in ("0", "1"):
         return env == "1"
     need = int(os.environ.get("VIREO_BALANCE_MIN_ITERS", "1200"))
+    if nnz is not None and nnz >= 500_000_000:
+        need *= 5
     return expected_iterations is not None and expected_iterations >= need
 
 
@@ -124,7 +127,7 @@ class DeviceCounts:
         self.nnz = int(rowidx.size)
         self.device = device
         self._h = C.c_void_p()
-        flags = _lib.PROBLEM_BALANCED if balance_policy(balance, expected_iterations) else 0
+        flags = _lib.PROBLEM_BALANCED if balance_policy(balance, expected_iterations, self.nnz) else 0
         _lib.check(_lib.lib().vrx_problem_create2(
             device, self.n_var, self.n_cell, self.nnz,
             colptr.ctypes.data_as(C.POINTER(C.c_int64)),

@@ -1286,6 +1286,7 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
     if (p->want_balance && host_greedy && forms.cell == 1 && env_int("VIREO_BALANCE_EARLY", 1) != 0) {
         const int rw0 = rw_cell, form0 = forms.cell;
         early = std::thread([&, rw0, form0] {
+          try {
             const auto t0 = std::chrono::steady_clock::now();
             TileLayout& L = cell_layout;
             if (tile_layout(L, colptr, n_cell, n_var, nnz, rw0, slab_cell, form0, p->n_cu) != VRX_OK) {
@@ -1298,6 +1299,10 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
             greedy_tiles(L, false, colptr, rowidx, words.data(), n_cell, L.posmap, L.perm, L.tile_of_row);
             L.greedy_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             L.greedy_done = true;
+          } catch (const std::exception&) {  // (out of memory: build_tiled computes -- or fails -- by itself)
+            cell_layout.ptr = nullptr;
+            cell_layout.greedy_done = false;
+          }
         });
     }
     JoinGuard early_guard{early};
@@ -1497,6 +1502,12 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
     int rc_var = VRX_OK;
     std::string err_var;
     hipStream_t s2 = nullptr;
+    struct StreamGuard {  // (destroyed after the thread that uses it has been joined: declared before its guard)
+        hipStream_t& st;
+        ~StreamGuard() {
+            if (st) (void)hipStreamDestroy(st);
+        }
+    } s2_guard{s2};
     if (concurrent) {
         VRX_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
         const int dev_id = p->device;
@@ -1506,8 +1517,13 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
                 err_var = "hipSetDevice failed on the variant orientation's build thread";
                 return;
             }
-            rc_var = build_var(s2);
-            if (rc_var) err_var = vrx_last_error();
+            try {
+                rc_var = build_var(s2);
+                if (rc_var) err_var = vrx_last_error();
+            } catch (const std::exception& e) {  // (a throw must not leave a thread)
+                rc_var = VRX_ERR_NOMEM;
+                err_var = std::string("variant orientation's build: ") + e.what();
+            }
         });
     }
     JoinGuard var_guard{var_thread};
@@ -1518,7 +1534,6 @@ static int device_build(vrx_problem* p, const int64_t* colptr, const int32_t* ro
     lap("cell stream");
     if (concurrent) {
         var_thread.join();
-        (void)hipStreamDestroy(s2);
         lap("wait for the variant stream (built beside it)");
     }
     if (rc) return rc;
@@ -1558,9 +1573,28 @@ extern "C" int vrx_problem_create(int device, int64_t n_var, int64_t n_cell, int
                                env_int("VIREO_BALANCE", 0) != 0 ? VRX_PROBLEM_BALANCED : 0, out);
 }
 
+static int problem_create2(int device, int64_t n_var, int64_t n_cell, int64_t nnz, const int64_t* colptr,
+                           const int32_t* rowidx, const int32_t* ad, const int32_t* dp, int32_t flags,
+                           vrx_problem** out);
+
 extern "C" int vrx_problem_create2(int device, int64_t n_var, int64_t n_cell, int64_t nnz,
                                    const int64_t* colptr, const int32_t* rowidx, const int32_t* ad,
                                    const int32_t* dp, int32_t flags, vrx_problem** out) {
+    try {  // (the build allocates host arrays of the problem's size: out of memory is a status, not a throw
+           //  across the C boundary)
+        return problem_create2(device, n_var, n_cell, nnz, colptr, rowidx, ad, dp, flags, out);
+    } catch (const std::bad_alloc&) {
+        vrx_set_error("vrx_problem_create: out of host memory");
+        return VRX_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        vrx_set_error("vrx_problem_create: %s", e.what());
+        return VRX_ERR_UNSUPPORTED;
+    }
+}
+
+static int problem_create2(int device, int64_t n_var, int64_t n_cell, int64_t nnz, const int64_t* colptr,
+                           const int32_t* rowidx, const int32_t* ad, const int32_t* dp, int32_t flags,
+                           vrx_problem** out) {
     VRX_REQUIRE(out, "vrx_problem_create: null output");
     *out = nullptr;
     VRX_REQUIRE(n_var > 0 && n_cell > 0 && nnz >= 0, "vrx_problem_create: bad shape");
