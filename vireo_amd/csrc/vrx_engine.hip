@@ -788,10 +788,20 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
             bool dev_greedy = !(gm && !strcmp(gm, "host")) && !pre_done && blocks.bs <= 64 &&
                               (tile_pos + 1) * 64 + 2 * VRX_BAL_BATCH * 4 <= 160 * 1024 && tile_pos <= 4095 && n_cols_all < (int64_t)INT32_MAX &&
                               n_groups < ((int64_t)1 << 20) && (int64_t)t.n_tile * tile_pos < (int64_t)INT32_MAX;
+            // (the sort buffers of the greedy's preparation serve the relabel below as well: multi-GB
+            //  allocations and releases are what a large build spends its time on)
+            DevBuf<uint64_t> k_in, k_out;
+            DevBuf<uint32_t> v_in, v_out;
+            VRX_HIP(k_in.alloc((size_t)o_nnz));
+            VRX_HIP(k_out.alloc((size_t)o_nnz));
+            VRX_HIP(v_in.alloc((size_t)o_nnz));
+            VRX_HIP(v_out.alloc((size_t)o_nnz));
             if (dev_greedy) {
                 DevBuf<int32_t> d_tpos, d_flags;
-                DevBuf<uint64_t> bk_in, bk_out, ok_in, ok_out;
-                DevBuf<uint32_t> bv_in, bv_out, d_cptr, d_deg, d_ostart, d_ovals;
+                DevBuf<uint64_t> ok_in, ok_out;
+                DevBuf<uint32_t> d_cptr, d_deg, d_ostart, d_ovals;
+                DevBuf<uint64_t>&bk_in = k_in, &bk_out = k_out;
+                DevBuf<uint32_t>&bv_in = v_in, &bv_out = v_out;
                 DevBuf<int64_t> d_seg;
                 DevBuf<char> tmp;
                 int cbits = 1, tbits = 1, gbits = 1;
@@ -803,10 +813,6 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
                 VRX_HIP(d_tpos.upload(tpos.data(), tpos.size(), s));
                 const int32_t zero2[2] = {0, 0};
                 VRX_HIP(d_flags.upload(zero2, 2, s));
-                VRX_HIP(bk_in.alloc((size_t)o_nnz));
-                VRX_HIP(bk_out.alloc((size_t)o_nnz));
-                VRX_HIP(bv_in.alloc((size_t)o_nnz));
-                VRX_HIP(bv_out.alloc((size_t)o_nnz));
                 vrx_bal_keys<<<nbe, VRX_BLOCK, 0, s>>>(o_nnz, n_unit_rows, du_ptr, du_idx, du_val, d_tpos.p, (int)tile_pos,
                                                        t.n_tile, cbits, bk_in.p, bv_in.p);
                 VRX_HIP(hipGetLastError());
@@ -840,8 +846,6 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
                 VRX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp3, d_deg.p, d_ostart.p, (size_t)n_cols_all, s));
                 uint32_t n_stream = 0;  // the entries that count = first entry of the column behind the last one
                 VRX_HIP(hipMemcpyAsync(&n_stream, d_cptr.p + n_cols_all, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-                bk_in.release();
-                bv_in.release();
                 VRX_HIP(d_ovals.alloc((size_t)o_nnz));
                 vrx_bal_stream<<<nbc, VRX_BLOCK, 0, s>>>(n_cols_all, o_n_contract, ok_out.p, cbits, blocks.nb, d_cptr.p,
                                                          bv_out.p, d_ostart.p, d_ovals.p);
@@ -915,12 +919,6 @@ static int build_tiled(Orient& o, const int64_t* ptr, const int32_t* idx, const 
                     VRX_HIP(t.perm.upload(perm.data(), perm.size(), s));
                 }
             }
-            DevBuf<uint64_t> k_in, k_out;
-            DevBuf<uint32_t> v_in, v_out;
-            VRX_HIP(k_in.alloc((size_t)o_nnz));
-            VRX_HIP(k_out.alloc((size_t)o_nnz));
-            VRX_HIP(v_in.alloc((size_t)o_nnz));
-            VRX_HIP(v_out.alloc((size_t)o_nnz));
             const unsigned nbe = (unsigned)((o_nnz + VRX_BLOCK - 1) / VRX_BLOCK);
             int rbits = 1, pbits = 1;  // key = row << pbits | position: as few radix passes as the sizes need
             while (((int64_t)1 << rbits) < n_unit_rows) ++rbits;
